@@ -1,0 +1,240 @@
+/* lumenos oracle -- TEST INFRASTRUCTURE ONLY (see lo_common.h).
+ * Minimal BGV client side (keygen / encode / encrypt / decrypt / decode) so
+ * that the decrypted-value equalities the reference's tests assert
+ * (fhe/code_test.go:87-116, fhe/ligero_test.go:128-174) can be re-run without
+ * Go.  Conventions follow Lattigo's bgv package [LATTIGO-RECALL]: plaintexts
+ * are stored as m * T^-1 mod Q ("MSB" form), ciphertexts
+ * in the NTT domain, ternary secret, Gaussian error sigma = 3.2.  The
+ * randomness is a local xoshiro256** -- the reference's encryptions are
+ * randomised too, so no bit-level claim rides on it. */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "lo_common.h"
+#include "lo_internal.h"
+
+void lo_ntt_core(uint64_t *a, uint32_t N, uint64_t q, const uint64_t *psi_rev);
+void lo_intt_core(uint64_t *a, uint32_t N, uint64_t q, const uint64_t *psi_inv_rev, uint64_t n_inv);
+
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+void lo_rng_seed(lo_rng *r, uint64_t seed) {
+    for (int i = 0; i < 4; i++) { /* splitmix64 */
+        uint64_t z = (seed += 0x9e3779b97f4a7c15ULL);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        r->s[i] = z ^ (z >> 31);
+    }
+}
+
+uint64_t lo_rng_next(lo_rng *r) {
+    uint64_t *s = r->s;
+    uint64_t result = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0], s[3] ^= s[1], s[1] ^= s[2], s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+static uint64_t rng_uniform(lo_rng *r, uint64_t q) {
+    uint64_t lim = UINT64_MAX - (UINT64_MAX % q);
+    uint64_t x;
+    do x = lo_rng_next(r);
+    while (x >= lim);
+    return x % q;
+}
+
+int64_t lo_sample_gaussian(lo_rng *r) {
+    const double sigma = 3.2, bound = 19.2;
+    for (;;) {
+        double u1 = ((double)(lo_rng_next(r) >> 11) + 1.0) / 9007199254740993.0;
+        double u2 = (double)(lo_rng_next(r) >> 11) / 9007199254740992.0;
+        double g = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2) * sigma;
+        if (fabs(g) <= bound) return (int64_t)llround(g);
+    }
+}
+
+static void small_to_limb(const lo_params *p, const int64_t *coef, uint32_t mi, uint64_t *out) {
+    uint64_t q = p->mod[mi];
+    for (uint32_t k = 0; k < p->N; k++)
+        out[k] = coef[k] >= 0 ? (uint64_t)coef[k] % q : q - ((uint64_t)(-coef[k]) % q);
+    lo_limb_ntt(p, mi, out);
+}
+
+void lo_keygen_secret(const lo_params *p, lo_rng *r, uint64_t *sk) {
+    int64_t *c = (int64_t *)malloc(p->N * sizeof(int64_t));
+    for (uint32_t k = 0; k < p->N; k++) c[k] = (int64_t)(lo_rng_next(r) % 3) - 1;
+    for (uint32_t i = 0; i < p->L + p->K; i++) small_to_limb(p, c, i, sk + (size_t)i * p->N);
+    free(c);
+}
+
+void lo_keygen_public(const lo_params *p, lo_rng *r, const uint64_t *sk, uint64_t *pk) {
+    uint32_t N = p->N, L = p->L;
+    int64_t *e = (int64_t *)malloc(N * sizeof(int64_t));
+    uint64_t *en = (uint64_t *)malloc(N * sizeof(uint64_t));
+    for (uint32_t k = 0; k < N; k++) e[k] = lo_sample_gaussian(r);
+    for (uint32_t i = 0; i < L; i++) {
+        uint64_t q = p->mod[i];
+        uint64_t *b = pk + (size_t)i * N, *a = pk + (size_t)(L + i) * N;
+        small_to_limb(p, e, i, en);
+        for (uint32_t k = 0; k < N; k++) {
+            a[k] = rng_uniform(r, q);
+            b[k] = lo_submod(en[k], lo_mulmod(a[k], sk[(size_t)i * N + k], q), q);
+        }
+    }
+    free(en);
+    free(e);
+}
+
+void lo_keygen_evk(const lo_params *p, lo_rng *r, const uint64_t *sk_in, const uint64_t *sk_out,
+                   uint64_t *evk) {
+    /* [LATTIGO-RECALL] genEvaluationKey: digit d, limb j:
+     *   b = -a*sk_out + e (+ P*sk_in on the Q limbs of digit d),  a uniform */
+    uint32_t N = p->N, L = p->L, K = p->K, LK = L + K, beta = lo_beta(p, L);
+    int64_t *e = (int64_t *)malloc(N * sizeof(int64_t));
+    uint64_t *en = (uint64_t *)malloc(N * sizeof(uint64_t));
+    for (uint32_t d = 0; d < beta; d++) {
+        for (uint32_t k = 0; k < N; k++) e[k] = lo_sample_gaussian(r);
+        for (uint32_t j = 0; j < LK; j++) {
+            uint64_t q = p->mod[j];
+            uint64_t *b = evk + (((size_t)d * 2 + 0) * LK + j) * N;
+            uint64_t *a = evk + (((size_t)d * 2 + 1) * LK + j) * N;
+            small_to_limb(p, e, j, en);
+            uint64_t pfac = 0;
+            if (j < L && j >= d * K && j < (d + 1) * K) {
+                pfac = 1;
+                for (uint32_t t = 0; t < K; t++) pfac = lo_mulmod(pfac, p->mod[L + t] % q, q);
+            }
+            for (uint32_t k = 0; k < N; k++) {
+                a[k] = rng_uniform(r, q);
+                uint64_t v = lo_submod(en[k], lo_mulmod(a[k], sk_out[(size_t)j * N + k], q), q);
+                if (pfac) v = lo_addmod(v, lo_mulmod(pfac, sk_in[(size_t)j * N + k], q), q);
+                b[k] = v;
+            }
+        }
+    }
+    free(en);
+    free(e);
+}
+
+void lo_keygen_galois(const lo_params *p, lo_rng *r, const uint64_t *sk, uint64_t gal_el,
+                      uint64_t *evk) {
+    /* [LATTIGO-RECALL] GenGaloisKey: "we encrypt [-a*pi_{k^-1}(sk) + sk, a]" */
+    uint32_t N = p->N, LK = p->L + p->K;
+    uint64_t two_n = 2ULL * N;
+    /* galEl^-1 mod 2N (2N is a power of two; galEl odd) */
+    uint64_t inv = 1;
+    for (int i = 0; i < 6; i++) inv = (inv * (2 - gal_el * inv)) & (two_n - 1);
+    uint32_t *index = (uint32_t *)malloc(N * sizeof(uint32_t));
+    lo_automorphism_index(p, inv, index);
+    uint64_t *sk_out = (uint64_t *)malloc((size_t)LK * N * sizeof(uint64_t));
+    for (uint32_t j = 0; j < LK; j++)
+        for (uint32_t k = 0; k < N; k++) sk_out[(size_t)j * N + k] = sk[(size_t)j * N + index[k]];
+    lo_keygen_evk(p, r, sk, sk_out, evk);
+    free(sk_out);
+    free(index);
+}
+
+void lo_encode(const lo_params *p, const uint64_t *values, uint32_t nvalues, uint32_t nl,
+               uint64_t *pt) {
+    /* [LATTIGO-RECALL] Encoder.Encode: slots -> INTT over Z_T -> RingT2Q with
+     * scaleUp (multiply by T^-1 mod q_i) -> NTT */
+    uint32_t N = p->N;
+    uint64_t *m = (uint64_t *)calloc(N, sizeof(uint64_t));
+    for (uint32_t i = 0; i < nvalues && i < N; i++) m[p->slot_index[i]] = values[i] % p->T;
+    lo_intt_core(m, N, p->T, p->psiT_inv_rev, p->n_invT);
+    for (uint32_t l = 0; l < nl; l++) {
+        uint64_t q = p->mod[l], tinv = lo_invmod(p->T % q, q);
+        uint64_t *o = pt + (size_t)l * N;
+        for (uint32_t k = 0; k < N; k++) o[k] = lo_mulmod(m[k] % q, tinv, q);
+        lo_limb_ntt(p, l, o);
+    }
+    free(m);
+}
+
+void lo_encrypt_pk(const lo_params *p, lo_rng *r, const uint64_t *pk, const uint64_t *pt,
+                   uint32_t nl, uint64_t *ct) {
+    uint32_t N = p->N, L = p->L;
+    int64_t *u = (int64_t *)malloc(N * sizeof(int64_t));
+    int64_t *e0 = (int64_t *)malloc(N * sizeof(int64_t));
+    int64_t *e1 = (int64_t *)malloc(N * sizeof(int64_t));
+    uint64_t *un = (uint64_t *)malloc(N * sizeof(uint64_t));
+    uint64_t *en = (uint64_t *)malloc(N * sizeof(uint64_t));
+    for (uint32_t k = 0; k < N; k++) {
+        u[k] = (int64_t)(lo_rng_next(r) % 3) - 1;
+        e0[k] = lo_sample_gaussian(r);
+        e1[k] = lo_sample_gaussian(r);
+    }
+    for (uint32_t l = 0; l < nl; l++) {
+        uint64_t q = p->mod[l];
+        small_to_limb(p, u, l, un);
+        uint64_t *c0 = ct + (size_t)l * N, *c1 = ct + (size_t)(nl + l) * N;
+        small_to_limb(p, e0, l, en);
+        for (uint32_t k = 0; k < N; k++) {
+            uint64_t v = lo_addmod(lo_mulmod(un[k], pk[(size_t)l * N + k], q), en[k], q);
+            c0[k] = pt ? lo_addmod(v, pt[(size_t)l * N + k], q) : v;
+        }
+        small_to_limb(p, e1, l, en);
+        for (uint32_t k = 0; k < N; k++)
+            c1[k] = lo_addmod(lo_mulmod(un[k], pk[(size_t)(L + l) * N + k], q), en[k], q);
+    }
+    free(en), free(un), free(e1), free(e0), free(u);
+}
+
+/* T * (c0 + c1*s), coefficient domain, per limb: [nl][N] */
+void lo_decrypt_phase(const lo_params *p, const uint64_t *sk, const uint64_t *ct, uint32_t nl,
+                      uint64_t *phase) {
+    uint32_t N = p->N;
+    for (uint32_t l = 0; l < nl; l++) {
+        uint64_t q = p->mod[l], t = p->T % q;
+        uint64_t *o = phase + (size_t)l * N;
+        for (uint32_t k = 0; k < N; k++)
+            o[k] = lo_addmod(ct[(size_t)l * N + k],
+                             lo_mulmod(ct[(size_t)(nl + l) * N + k], sk[(size_t)l * N + k], q), q);
+        lo_limb_intt(p, l, o);
+        for (uint32_t k = 0; k < N; k++) o[k] = lo_mulmod(o[k], t, q);
+    }
+}
+
+/* coefficients mod T -> slots (Encoder.Decode), divided by `scale` */
+void lo_decode_coeffs(const lo_params *p, const uint64_t *m, uint64_t scale, uint64_t *values,
+                      uint32_t nvalues) {
+    uint32_t N = p->N;
+    uint64_t *t = (uint64_t *)malloc(N * sizeof(uint64_t));
+    memcpy(t, m, N * sizeof(uint64_t));
+    lo_ntt_core(t, N, p->T, p->psiT_rev);
+    uint64_t sinv = lo_invmod(scale % p->T, p->T);
+    for (uint32_t i = 0; i < nvalues && i < N; i++)
+        values[i] = lo_mulmod(t[p->slot_index[i]], sinv, p->T);
+    free(t);
+}
+
+int lo_decrypt_decode(const lo_params *p, const uint64_t *sk, const uint64_t *ct, uint32_t nl,
+                      uint64_t scale, uint64_t *values, uint32_t nvalues) {
+    if (nl < 1 || nl > 2) return -1;
+    uint32_t N = p->N;
+    uint64_t *ph = (uint64_t *)malloc((size_t)nl * N * sizeof(uint64_t));
+    uint64_t *m = (uint64_t *)malloc(N * sizeof(uint64_t));
+    lo_decrypt_phase(p, sk, ct, nl, ph);
+    uint64_t q0 = p->mod[0], T = p->T;
+    if (nl == 1) {
+        for (uint32_t k = 0; k < N; k++) {
+            uint64_t y = ph[k];
+            m[k] = y > (q0 >> 1) ? (T - ((q0 - y) % T)) % T : y % T;
+        }
+    } else {
+        uint64_t q1 = p->mod[1], q0inv = lo_invmod(q0 % q1, q1);
+        lo_u128 Q = (lo_u128)q0 * q1;
+        for (uint32_t k = 0; k < N; k++) {
+            uint64_t y0 = ph[k], y1 = ph[N + k];
+            uint64_t h = lo_mulmod(lo_submod(y1, y0 % q1, q1), q0inv, q1);
+            lo_u128 y = (lo_u128)y0 + (lo_u128)q0 * h;
+            m[k] = y > (Q >> 1) ? (T - (uint64_t)((Q - y) % T)) % T : (uint64_t)(y % T);
+        }
+    }
+    lo_decode_coeffs(p, m, scale, values, nvalues);
+    free(m);
+    free(ph);
+    return 0;
+}

@@ -1,0 +1,233 @@
+/*
+ * lumenos oracle -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, single-threaded-by-default CPU restatement of the reference's
+ * server-side homomorphic Ligero prover (fhe/{code,ntt,ligero,bfv}.go and the
+ * core/ helpers they call).  It exists so that the HIP product path in
+ * lumenos_amd/csrc can be checked bit-for-bit on the same inputs.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker.  Nothing under lumenos_amd/
+ * links, imports or falls back to it.
+ *
+ * PARITY STATUS: "parity unpinned" at the ciphertext-bit level.  The
+ * reference is Go; its arithmetic lives in the un-vendored dependency
+ * github.com/tuneinsight/lattigo/v6 v6.1.2-0.20250520151126-84f6bc33cb5b
+ * (go.mod:5) and neither a Go toolchain nor that module is present here.
+ * What IS pinned by the reference's own on-disk known answers:
+ *   - the ChaCha20 witness recipe (core/utils.go:46-82) against the four
+ *     P(x=1) values in results/baseline/client/bench_*.txt:22,
+ *   - queries = 309 (results/baseline/server/bench_*.txt:19),
+ *   - Q-chain lengths 10/11/12/12 (bench_*.txt:16),
+ *   - SHA-256 (FIPS 180-4 vectors), ChaCha20 (RFC 8439 vectors),
+ *   - the decrypted-value equalities the reference's tests assert
+ *     (fhe/code_test.go:110-116, fhe/ligero_test.go:150-174), re-run here on
+ *     this oracle's own BGV.
+ * Lattigo semantics restated from its published algorithm are marked
+ * [LATTIGO-RECALL] at each function.
+ */
+#ifndef LO_COMMON_H
+#define LO_COMMON_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef unsigned __int128 lo_u128;
+
+#define LO_MAX_LIMBS 24 /* Q limbs + P limbs */
+
+/* ---------------------------------------------------------------- modarith */
+uint64_t lo_addmod(uint64_t a, uint64_t b, uint64_t q);
+uint64_t lo_submod(uint64_t a, uint64_t b, uint64_t q);
+uint64_t lo_mulmod(uint64_t a, uint64_t b, uint64_t q);
+uint64_t lo_powmod(uint64_t a, uint64_t e, uint64_t q);
+uint64_t lo_invmod(uint64_t a, uint64_t q); /* q prime */
+int lo_is_prime(uint64_t n);
+/* smallest primitive root of prime q (Lattigo ring.PrimitiveRoot) */
+uint64_t lo_primitive_root(uint64_t q);
+uint64_t lo_bitrev(uint64_t x, int bits);
+/* NTT-friendly primes == 1 mod nth_root around 2^bits, alternating
+ * above/below ([LATTIGO-RECALL] ring.NTTFriendlyPrimesGenerator
+ * .NextAlternatingPrime).  Writes `count` primes, skipping any in
+ * `exclude[0..nexclude)`.  Returns 0 on success. */
+int lo_gen_primes(int bits, uint64_t nth_root, int count, const uint64_t *exclude,
+                  int nexclude, uint64_t *out);
+
+/* ------------------------------------------------ plain field (core/field.go) */
+/* RootsForward table of core.PrimeField (core/field.go:138-197): entry
+ * bitrev(j) = psi^j * 2^64 mod T, psi = g^((T-1)/(2*fieldN)), g = smallest
+ * primitive root.  `roots` has fieldN entries. */
+int lo_field_roots_forward(uint64_t T, uint32_t fieldN, uint64_t *roots);
+/* core.SqrtFactor (core/math.go:25-36) */
+uint32_t lo_sqrt_factor(uint32_t n);
+/* core.NTT (core/ntt.go:3-98): in place on v[0..len), chunk size `size`. */
+void lo_plain_ntt(uint64_t *v, uint32_t len, uint32_t size, uint64_t T,
+                  const uint64_t *roots, uint32_t fieldN);
+/* core.Encode (core/code.go:3-23): out has cols*rho_inv entries. */
+void lo_plain_encode(const uint64_t *row, uint32_t cols, uint32_t rho_inv, uint64_t T,
+                     const uint64_t *roots, uint32_t fieldN, uint64_t *out);
+/* Program-order twiddle-index trace of nttInner:
+ * base cases contribute 4 (size 4) and 8,4,-1,4,4 (size 8).  Returns count,
+ * writes up to cap entries. */
+size_t lo_ntt_twiddle_trace(uint32_t len, uint32_t size, uint32_t fieldN, int32_t *out,
+                            size_t cap);
+
+/* ------------------------------------------------------------- chacha/witness */
+void lo_chacha20_xor(const uint8_t key[32], const uint8_t nonce[12], uint32_t counter,
+                     uint8_t *buf, size_t len);
+/* core.RandomMatrixRowMajor (core/utils.go:46-82): row-major rows*cols */
+void lo_witness_row_major(uint32_t rows, uint32_t cols, uint64_t T, uint64_t *out);
+
+/* ------------------------------------------------------------------- sha/merkle */
+void lo_sha256(const uint8_t *data, size_t len, uint8_t out[32]);
+/* core.NewTree (core/tree.go:76-163) over precomputed leaf digests.
+ * nodes: caller buffer for all levels; returns total node count written.
+ * Level 0 = leaves.  Odd node is paired with itself (tree.go:127-131). */
+size_t lo_merkle_build(const uint8_t *leaf_digests, uint32_t nleaves, uint8_t *nodes,
+                       size_t cap_nodes, uint8_t root[32]);
+/* core.GetMerklePath (tree.go:174-221): sibling hashes bottom-up; returns depth */
+uint32_t lo_merkle_path(const uint8_t *nodes, uint32_t nleaves, uint32_t index,
+                        uint8_t *path /* depth*32 */);
+/* core.VerifyMerklePath (tree.go:225-268) */
+int lo_merkle_verify(const uint8_t leaf_digest[32], const uint8_t *path, uint32_t depth,
+                     const uint8_t root[32], uint32_t index);
+
+/* -------------------------------------------------------------- merlin transcript */
+typedef struct lo_transcript lo_transcript;
+lo_transcript *lo_transcript_new(const char *label);
+void lo_transcript_free(lo_transcript *t);
+void lo_transcript_append(lo_transcript *t, const char *label, const uint8_t *msg, uint32_t len);
+void lo_transcript_challenge(lo_transcript *t, const char *label, uint8_t *out, uint32_t len);
+uint64_t lo_transcript_sample_u64(lo_transcript *t, const char *label);
+
+/* ------------------------------------------------------------------ RNS ring */
+typedef struct lo_params {
+    uint32_t logN, N;
+    uint32_t L; /* number of Q limbs */
+    uint32_t K; /* number of P limbs */
+    uint64_t T;
+    uint64_t mod[LO_MAX_LIMBS];        /* q_0..q_{L-1}, p_0..p_{K-1} */
+    uint64_t psi[LO_MAX_LIMBS];        /* primitive 2N-th root per modulus */
+    uint64_t *psi_rev[LO_MAX_LIMBS];   /* psi^bitrev(i), standard form */
+    uint64_t *psi_inv_rev[LO_MAX_LIMBS];
+    uint64_t n_inv[LO_MAX_LIMBS];
+    /* plaintext ring Z_T[X]/(X^N+1) */
+    uint64_t psiT;
+    uint64_t *psiT_rev, *psiT_inv_rev;
+    uint64_t n_invT;
+    uint32_t *slot_index; /* encoder index matrix, N entries */
+} lo_params;
+
+/* fhe.GenerateBGVParamsForNTT (fhe/bfv.go:121-188): logQ/logP bit sizes.
+ * Returns the number of Q primes, writes logq[0..], logp[0..1]. */
+int lo_bgv_param_bits(uint32_t ntt_size, uint32_t logN, uint64_t T, int *logq, int *nq,
+                      int *logp, int *np);
+/* Build params from explicit moduli (drop-in: the Go host passes Lattigo's) */
+lo_params *lo_params_new(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *moduli,
+                         uint64_t T);
+/* Build params the way the reference does for (cols, logN, T) */
+lo_params *lo_params_for_ntt(uint32_t cols, uint32_t logN, uint64_t T);
+void lo_params_free(lo_params *p);
+uint64_t lo_params_modulus(const lo_params *p, uint32_t i);
+uint64_t lo_params_psi(const lo_params *p, uint32_t i);
+uint32_t lo_params_L(const lo_params *p);
+uint32_t lo_params_K(const lo_params *p);
+
+/* Lattigo SubRing.NTT / INTT [LATTIGO-RECALL]: negacyclic, natural-order in,
+ * bit-reversed-evaluation out; canonical [0,q) in and out. */
+void lo_limb_ntt(const lo_params *p, uint32_t mod_idx, uint64_t *a);
+void lo_limb_intt(const lo_params *p, uint32_t mod_idx, uint64_t *a);
+
+/* ------------------------------------------------------ ciphertext-axis NTT */
+/* Ciphertext layout everywhere: [poly(2)][limb(nl)][N] u64, NTT domain,
+ * canonical.  A "set" is [ct][poly][limb][N]. */
+/* Evaluator.Mul(ct, uint64) scalar seen by limb i: centre_T(w) mod q_i
+ * (SURVEY Appendix A.2 [LATTIGO-RECALL]). */
+uint64_t lo_centered_scalar(uint64_t w, uint64_t T, uint64_t q);
+/* fhe.NTT (fhe/ntt.go:12-281), literal control flow, in place on `count`
+ * ciphertexts of nl limbs; permutes ciphertexts exactly as the Go pointer
+ * swaps/transposes do. */
+void lo_ct_ntt(const lo_params *p, uint64_t *set, uint32_t count, uint32_t nl, uint32_t size,
+               const uint64_t *roots, uint32_t fieldN);
+/* fhe.Encode (fhe/code.go:8-34): out = [cols*rho_inv] cts.  zero_ct is the
+ * single fresh encryption of the zero vector (code.go:15-22). */
+void lo_ct_encode(const lo_params *p, const uint64_t *matrix, uint32_t cols, uint32_t nl,
+                  uint32_t rho_inv, const uint64_t *zero_ct, const uint64_t *roots,
+                  uint32_t fieldN, uint64_t *out);
+
+/* ------------------------------------------------------------- evaluator ops */
+/* Evaluator.Rescale (SURVEY A.3 [LATTIGO-RECALL] DivRoundByLastModulusNTT):
+ * in has nl limbs, out has nl-1 limbs. */
+void lo_rescale(const lo_params *p, const uint64_t *in, uint32_t nl, uint64_t *out);
+/* loop `for ct.Level() > 1` (fhe/ligero.go:149,271,331): out has 2 limbs */
+void lo_rescale_to_level1(const lo_params *p, const uint64_t *in, uint32_t nl, uint64_t *out);
+/* Evaluator.MulNew(ct, pt): pt = [nl][N] NTT-domain canonical */
+void lo_mul_plain(const lo_params *p, const uint64_t *ct, const uint64_t *pt, uint32_t nl,
+                  uint64_t *out);
+
+/* Galois / evaluation keys: [digit(beta)][b|a (2)][limb(L+K)][N], NTT
+ * domain, standard (non-Montgomery) form. */
+uint32_t lo_beta(const lo_params *p, uint32_t nl);
+size_t lo_evk_words(const lo_params *p);
+uint64_t lo_galois_element(const lo_params *p, int64_t k); /* 5^k mod 2N */
+uint64_t lo_galois_row_swap(const lo_params *p);           /* 2N-1 */
+void lo_automorphism_index(const lo_params *p, uint64_t gal_el, uint32_t *index);
+/* one hoisted rotation: out = sigma_galEl(ct) switched back to s
+ * [LATTIGO-RECALL] Evaluator.AutomorphismHoisted */
+void lo_automorphism(const lo_params *p, const uint64_t *ct, uint32_t nl, uint64_t gal_el,
+                     const uint64_t *evk, uint64_t *out);
+/* Evaluator.InnerSum(ct, 1, n, out) for n a power of two (SURVEY A.5, App.
+ * D-1): gal_els/evks are the log2(n) keys in the order used. */
+uint32_t lo_inner_sum_galois_elements(const lo_params *p, uint32_t n, uint64_t *gal_els);
+void lo_inner_sum(const lo_params *p, const uint64_t *ct, uint32_t nl, uint32_t n,
+                  const uint64_t *const *evks, uint64_t *out);
+
+/* ------------------------------------------------------- BGV (test harness) */
+typedef struct lo_rng {
+    uint64_t s[4];
+} lo_rng;
+void lo_rng_seed(lo_rng *r, uint64_t seed);
+uint64_t lo_rng_next(lo_rng *r);
+/* sk: ternary, stored NTT-domain over all L+K limbs: [L+K][N] */
+void lo_keygen_secret(const lo_params *p, lo_rng *r, uint64_t *sk);
+/* pk: [2][L][N] */
+void lo_keygen_public(const lo_params *p, lo_rng *r, const uint64_t *sk, uint64_t *pk);
+/* key switching key from sk_in to sk_out */
+void lo_keygen_evk(const lo_params *p, lo_rng *r, const uint64_t *sk_in, const uint64_t *sk_out,
+                   uint64_t *evk);
+void lo_keygen_galois(const lo_params *p, lo_rng *r, const uint64_t *sk, uint64_t gal_el,
+                      uint64_t *evk);
+/* Encoder.Encode [LATTIGO-RECALL]: slots -> pt [nl][N] NTT domain
+ * (m * T^-1 mod Q form) */
+void lo_encode(const lo_params *p, const uint64_t *values, uint32_t nvalues, uint32_t nl,
+               uint64_t *pt);
+/* Encryptor.EncryptNew with pk */
+void lo_encrypt_pk(const lo_params *p, lo_rng *r, const uint64_t *pk, const uint64_t *pt,
+                   uint32_t nl, uint64_t *ct);
+/* Decrypt + decode `nvalues` slots; ct must have nl <= 2 limbs (phase is
+ * CRT-reconstructed in 128 bits).  scale_inv: multiply decoded slots by this
+ * (mod T) to undo rescale scaling; pass 1 for none. */
+int lo_decrypt_decode(const lo_params *p, const uint64_t *sk, const uint64_t *ct, uint32_t nl,
+                      uint64_t scale, uint64_t *values, uint32_t nvalues);
+/* scale factor picked up by rescaling from nl_from limbs down to nl_to limbs:
+ * prod q_dropped^-1 mod T */
+uint64_t lo_rescale_scale(const lo_params *p, uint32_t nl_from, uint32_t nl_to);
+
+/* ---------------------------------------------------------------- ligero glue */
+/* calculateQueries (fhe/ligero.go:65-71) */
+int lo_calculate_queries(double security_bits, int rho_inv);
+/* leaf bytes of one level-1 ciphertext.  STAND-IN for Lattigo's
+ * rlwe.Ciphertext.WriteTo (fhe/ligero.go:156-157) whose header bytes are
+ * unknown offline: 16-byte header {u32 magic 'LMCT', u32 degree+1,
+ * u32 limbs, u32 N} then raw little-endian limbs [poly][limb][N]. */
+size_t lo_ct_serialized_size(uint32_t nl, uint32_t N);
+void lo_ct_serialize(const uint64_t *ct, uint32_t nl, uint32_t N, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

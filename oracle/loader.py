@@ -1,0 +1,418 @@
+"""ctypes loader for the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module (see oracle/lo_common.h).  Nothing under lumenos_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liblumen_oracle.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB
+
+
+def _p64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def _p32(a):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+def _p8(a):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u8p)
+
+
+class Oracle:
+    """Thin numpy-facing wrapper; every method names the C function it calls."""
+
+    def __init__(self):
+        build()
+        L = self.lib = C.CDLL(_LIB)
+        vp = C.c_void_p
+        sigs = {
+            "lo_mulmod": (C.c_uint64, [C.c_uint64] * 3),
+            "lo_powmod": (C.c_uint64, [C.c_uint64] * 3),
+            "lo_invmod": (C.c_uint64, [C.c_uint64] * 2),
+            "lo_is_prime": (C.c_int, [C.c_uint64]),
+            "lo_primitive_root": (C.c_uint64, [C.c_uint64]),
+            "lo_gen_primes": (C.c_int, [C.c_int, C.c_uint64, C.c_int, u64p, C.c_int, u64p]),
+            "lo_field_roots_forward": (C.c_int, [C.c_uint64, C.c_uint32, u64p]),
+            "lo_sqrt_factor": (C.c_uint32, [C.c_uint32]),
+            "lo_plain_ntt": (None, [u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, C.c_uint32]),
+            "lo_plain_encode": (None, [u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, C.c_uint32, u64p]),
+            "lo_ntt_twiddle_trace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, i32p, C.c_size_t]),
+            "lo_omega8_cubed": (C.c_uint64, [C.c_uint64, u64p]),
+            "lo_chacha20_xor": (None, [u8p, u8p, C.c_uint32, u8p, C.c_size_t]),
+            "lo_witness_row_major": (None, [C.c_uint32, C.c_uint32, C.c_uint64, u64p]),
+            "lo_sha256": (None, [u8p, C.c_size_t, u8p]),
+            "lo_merkle_build": (C.c_size_t, [u8p, C.c_uint32, u8p, C.c_size_t, u8p]),
+            "lo_merkle_path": (C.c_uint32, [u8p, C.c_uint32, C.c_uint32, u8p]),
+            "lo_merkle_verify": (C.c_int, [u8p, u8p, C.c_uint32, u8p, C.c_uint32]),
+            "lo_transcript_new": (vp, [C.c_char_p]),
+            "lo_transcript_free": (None, [vp]),
+            "lo_transcript_append": (None, [vp, C.c_char_p, u8p, C.c_uint32]),
+            "lo_transcript_challenge": (None, [vp, C.c_char_p, u8p, C.c_uint32]),
+            "lo_transcript_sample_u64": (C.c_uint64, [vp, C.c_char_p]),
+            "lo_bgv_param_bits": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, i32p, i32p, i32p, i32p]),
+            "lo_params_new": (vp, [C.c_uint32, C.c_uint32, C.c_uint32, u64p, C.c_uint64]),
+            "lo_params_for_ntt": (vp, [C.c_uint32, C.c_uint32, C.c_uint64]),
+            "lo_params_free": (None, [vp]),
+            "lo_params_modulus": (C.c_uint64, [vp, C.c_uint32]),
+            "lo_params_psi": (C.c_uint64, [vp, C.c_uint32]),
+            "lo_params_L": (C.c_uint32, [vp]),
+            "lo_params_K": (C.c_uint32, [vp]),
+            "lo_limb_ntt": (None, [vp, C.c_uint32, u64p]),
+            "lo_limb_intt": (None, [vp, C.c_uint32, u64p]),
+            "lo_centered_scalar": (C.c_uint64, [C.c_uint64] * 3),
+            "lo_ct_ntt": (None, [vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, C.c_uint32]),
+            "lo_ct_encode": (None, [vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p, C.c_uint32, u64p]),
+            "lo_rescale": (None, [vp, u64p, C.c_uint32, u64p]),
+            "lo_rescale_to_level1": (None, [vp, u64p, C.c_uint32, u64p]),
+            "lo_rescale_scale": (C.c_uint64, [vp, C.c_uint32, C.c_uint32]),
+            "lo_mul_plain": (None, [vp, u64p, u64p, C.c_uint32, u64p]),
+            "lo_beta": (C.c_uint32, [vp, C.c_uint32]),
+            "lo_evk_words": (C.c_size_t, [vp]),
+            "lo_galois_element": (C.c_uint64, [vp, C.c_int64]),
+            "lo_galois_row_swap": (C.c_uint64, [vp]),
+            "lo_automorphism_index": (None, [vp, C.c_uint64, u32p]),
+            "lo_automorphism": (None, [vp, u64p, C.c_uint32, C.c_uint64, u64p, u64p]),
+            "lo_inner_sum_galois_elements": (C.c_uint32, [vp, C.c_uint32, u64p]),
+            "lo_inner_sum": (None, [vp, u64p, C.c_uint32, C.c_uint32, C.POINTER(u64p), u64p]),
+            "lo_rng_seed": (None, [vp, C.c_uint64]),
+            "lo_keygen_secret": (None, [vp, vp, u64p]),
+            "lo_keygen_public": (None, [vp, vp, u64p, u64p]),
+            "lo_keygen_evk": (None, [vp, vp, u64p, u64p, u64p]),
+            "lo_keygen_galois": (None, [vp, vp, u64p, C.c_uint64, u64p]),
+            "lo_encode": (None, [vp, u64p, C.c_uint32, C.c_uint32, u64p]),
+            "lo_encrypt_pk": (None, [vp, vp, u64p, u64p, C.c_uint32, u64p]),
+            "lo_decrypt_phase": (None, [vp, u64p, u64p, C.c_uint32, u64p]),
+            "lo_decode_coeffs": (None, [vp, u64p, C.c_uint64, u64p, C.c_uint32]),
+            "lo_decrypt_decode": (C.c_int, [vp, u64p, u64p, C.c_uint32, C.c_uint64, u64p, C.c_uint32]),
+            "lo_calculate_queries": (C.c_int, [C.c_double, C.c_int]),
+            "lo_ct_serialized_size": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+            "lo_ct_serialize": (None, [u64p, C.c_uint32, C.c_uint32, u8p]),
+            "lo_commit_leaves": (None, [vp, u64p, C.c_uint32, C.c_uint32, u64p, u8p]),
+            "lo_matrix_inner_sum": (None, [vp, u64p, C.c_uint32, C.c_uint32, u64p, C.c_uint32, C.POINTER(u64p), u64p]),
+            "lo_sample_query_indices": (None, [vp, C.c_uint32, C.c_uint32, u32p]),
+            "lo_prove_b_vector": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p]),
+        }
+        for name, (res, args) in sigs.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+
+    # -- small helpers -----------------------------------------------------
+    def field_roots(self, T, fieldN):
+        r = np.zeros(fieldN, dtype=np.uint64)
+        rc = self.lib.lo_field_roots_forward(T, fieldN, _p64(r))
+        if rc:
+            raise ValueError(f"lo_field_roots_forward rc={rc}")
+        return r
+
+    def witness(self, rows, cols, T):
+        m = np.zeros((rows, cols), dtype=np.uint64)
+        self.lib.lo_witness_row_major(rows, cols, T, _p64(m))
+        return m
+
+    def plain_encode(self, row, rho_inv, T, roots):
+        row = np.ascontiguousarray(row, dtype=np.uint64)
+        out = np.zeros(len(row) * rho_inv, dtype=np.uint64)
+        self.lib.lo_plain_encode(_p64(row), len(row), rho_inv, T, _p64(roots), len(roots), _p64(out))
+        return out
+
+    def twiddle_trace(self, S, fieldN):
+        cap = 1 << 17
+        out = np.zeros(cap, dtype=np.int32)
+        n = self.lib.lo_ntt_twiddle_trace(S, S, fieldN, out.ctypes.data_as(i32p), cap)
+        assert n <= cap
+        return out[:n].copy()
+
+    def sha256(self, data: bytes):
+        a = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+        out = np.zeros(32, dtype=np.uint8)
+        self.lib.lo_sha256(_p8(a), len(data), _p8(out))
+        return out.tobytes()
+
+    def merkle(self, digests):
+        d = np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 32)
+        n = d.shape[0]
+        nodes = np.zeros((2 * n + 64, 32), dtype=np.uint8)
+        root = np.zeros(32, dtype=np.uint8)
+        total = self.lib.lo_merkle_build(_p8(d), n, _p8(nodes), nodes.shape[0], _p8(root))
+        assert total > 0
+        return nodes[:total].copy(), root.tobytes()
+
+    def merkle_path(self, nodes, nleaves, index):
+        path = np.zeros((64, 32), dtype=np.uint8)
+        depth = self.lib.lo_merkle_path(_p8(nodes), nleaves, index, _p8(path))
+        return path[:depth].copy()
+
+    def merkle_verify(self, leaf_digest, path, root, index):
+        ld = np.frombuffer(leaf_digest, dtype=np.uint8).copy()
+        rt = np.frombuffer(root, dtype=np.uint8).copy()
+        path = np.ascontiguousarray(path, dtype=np.uint8)
+        return bool(self.lib.lo_merkle_verify(_p8(ld), _p8(path), path.shape[0], _p8(rt), index))
+
+
+class Transcript:
+    def __init__(self, oracle, label: str):
+        self.o = oracle
+        self.h = oracle.lib.lo_transcript_new(label.encode())
+
+    def append(self, label: str, msg: bytes):
+        a = np.frombuffer(msg, dtype=np.uint8).copy() if msg else np.zeros(1, np.uint8)
+        self.o.lib.lo_transcript_append(self.h, label.encode(), _p8(a), len(msg))
+
+    def challenge(self, label: str, n: int) -> bytes:
+        out = np.zeros(n, dtype=np.uint8)
+        self.o.lib.lo_transcript_challenge(self.h, label.encode(), _p8(out), n)
+        return out.tobytes()
+
+    def sample_u64(self, label: str) -> int:
+        return int(self.o.lib.lo_transcript_sample_u64(self.h, label.encode()))
+
+    def __del__(self):
+        try:
+            self.o.lib.lo_transcript_free(self.h)
+        except Exception:
+            pass
+
+
+class Params:
+    """lo_params handle + the BGV harness (keys live as numpy arrays)."""
+
+    def __init__(self, oracle, handle, logN):
+        self.o = oracle
+        self.h = handle
+        self.logN = logN
+        self.N = 1 << logN
+        lib = oracle.lib
+        self.L = lib.lo_params_L(handle)
+        self.K = lib.lo_params_K(handle)
+        self.moduli = [int(lib.lo_params_modulus(handle, i)) for i in range(self.L + self.K)]
+        self.psi = [int(lib.lo_params_psi(handle, i)) for i in range(self.L + self.K)]
+        self._rng = (C.c_uint64 * 4)()
+
+    @classmethod
+    def for_ntt(cls, oracle, cols, logN, T):
+        h = oracle.lib.lo_params_for_ntt(cols, logN, T)
+        if not h:
+            raise ValueError("lo_params_for_ntt failed")
+        p = cls(oracle, h, logN)
+        p.T = T
+        return p
+
+    @classmethod
+    def from_moduli(cls, oracle, logN, q, pmods, T):
+        m = np.array(list(q) + list(pmods), dtype=np.uint64)
+        h = oracle.lib.lo_params_new(logN, len(q), len(pmods), _p64(m), T)
+        if not h:
+            raise ValueError("lo_params_new failed")
+        p = cls(oracle, h, logN)
+        p.T = T
+        return p
+
+    def seed(self, s):
+        self.o.lib.lo_rng_seed(C.byref(self._rng), s)
+
+    def _r(self):
+        return C.cast(C.byref(self._rng), C.c_void_p)
+
+    # transforms
+    def limb_ntt(self, a, mi):
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        self.o.lib.lo_limb_ntt(self.h, mi, _p64(a))
+        return a
+
+    def limb_intt(self, a, mi):
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        self.o.lib.lo_limb_intt(self.h, mi, _p64(a))
+        return a
+
+    def ct_ntt(self, cts, size, roots):
+        """cts: [count][2][nl][N] -> transformed copy (fhe.NTT)."""
+        cts = np.ascontiguousarray(cts, dtype=np.uint64).copy()
+        count, _, nl, N = cts.shape
+        self.o.lib.lo_ct_ntt(self.h, _p64(cts), count, nl, size, _p64(roots), len(roots))
+        return cts
+
+    def ct_encode(self, matrix, rho_inv, zero_ct, roots):
+        matrix = np.ascontiguousarray(matrix, dtype=np.uint64)
+        cols, _, nl, N = matrix.shape
+        out = np.zeros((cols * rho_inv, 2, nl, N), dtype=np.uint64)
+        zero_ct = np.ascontiguousarray(zero_ct, dtype=np.uint64)
+        self.o.lib.lo_ct_encode(self.h, _p64(matrix), cols, nl, rho_inv, _p64(zero_ct), _p64(roots), len(roots), _p64(out))
+        return out
+
+    def rescale(self, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        _, nl, N = ct.shape
+        out = np.zeros((2, nl - 1, N), dtype=np.uint64)
+        self.o.lib.lo_rescale(self.h, _p64(ct), nl, _p64(out))
+        return out
+
+    def rescale_to_level1(self, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        _, nl, N = ct.shape
+        out = np.zeros((2, min(nl, 2), N), dtype=np.uint64)
+        self.o.lib.lo_rescale_to_level1(self.h, _p64(ct), nl, _p64(out))
+        return out
+
+    def rescale_scale(self, nl_from, nl_to):
+        return int(self.o.lib.lo_rescale_scale(self.h, nl_from, nl_to))
+
+    def mul_plain(self, ct, pt):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        pt = np.ascontiguousarray(pt, dtype=np.uint64)
+        out = np.zeros_like(ct)
+        self.o.lib.lo_mul_plain(self.h, _p64(ct), _p64(pt), ct.shape[1], _p64(out))
+        return out
+
+    def beta(self, nl=None):
+        return int(self.o.lib.lo_beta(self.h, self.L if nl is None else nl))
+
+    def evk_shape(self):
+        return (self.beta(), 2, self.L + self.K, self.N)
+
+    def galois_element(self, k):
+        return int(self.o.lib.lo_galois_element(self.h, k))
+
+    def automorphism_index(self, gal_el):
+        idx = np.zeros(self.N, dtype=np.uint32)
+        self.o.lib.lo_automorphism_index(self.h, gal_el, _p32(idx))
+        return idx
+
+    def automorphism(self, ct, gal_el, evk):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        out = np.zeros_like(ct)
+        self.o.lib.lo_automorphism(self.h, _p64(ct), ct.shape[1], gal_el, _p64(evk), _p64(out))
+        return out
+
+    def inner_sum_galois_elements(self, n):
+        g = np.zeros(64, dtype=np.uint64)
+        cnt = self.o.lib.lo_inner_sum_galois_elements(self.h, n, _p64(g))
+        return [int(x) for x in g[:cnt]]
+
+    def _evk_ptrs(self, evks):
+        arr = (u64p * len(evks))()
+        for i, e in enumerate(evks):
+            arr[i] = _p64(e)
+        return arr
+
+    def inner_sum(self, ct, n, evks):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        out = np.zeros_like(ct)
+        self.o.lib.lo_inner_sum(self.h, _p64(ct), ct.shape[1], n, self._evk_ptrs(evks), _p64(out))
+        return out
+
+    # BGV harness
+    def keygen_secret(self):
+        sk = np.zeros((self.L + self.K, self.N), dtype=np.uint64)
+        self.o.lib.lo_keygen_secret(self.h, self._r(), _p64(sk))
+        return sk
+
+    def keygen_public(self, sk):
+        pk = np.zeros((2, self.L, self.N), dtype=np.uint64)
+        self.o.lib.lo_keygen_public(self.h, self._r(), _p64(sk), _p64(pk))
+        return pk
+
+    def keygen_galois(self, sk, gal_el):
+        evk = np.zeros(self.evk_shape(), dtype=np.uint64)
+        self.o.lib.lo_keygen_galois(self.h, self._r(), _p64(sk), gal_el, _p64(evk))
+        return evk
+
+    def encode(self, values, nl=None):
+        nl = self.L if nl is None else nl
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        pt = np.zeros((nl, self.N), dtype=np.uint64)
+        self.o.lib.lo_encode(self.h, _p64(v), len(v), nl, _p64(pt))
+        return pt
+
+    def encrypt(self, pk, pt, nl=None):
+        nl = self.L if nl is None else nl
+        ct = np.zeros((2, nl, self.N), dtype=np.uint64)
+        self.o.lib.lo_encrypt_pk(self.h, self._r(), _p64(pk), _p64(pt) if pt is not None else None, nl, _p64(ct))
+        return ct
+
+    def decrypt_phase(self, sk, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        nl = ct.shape[1]
+        ph = np.zeros((nl, self.N), dtype=np.uint64)
+        self.o.lib.lo_decrypt_phase(self.h, _p64(sk), _p64(ct), nl, _p64(ph))
+        return ph
+
+    def decode_coeffs(self, m, scale, nvalues):
+        m = np.ascontiguousarray(m, dtype=np.uint64)
+        out = np.zeros(nvalues, dtype=np.uint64)
+        self.o.lib.lo_decode_coeffs(self.h, _p64(m), scale, _p64(out), nvalues)
+        return out
+
+    def decrypt(self, sk, ct, nvalues, scale=1):
+        """Decrypt at any level: levels <= 1 in C (128-bit CRT), deeper ones
+        by CRT in Python integers."""
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        nl = ct.shape[1]
+        if nl <= 2:
+            out = np.zeros(nvalues, dtype=np.uint64)
+            rc = self.o.lib.lo_decrypt_decode(self.h, _p64(sk), _p64(ct), nl, scale, _p64(out), nvalues)
+            assert rc == 0
+            return out
+        ph = self.decrypt_phase(sk, ct)
+        mods = self.moduli[:nl]
+        Q = 1
+        for q in mods:
+            Q *= q
+        acc = np.zeros(self.N, dtype=object)
+        for i, q in enumerate(mods):
+            Qi = Q // q
+            c = Qi * pow(Qi % q, -1, q)
+            acc = (acc + ph[i].astype(object) * c) % Q
+        half = Q // 2
+        m = np.array([int(((y - Q) if y > half else y) % self.T) for y in acc], dtype=np.uint64)
+        return self.decode_coeffs(m, scale, nvalues)
+
+    def commit_leaves(self, encoded):
+        encoded = np.ascontiguousarray(encoded, dtype=np.uint64)
+        count, _, nl, N = encoded.shape
+        level1 = np.zeros((count, 2, 2, N), dtype=np.uint64)
+        digests = np.zeros((count, 32), dtype=np.uint8)
+        self.o.lib.lo_commit_leaves(self.h, _p64(encoded), count, nl, _p64(level1), _p8(digests))
+        return level1, digests
+
+    def matrix_inner_sum(self, matrix, pt, rows, evks):
+        matrix = np.ascontiguousarray(matrix, dtype=np.uint64)
+        cols, _, nl, N = matrix.shape
+        out = np.zeros((cols, 2, 2, N), dtype=np.uint64)
+        self.o.lib.lo_matrix_inner_sum(self.h, _p64(matrix), cols, nl, _p64(pt), rows, self._evk_ptrs(evks), _p64(out))
+        return out
+
+    def ct_serialize(self, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        _, nl, N = ct.shape
+        sz = self.o.lib.lo_ct_serialized_size(nl, N)
+        out = np.zeros(sz, dtype=np.uint8)
+        self.o.lib.lo_ct_serialize(_p64(ct), nl, N, _p8(out))
+        return out.tobytes()
+
+    def __del__(self):
+        try:
+            self.o.lib.lo_params_free(self.h)
+        except Exception:
+            pass

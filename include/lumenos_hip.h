@@ -1,0 +1,146 @@
+/*
+ * lumenos_hip.h -- C ABI of the MI355X-native (gfx950) server-side homomorphic
+ * Ligero prover.  This is the drop-in boundary: plain pointers and sizes, no
+ * C++/torch types.  Every entry point names the reference interface it
+ * replaces (paths relative to the ChainSafe/lumenos tree; Lattigo calls are
+ * the ones made at those lines).  The Go-side cgo binding a maintainer would
+ * add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - return value: 0 = OK, non-zero = error; lumen_last_error() gives text
+ *     (the reference's cgo convention in vdec/prover.go:121-232 is mirrored:
+ *     Create/Destroy pairs, opaque handles checked for NULL).
+ *   - residues are canonical u64 in [0, q_i), NTT domain, non-Montgomery --
+ *     exactly what rlwe.Ciphertext.Value[k].Coeffs[i] holds.
+ *   - a ciphertext is [poly(2)][limb(nl)][N] u64; a "set" is an HBM-resident
+ *     array [ct][poly][limb][N].  Host buffers passed in/out use the same
+ *     layout (the Go shim stages Lattigo's per-limb slices into it).
+ *   - all calls on one context are serialised on the context's HIP stream;
+ *     distinct contexts are independent (one per goroutine-pool, or one per
+ *     GPU).  Calls return after the work is enqueued unless they hand back
+ *     host data; lumen_sync() waits.
+ */
+#ifndef LUMENOS_HIP_H
+#define LUMENOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LUMEN_ABI_VERSION 1
+#define LUMEN_MAX_LIMBS 24
+
+typedef struct lumen_ctx lumen_ctx;
+typedef struct lumen_set lumen_set;
+
+/* What fhe.NewBackendBFV (fhe/bfv.go:23-28) captures from bgv.Parameters:
+ * ring degree, the Q and P moduli chains, the plaintext modulus, and for
+ * every modulus the primitive 2N-th root psi its NTT tables are built from
+ * (Lattigo: SubRing.RootsForward; standard form here). */
+typedef struct lumen_params_desc {
+    uint32_t abi_version; /* LUMEN_ABI_VERSION */
+    uint32_t log_n;
+    uint32_t num_q; /* L */
+    uint32_t num_p; /* K (alpha) */
+    uint64_t plaintext_modulus;
+    uint64_t moduli[LUMEN_MAX_LIMBS]; /* q_0..q_{L-1}, p_0..p_{K-1} */
+    uint64_t psi[LUMEN_MAX_LIMBS];    /* primitive 2N-th root per modulus */
+    int32_t device;                   /* HIP device ordinal */
+} lumen_params_desc;
+
+/* ---- context: replaces fhe.ServerBFV / NewBackendBFV / CopyNew (fhe/bfv.go:13-58) */
+int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out);
+void lumen_ctx_destroy(lumen_ctx *ctx);
+const char *lumen_last_error(const lumen_ctx *ctx); /* ctx may be NULL */
+int lumen_sync(lumen_ctx *ctx);
+/* number of ct x scalar multiplications issued: ServerBFV.MulCounter (bfv.go:44-46) */
+uint64_t lumen_mul_counter(const lumen_ctx *ctx);
+
+/* ---- HBM-resident ciphertext sets ([]*rlwe.Ciphertext on the Go side) */
+int lumen_set_create(lumen_ctx *ctx, uint32_t count, uint32_t num_limbs, lumen_set **out);
+void lumen_set_destroy(lumen_ctx *ctx, lumen_set *set);
+uint32_t lumen_set_count(const lumen_set *set);
+uint32_t lumen_set_limbs(const lumen_set *set);
+/* device pointer of the set's storage (for callers that own HIP interop) */
+void *lumen_set_device_ptr(const lumen_set *set);
+int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, uint32_t n,
+                     const uint64_t *host);
+int lumen_set_download(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,
+                       uint64_t *host);
+/* synthetic input: residues uniform in [0,q_i) from a counter-based RNG
+ * (benchmark inputs) */
+int lumen_set_fill_random(lumen_ctx *ctx, lumen_set *set, uint64_t seed);
+
+/* ---- polynomial NTT per limb: Lattigo SubRing.NTT / INTT as used inside
+ * Rescale and key-switching.  In place on every limb of
+ * every ciphertext of the set.  inverse: 0 = NTT, 1 = INTT. */
+int lumen_set_ntt(lumen_ctx *ctx, lumen_set *set, int inverse);
+
+/* ---- plaintext field table: backend.Field().RootForwardUint64(i)
+ * (core/field.go:45-47), fieldN = 2*cols entries, raw Montgomery-form words. */
+int lumen_field_set(lumen_ctx *ctx, const uint64_t *roots_forward, uint32_t field_n);
+
+/* ---- fhe.NTT(values, size, backend) (fhe/ntt.go:12-18): in place on the set,
+ * including the final ciphertext permutation the Go pointer swaps produce. */
+int lumen_ct_ntt(lumen_ctx *ctx, lumen_set *values, uint32_t size);
+
+/* ---- fhe.Encode(matrix, rows, rhoInv, backend) (fhe/code.go:8-34).
+ * zero_ct: the one fresh encryption of the zero vector (code.go:15-22), made by
+ * the host Encryptor, host layout [2][nl][N].  Returns a new set of
+ * cols*rho_inv ciphertexts; `matrix` is not modified. */
+int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *zero_ct,
+                 uint32_t rho_inv, lumen_set **encoded);
+
+/* ---- Evaluator.Rescale looped `for ct.Level() > target` (fhe/ligero.go:149-155,
+ * 271-273, 331-333).  out is a new set with target_limbs limbs. */
+int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t target_limbs, lumen_set **out);
+
+/* ---- leaves of the commitment: serialize every ciphertext of a level-1 set
+ * (ct.WriteTo, fhe/ligero.go:156-157) and SHA-256 it (core/tree.go:96-111).
+ * digests: host buffer, count*32 bytes. */
+int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8_t *digests);
+/* core.NewTree over leaf digests (core/tree.go:113-163): nodes = all levels,
+ * bottom-up, (returns node count through n_nodes); root: 32 bytes. */
+int lumen_merkle_build(lumen_ctx *ctx, const uint8_t *leaf_digests, uint32_t n_leaves,
+                       uint8_t *nodes, size_t nodes_cap, size_t *n_nodes, uint8_t *root);
+
+/* ---- Galois keys: rlwe.EvaluationKeySet entries used by InnerSum.
+ * evk host layout [digit(beta)][b|a][limb(L+K)][N], NTT domain, standard form
+ * (the Go shim converts from Lattigo's Montgomery-form GadgetCiphertext). */
+int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint64_t *evk);
+/* Galois elements InnerSum(ct, 1, n) needs, in the order it uses them
+ * (params.GaloisElementsForInnerSum(1, rows), fhe/ligero_test.go:53) */
+uint32_t lumen_inner_sum_galois_elements(const lumen_ctx *ctx, uint32_t n, uint64_t *gal_els);
+
+/* ---- matrixInnerSumEval (fhe/ligero.go:299-370) without the ring switch:
+ * for every ciphertext j of `matrix`:
+ *   MulNew(matrix[j], pt) -> InnerSum(., 1, rows) -> Rescale to level 1.
+ * pt: host, [nl][N], NTT domain (bgv.Encoder.Encode output).  out: new level-1 set. */
+int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *pt,
+                           uint32_t rows, lumen_set **out);
+/* building blocks of the above, exposed for parity tests */
+int lumen_mul_plain(lumen_ctx *ctx, const lumen_set *in, const uint64_t *pt, lumen_set **out);
+int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, lumen_set **out);
+
+/* ---- query loop of Prove (fhe/ligero.go:268-279): gather ciphertexts idx[i]
+ * of a set into a new set (duplicates allowed). */
+int lumen_gather(lumen_ctx *ctx, const lumen_set *src, const uint32_t *idx, uint32_t n,
+                 lumen_set **out);
+
+/* ---- timing on the context's stream (bench.py / roofline) */
+int lumen_timer_start(lumen_ctx *ctx);
+int lumen_timer_stop(lumen_ctx *ctx, float *elapsed_ms);
+/* accumulated HIP-event time and launch count of the limb-NTT kernels since
+ * the last reset (measured only while profiling is enabled) */
+int lumen_prof_enable(lumen_ctx *ctx, int on);
+int lumen_prof_read(lumen_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches,
+                    uint64_t *units);
+int lumen_prof_reset(lumen_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

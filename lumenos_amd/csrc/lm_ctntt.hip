@@ -1,0 +1,526 @@
+// Ciphertext-axis transform: fhe.NTT / fhe.Encode (fhe/ntt.go:12-281,
+// fhe/code.go:8-34) -- the homomorphic Reed-Solomon row encoder.
+//
+// The reference walks a butterfly DAG over a slice of ciphertext POINTERS, one
+// whole-ciphertext Evaluator.Add/Sub/Mul(ct, uint64) per node, on a single
+// goroutine.  Every node acts identically and independently on each of the
+// 2*L*N "lanes" (poly, limb, coefficient) of the ciphertexts, so on the GPU
+// the roles are swapped: lanes are the parallel axis (coalesced along the
+// coefficient index) and the DAG is replayed per lane.
+//
+// Host side ("schedule compiler"): the DAG is derived once per (count, size,
+// fieldN) by running the control flow of nttInner on slot indices -- it cannot
+// be derived from a DFT formula: the twiddle indices come from a `step`
+// variable that is overwritten cumulatively and leaks across chunks
+// (ntt.go:249,263), pointer swaps/transposes permute the slice, and twiddles
+// are raw Montgomery-form table words.  The flat op list is
+// cut into HBM passes (connected components of at most LM_CT_GROUP slots) and
+// each component is levelised into layers of independent butterflies/scalings.
+//
+// Device side: one workgroup = one component x a tile of W lanes.  The tile
+// ([slot][lane], 8 B each) sits in LDS, layers are applied with a barrier in
+// between, then the tile goes back to HBM.  S = 2048/4096/8192 need two
+// passes, i.e. the encoded matrix crosses HBM twice.
+//
+// Per-limb scalar of a twiddle w (Evaluator.Mul(ct, uint64)):
+// centre_T(w) mod q_i, precomputed with its Shoup companion for every table
+// entry and limb (lumen_field_set).
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "lm_common.h"
+
+#define LM_CT_GROUP 128 // max slots per component (LDS tile = GROUP * W * 8 B)
+#define LM_CT_W 32      // lanes per tile
+#define LM_CT_THREADS 512
+#define LM_NOSLOT 0xFFFFFFFFu
+
+// ------------------------------------------------------------ schedule compiler
+namespace {
+
+struct Op {
+    uint8_t is_mul;
+    uint32_t a, b; // physical slots
+    int32_t tw;    // table index, -1 = RootForward(8)^3
+};
+
+struct Walker {
+    // state of the Go slice `v`: logical position -> physical slot
+    std::vector<uint32_t> v;
+    std::vector<Op> ops;
+    uint32_t fieldN;
+
+    void bfly(uint32_t i, uint32_t j) { ops.push_back({0, v[i], v[j], 0}); }
+    void mul(uint32_t i, int32_t tw) { ops.push_back({1, v[i], 0, tw}); }
+    void transpose(uint32_t start, uint32_t rows, uint32_t cols) { // core/math.go:38-60
+        std::vector<uint32_t> t(v.begin() + start, v.begin() + start + (size_t)rows * cols);
+        for (uint32_t i = 0; i < rows; i++)
+            for (uint32_t j = 0; j < cols; j++) v[start + j * rows + i] = t[i * cols + j];
+    }
+    static uint32_t sqrt_factor(uint32_t n) { // core/math.go:25-36
+        int lg = 31 - __builtin_clz(n);
+        return 1u << (lg % 2 ? (lg - 1) / 2 : lg / 2);
+    }
+    void walk(uint32_t start, uint32_t len, uint32_t size) {
+        if (size <= 1) return;
+        if (size == 2) { // ntt.go:24-35
+            for (uint32_t i = start; i < start + len; i += 2) bfly(i, i + 1);
+        } else if (size == 4) { // ntt.go:36-89
+            for (uint32_t i = start; i < start + len; i += 4) {
+                bfly(i, i + 2), bfly(i + 1, i + 3);
+                mul(i + 3, 4);
+                bfly(i, i + 1), bfly(i + 2, i + 3);
+                std::swap(v[i + 1], v[i + 2]);
+            }
+        } else if (size == 8) { // ntt.go:90-244
+            for (uint32_t i = start; i < start + len; i += 8) {
+                for (uint32_t k = 0; k < 4; k++) bfly(i + k, i + k + 4);
+                mul(i + 5, 8), mul(i + 6, 4), mul(i + 7, -1);
+                bfly(i, i + 2), bfly(i + 1, i + 3);
+                mul(i + 3, 4);
+                bfly(i, i + 1), bfly(i + 2, i + 3), bfly(i + 4, i + 6), bfly(i + 5, i + 7);
+                mul(i + 7, 4);
+                bfly(i + 4, i + 5), bfly(i + 6, i + 7);
+                std::swap(v[i + 1], v[i + 4]);
+                std::swap(v[i + 3], v[i + 6]);
+            }
+        } else { // six-step, ntt.go:245-279
+            const uint32_t n1 = sqrt_factor(size), n2 = size / n1;
+            uint64_t step = fieldN / size; // once per call; carried across chunks
+            for (uint32_t cs = start; cs < start + len; cs += size) {
+                transpose(cs, n1, n2);
+                walk(cs, size, n1);
+                transpose(cs, n2, n1);
+                for (uint32_t i = 1; i < n1; i++) {
+                    step = ((uint64_t)i * step) % fieldN;
+                    uint64_t idx = step;
+                    for (uint32_t j = 1; j < n2; j++) {
+                        idx %= fieldN;
+                        mul(cs + i * n2 + j, (int32_t)idx);
+                        idx += step;
+                    }
+                }
+                walk(cs, size, n2);
+                transpose(cs, n1, n2);
+            }
+        }
+    }
+};
+
+struct Layer {
+    std::vector<uint32_t> bfly; // a | b << 16 (local slot ids)
+    std::vector<uint32_t> mul;  // a | tw_id << 8
+};
+
+struct Group {
+    std::vector<uint32_t> slots;
+    std::vector<Layer> layers;
+};
+
+struct Pass {
+    std::vector<Group> groups;
+};
+
+struct Plan {
+    std::vector<Pass> passes;
+    std::vector<uint32_t> out_pos; // physical slot -> final logical position
+    uint64_t n_mul = 0, n_bfly = 0;
+    // device copies, one per pass
+    struct Dev {
+        uint32_t ngroups, gsize, nlayers;
+        uint32_t *d_slots = nullptr; // [ngroups][gsize]
+        uint32_t *d_ops = nullptr;   // [ngroups][total]
+        uint32_t *d_layer = nullptr; // [nlayers][3]: offset, nb, nm (padded counts)
+        uint32_t total = 0;
+    };
+    std::vector<Dev> dev;
+    uint32_t *d_out_pos = nullptr;
+};
+
+struct UF {
+    std::vector<uint32_t> p, sz;
+    explicit UF(uint32_t n) : p(n), sz(n, 1) { std::iota(p.begin(), p.end(), 0u); }
+    uint32_t find(uint32_t x) {
+        while (p[x] != x) x = p[x] = p[p[x]];
+        return x;
+    }
+};
+
+void close_pass(const std::vector<Op> &ops, size_t lo, size_t hi, UF &uf, uint32_t fieldN,
+                uint32_t count, Plan &plan) {
+    if (lo == hi) return;
+    // components touched by ops[lo,hi)
+    std::map<uint32_t, uint32_t> gid;
+    Pass pass;
+    std::vector<std::map<uint32_t, uint32_t>> local; // per group: slot -> local id
+    std::vector<std::vector<uint32_t>> last;         // per group: last layer per local slot
+    auto group_of = [&](uint32_t slot) {
+        uint32_t r = uf.find(slot);
+        auto it = gid.find(r);
+        if (it != gid.end()) return it->second;
+        uint32_t g = (uint32_t)pass.groups.size();
+        gid[r] = g;
+        pass.groups.emplace_back();
+        local.emplace_back();
+        last.emplace_back();
+        return g;
+    };
+    auto local_of = [&](uint32_t g, uint32_t slot) {
+        auto it = local[g].find(slot);
+        if (it != local[g].end()) return it->second;
+        uint32_t id = (uint32_t)pass.groups[g].slots.size();
+        local[g][slot] = id;
+        pass.groups[g].slots.push_back(slot);
+        last[g].push_back(0);
+        return id;
+    };
+    for (size_t i = lo; i < hi; i++) {
+        const Op &o = ops[i];
+        uint32_t g = group_of(o.a);
+        Group &G = pass.groups[g];
+        if (o.is_mul) {
+            uint32_t a = local_of(g, o.a);
+            uint32_t lay = last[g][a];
+            if (G.layers.size() <= lay) G.layers.resize(lay + 1);
+            uint32_t id = o.tw < 0 ? fieldN : (uint32_t)o.tw;
+            G.layers[lay].mul.push_back(a | (id << 8));
+            last[g][a] = lay + 1;
+        } else {
+            uint32_t a = local_of(g, o.a), b = local_of(g, o.b);
+            uint32_t lay = std::max(last[g][a], last[g][b]);
+            if (G.layers.size() <= lay) G.layers.resize(lay + 1);
+            G.layers[lay].bfly.push_back(a | (b << 16));
+            last[g][a] = last[g][b] = lay + 1;
+        }
+    }
+    // every slot must cross the pass (the next pass reads the pass's output
+    // buffer): slots no op touched become op-less single-slot components
+    {
+        std::vector<uint8_t> seen(count, 0);
+        for (Group &g : pass.groups)
+            for (uint32_t s : g.slots) seen[s] = 1;
+        for (uint32_t s = 0; s < count; s++)
+            if (!seen[s]) {
+                Group g;
+                g.slots.push_back(s);
+                pass.groups.push_back(std::move(g));
+            }
+    }
+    // pack small components together so each workgroup's LDS tile is full
+    // (first-fit in program order; components are independent, so their
+    // layers simply merge index by index)
+    Pass packed;
+    for (Group &g : pass.groups) {
+        if (packed.groups.empty() || packed.groups.back().slots.size() + g.slots.size() > LM_CT_GROUP) {
+            packed.groups.emplace_back();
+        }
+        Group &bin = packed.groups.back();
+        const uint32_t base = (uint32_t)bin.slots.size();
+        bin.slots.insert(bin.slots.end(), g.slots.begin(), g.slots.end());
+        if (bin.layers.size() < g.layers.size()) bin.layers.resize(g.layers.size());
+        for (size_t l = 0; l < g.layers.size(); l++) {
+            for (uint32_t op : g.layers[l].bfly) bin.layers[l].bfly.push_back(op + base + (base << 16));
+            for (uint32_t op : g.layers[l].mul) bin.layers[l].mul.push_back(op + base);
+        }
+    }
+    plan.passes.push_back(std::move(packed));
+}
+
+Plan *build_plan(uint32_t count, uint32_t size, uint32_t fieldN) {
+    Walker w;
+    w.fieldN = fieldN;
+    w.v.resize(count);
+    std::iota(w.v.begin(), w.v.end(), 0u);
+    w.walk(0, count, size);
+    Plan *plan = new Plan();
+    plan->out_pos.assign(count, 0);
+    for (uint32_t k = 0; k < count; k++) plan->out_pos[w.v[k]] = k;
+    // cut into passes: a pass ends when a butterfly would merge two
+    // components into more than LM_CT_GROUP slots
+    UF uf(count);
+    size_t lo = 0;
+    for (size_t i = 0; i < w.ops.size(); i++) {
+        const Op &o = w.ops[i];
+        if (o.is_mul) {
+            plan->n_mul++;
+            continue;
+        }
+        plan->n_bfly++;
+        uint32_t ra = uf.find(o.a), rb = uf.find(o.b);
+        if (ra == rb) continue;
+        if (uf.sz[ra] + uf.sz[rb] > LM_CT_GROUP) {
+            close_pass(w.ops, lo, i, uf, fieldN, count, *plan);
+            lo = i;
+            uf = UF(count);
+            ra = o.a, rb = o.b;
+        }
+        if (uf.sz[ra] < uf.sz[rb]) std::swap(ra, rb);
+        uf.p[rb] = ra;
+        uf.sz[ra] += uf.sz[rb];
+    }
+    close_pass(w.ops, lo, w.ops.size(), uf, fieldN, count, *plan);
+    return plan;
+}
+
+int upload_plan(lumen_ctx *ctx, Plan *plan, uint32_t count) {
+    for (Pass &pass : plan->passes) {
+        Plan::Dev d;
+        d.ngroups = (uint32_t)pass.groups.size();
+        d.gsize = 0;
+        d.nlayers = 0;
+        for (Group &g : pass.groups) {
+            d.gsize = std::max<uint32_t>(d.gsize, (uint32_t)g.slots.size());
+            d.nlayers = std::max<uint32_t>(d.nlayers, (uint32_t)g.layers.size());
+        }
+        std::vector<uint32_t> layer(3 * d.nlayers, 0);
+        uint32_t total = 0;
+        for (uint32_t l = 0; l < d.nlayers; l++) {
+            uint32_t nb = 0, nm = 0;
+            for (Group &g : pass.groups)
+                if (l < g.layers.size()) {
+                    nb = std::max<uint32_t>(nb, (uint32_t)g.layers[l].bfly.size());
+                    nm = std::max<uint32_t>(nm, (uint32_t)g.layers[l].mul.size());
+                }
+            layer[3 * l] = total, layer[3 * l + 1] = nb, layer[3 * l + 2] = nm;
+            total += nb + nm;
+        }
+        d.total = total;
+        std::vector<uint32_t> slots((size_t)d.ngroups * d.gsize, LM_NOSLOT);
+        std::vector<uint32_t> ops((size_t)d.ngroups * total, LM_NOSLOT);
+        for (uint32_t gi = 0; gi < d.ngroups; gi++) {
+            Group &g = pass.groups[gi];
+            std::copy(g.slots.begin(), g.slots.end(), slots.begin() + (size_t)gi * d.gsize);
+            for (uint32_t l = 0; l < g.layers.size(); l++) {
+                uint32_t *o = ops.data() + (size_t)gi * total + layer[3 * l];
+                std::copy(g.layers[l].bfly.begin(), g.layers[l].bfly.end(), o);
+                std::copy(g.layers[l].mul.begin(), g.layers[l].mul.end(), o + layer[3 * l + 1]);
+            }
+        }
+        LM_HIP(ctx, hipMalloc((void **)&d.d_slots, slots.size() * 4));
+        LM_HIP(ctx, hipMalloc((void **)&d.d_ops, std::max<size_t>(ops.size(), 1) * 4));
+        LM_HIP(ctx, hipMalloc((void **)&d.d_layer, std::max<size_t>(layer.size(), 1) * 4));
+        LM_HIP(ctx, hipMemcpy(d.d_slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+        if (!ops.empty()) LM_HIP(ctx, hipMemcpy(d.d_ops, ops.data(), ops.size() * 4, hipMemcpyHostToDevice));
+        if (!layer.empty()) LM_HIP(ctx, hipMemcpy(d.d_layer, layer.data(), layer.size() * 4, hipMemcpyHostToDevice));
+        plan->dev.push_back(d);
+    }
+    LM_HIP(ctx, hipMalloc((void **)&plan->d_out_pos, std::max<size_t>(count, 1) * 4));
+    LM_HIP(ctx, hipMemcpy(plan->d_out_pos, plan->out_pos.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+std::map<std::pair<lumen_ctx *, std::pair<uint64_t, uint32_t>>, Plan *> g_plans;
+
+int get_plan(lumen_ctx *ctx, uint32_t count, uint32_t size, Plan **out) {
+    auto key = std::make_pair(ctx, std::make_pair(((uint64_t)count << 32) | size, ctx->fieldN));
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) {
+        *out = it->second;
+        return 0;
+    }
+    Plan *p = build_plan(count, size, ctx->fieldN);
+    if (int rc = upload_plan(ctx, p, count)) return rc;
+    g_plans[key] = p;
+    *out = p;
+    return 0;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------- kernel
+struct ct_pass_args {
+    const u64 *srcA; // slots < splitA: srcA + slot * ctw
+    const u64 *srcB; // slots >= splitA: srcB (one ciphertext, broadcast)
+    u64 *dst;
+    const uint32_t *slots;   // [ngroups][gsize]
+    const uint32_t *ops;     // [ngroups][total]
+    const uint32_t *layer;   // [nlayers][3]
+    const uint32_t *out_pos; // slot -> destination index, or NULL for identity
+    const tw_t *scal;        // [nl_table][fieldN+1]
+    uint32_t splitA, gsize, total, nlayers, fieldN1, logN, nl;
+    size_t ctw;
+};
+
+__global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mods mods) {
+    extern __shared__ __attribute__((aligned(16))) u64 buf[]; // [gsize][W]
+    const uint32_t tid = threadIdx.x, l = tid % LM_CT_W, r = tid / LM_CT_W;
+    constexpr uint32_t R = LM_CT_THREADS / LM_CT_W;
+    const uint32_t group = blockIdx.y;
+    const size_t lane = (size_t)blockIdx.x * LM_CT_W + l;
+    const uint32_t limb = (uint32_t)((lane >> a.logN) % a.nl);
+    const u64 q = mods.m[limb].q;
+    const tw_t *scal = a.scal + (size_t)limb * a.fieldN1;
+    const uint32_t *slots = a.slots + (size_t)group * a.gsize;
+
+    for (uint32_t s = r; s < a.gsize; s += R) {
+        const uint32_t slot = slots[s];
+        if (slot == LM_NOSLOT) continue;
+        const u64 *src = slot < a.splitA ? a.srcA + (size_t)slot * a.ctw : a.srcB;
+        buf[s * LM_CT_W + l] = src[lane];
+    }
+    __syncthreads();
+    const uint32_t *ops = a.ops + (size_t)group * a.total;
+    for (uint32_t ly = 0; ly < a.nlayers; ly++) {
+        const uint32_t off = a.layer[3 * ly], nb = a.layer[3 * ly + 1], nm = a.layer[3 * ly + 2];
+        for (uint32_t i = r; i < nb; i += R) {
+            const uint32_t op = ops[off + i];
+            if (op == LM_NOSLOT) continue;
+            const uint32_t ia = (op & 0xFFFF) * LM_CT_W + l, ib = (op >> 16) * LM_CT_W + l;
+            const u64 x = buf[ia], y = buf[ib];
+            buf[ia] = lm_addmod(x, y, q); // Evaluator.Add
+            buf[ib] = lm_submod(x, y, q); // Evaluator.Sub
+        }
+        for (uint32_t i = r; i < nm; i += R) {
+            const uint32_t op = ops[off + nb + i];
+            if (op == LM_NOSLOT) continue;
+            const uint32_t ia = (op & 0xFF) * LM_CT_W + l;
+            buf[ia] = lm_shoup(buf[ia], scal[op >> 8], q); // Evaluator.Mul(ct, uint64)
+        }
+        __syncthreads();
+    }
+    for (uint32_t s = r; s < a.gsize; s += R) {
+        const uint32_t slot = slots[s];
+        if (slot == LM_NOSLOT) continue;
+        const uint32_t pos = a.out_pos ? a.out_pos[slot] : slot;
+        a.dst[(size_t)pos * a.ctw + lane] = buf[s * LM_CT_W + l];
+    }
+}
+
+static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, const u64 *srcA,
+                    uint32_t splitA, const u64 *srcB, u64 *tmp, u64 *out) {
+    const size_t ctw = (size_t)2 * nl * ctx->N;
+    const uint32_t P = (uint32_t)plan->dev.size();
+    LM_CHECK(ctx, ctw % LM_CT_W == 0, "ciphertext width not a multiple of the lane tile");
+    const u64 *cur = srcA;
+    uint32_t split = splitA;
+    const u64 *curB = srcB;
+    for (uint32_t p = 0; p < P; p++) {
+        const Plan::Dev &d = plan->dev[p];
+        LM_CHECK(ctx, d.gsize <= 256 && d.gsize <= LM_CT_GROUP, "component of %u slots exceeds the LDS tile", d.gsize);
+        const bool final_pass = p + 1 == P;
+        ct_pass_args a;
+        a.srcA = cur, a.srcB = curB, a.splitA = split;
+        a.dst = final_pass ? out : tmp;
+        a.slots = d.d_slots, a.ops = d.d_ops, a.layer = d.d_layer;
+        a.out_pos = final_pass ? plan->d_out_pos : nullptr;
+        a.scal = ctx->d_scal;
+        a.gsize = d.gsize, a.total = d.total, a.nlayers = d.nlayers;
+        a.fieldN1 = ctx->fieldN + 1, a.logN = ctx->logN, a.nl = nl, a.ctw = ctw;
+        dim3 grid((uint32_t)(ctw / LM_CT_W), d.ngroups);
+        size_t lds = (size_t)d.gsize * LM_CT_W * sizeof(u64);
+        lm_prof_scope ps(ctx, "ct_axis_pass", (uint64_t)d.ngroups * d.gsize);
+        hipLaunchKernelGGL(k_ct_pass, grid, dim3(LM_CT_THREADS), lds, ctx->stream, a, ctx->mods);
+        LM_HIP(ctx, hipGetLastError());
+        cur = tmp, split = count, curB = nullptr;
+    }
+    // slots no pass touched (size <= 1, or count == 0): plain permuted copy
+    if (P == 0 && count) {
+        LM_HIP(ctx, hipMemcpyAsync(out, srcA, (size_t)count * ctw * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ctx->mul_counter += plan->n_mul;
+    return 0;
+}
+
+static int check_field(lumen_ctx *ctx, uint32_t size) {
+    LM_CHECK(ctx, ctx->fieldN && ctx->d_scal, "lumen_field_set must be called before the ciphertext transform");
+    LM_CHECK(ctx, size && (size & (size - 1)) == 0, "transform size %u is not a power of two", size);
+    LM_CHECK(ctx, size <= ctx->fieldN, "transform size %u exceeds the field table (%u)", size, ctx->fieldN);
+    return 0;
+}
+
+extern "C" int lumen_field_set(lumen_ctx *ctx, const uint64_t *roots_forward, uint32_t field_n) {
+    LM_CHECK(nullptr, ctx && roots_forward, "lumen_field_set: NULL argument");
+    LM_CHECK(ctx, field_n >= 2 && (field_n & (field_n - 1)) == 0, "field_n %u is not a power of two >= 2", field_n);
+    LM_CHECK(ctx, field_n < (1u << 24), "field_n too large");
+    const uint64_t T = ctx->T;
+    ctx->roots.assign(roots_forward, roots_forward + field_n);
+    ctx->fieldN = field_n;
+    // RootForward(8)^3 by plain products mod T (field.Pow(3, .), fhe/ntt.go:142)
+    uint64_t w83 = 0;
+    if (field_n > 8) {
+        uint64_t r8 = roots_forward[8] % T;
+        w83 = h_mulmod(h_mulmod(r8, r8, T), r8, T);
+    }
+    std::vector<tw_t> tab((size_t)ctx->L * (field_n + 1));
+    for (uint32_t i = 0; i < ctx->L; i++) {
+        const uint64_t q = ctx->mod[i];
+        for (uint32_t k = 0; k <= field_n; k++) {
+            uint64_t w = (k == field_n ? w83 : roots_forward[k]) % T;
+            // centred representative of w mod T, then its non-negative residue mod q_i
+            uint64_t s = w > (T >> 1) ? (q - ((T - w) % q)) % q : w % q;
+            tab[(size_t)i * (field_n + 1) + k] = h_tw(s, q);
+        }
+    }
+    if (ctx->d_scal) {
+        LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LM_HIP(ctx, hipFree(ctx->d_scal));
+        ctx->d_scal = nullptr;
+    }
+    LM_HIP(ctx, hipMalloc((void **)&ctx->d_scal, tab.size() * sizeof(tw_t)));
+    LM_HIP(ctx, hipMemcpy(ctx->d_scal, tab.data(), tab.size() * sizeof(tw_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int lumen_ct_ntt(lumen_ctx *ctx, lumen_set *values, uint32_t size) {
+    LM_CHECK(nullptr, ctx && values, "lumen_ct_ntt: NULL argument");
+    if (size <= 1 || values->count == 0) return 0; // ntt.go:22-23
+    if (int rc = check_field(ctx, size)) return rc;
+    LM_CHECK(ctx, values->count % size == 0, "len(values)=%u is not a multiple of size=%u", values->count, size);
+    Plan *plan = nullptr;
+    if (int rc = get_plan(ctx, values->count, size, &plan)) return rc;
+    const uint32_t P = (uint32_t)plan->dev.size();
+    u64 *tmp = (u64 *)lm_scratch(ctx, "ct_tmp", values->words * sizeof(u64));
+    if (!tmp) return 1;
+    if (P >= 2) {
+        // passes 0..P-2 keep slot positions (so they may all target tmp after
+        // the first); the last pass permutes back into the set
+        return run_plan(ctx, plan, values->count, values->nl, values->d, values->count, nullptr, tmp, values->d);
+    }
+    // single pass: permuting pass cannot run in place
+    u64 *tmp2 = (u64 *)lm_scratch(ctx, "ct_tmp2", values->words * sizeof(u64));
+    if (!tmp2) return 1;
+    if (int rc = run_plan(ctx, plan, values->count, values->nl, values->d, values->count, nullptr, tmp, tmp2)) return rc;
+    LM_HIP(ctx, hipMemcpyAsync(values->d, tmp2, values->words * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *zero_ct,
+                            uint32_t rho_inv, lumen_set **encoded) {
+    LM_CHECK(nullptr, ctx && matrix && zero_ct && encoded, "lumen_encode: NULL argument");
+    LM_CHECK(ctx, rho_inv >= 1, "rho_inv must be >= 1");
+    const uint32_t cols = matrix->count, S = cols * rho_inv, nl = matrix->nl;
+    LM_CHECK(ctx, cols > 0, "matrix is empty"); // core/code.go:4-6 panics on an empty row
+    if (int rc = check_field(ctx, S)) return rc;
+    const size_t ctw = (size_t)2 * nl * ctx->N;
+    // the single Enc(0) of code.go:15-22, broadcast to slots cols..S-1 by the first pass
+    u64 *dzero = (u64 *)lm_scratch(ctx, "zero_ct", ctw * sizeof(u64));
+    if (!dzero) return 1;
+    LM_HIP(ctx, hipMemcpyAsync(dzero, zero_ct, ctw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lumen_set *out = nullptr;
+    if (int rc = lumen_set_create(ctx, S, nl, &out)) return rc;
+    Plan *plan = nullptr;
+    if (int rc = get_plan(ctx, S, S, &plan)) {
+        lumen_set_destroy(ctx, out);
+        return rc;
+    }
+    const uint32_t P = (uint32_t)plan->dev.size();
+    int rc = 0;
+    if (P == 0) { // S == 1
+        LM_HIP(ctx, hipMemcpyAsync(out->d, matrix->d, (size_t)cols * ctw * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        u64 *tmp = nullptr;
+        if (P >= 2) {
+            tmp = (u64 *)lm_scratch(ctx, "ct_tmp", out->words * sizeof(u64));
+            if (!tmp) rc = 1;
+        }
+        if (!rc) rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d);
+    }
+    if (rc) {
+        lumen_set_destroy(ctx, out);
+        return rc;
+    }
+    *encoded = out;
+    return 0;
+}

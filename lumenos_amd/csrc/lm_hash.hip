@@ -1,0 +1,221 @@
+// Commit tail: leaf serialisation + SHA-256 on the device, Merkle levels and
+// paths on the host (core/tree.go:39-163; fhe/ligero.go:156-157).
+//
+// Leaf bytes.  The reference hashes rlwe.Ciphertext.WriteTo output; that
+// format lives in the un-vendored Lattigo module and its header bytes are
+// unknown offline.  Until it is pinned
+// from a Go host the leaf layout is a documented stand-in: a 16-byte header
+// {u32 'LMCT', u32 polys = 2, u32 limbs, u32 N} followed by the raw
+// little-endian residues [poly][limb][N] -- i.e. exactly the ciphertext's HBM
+// image, so the hash streams straight from the rescaled set.  In drop-in use
+// the Go shim keeps hashing Lattigo's own bytes on the host until then
+// (INTEGRATION.md).
+#include <cstring>
+
+#include "lm_common.h"
+
+__constant__ u32 c_k256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+static const u32 h_k256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+#define ROTR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+
+template <typename KT>
+__host__ __device__ __forceinline__ void sha256_compress(u32 h[8], u32 w[16], const KT *K) {
+    u32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            const u32 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            const u32 s0 = ROTR(w15, 7) ^ ROTR(w15, 18) ^ (w15 >> 3);
+            const u32 s1 = ROTR(w2, 17) ^ ROTR(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        const u32 S1 = ROTR(e, 6) ^ ROTR(e, 11) ^ ROTR(e, 25);
+        const u32 ch = (e & f) ^ (~e & g);
+        const u32 t1 = hh + S1 + ch + K[i] + w[i & 15];
+        const u32 S0 = ROTR(a, 2) ^ ROTR(a, 13) ^ ROTR(a, 22);
+        const u32 mj = (a & b) ^ (a & c) ^ (b & c);
+        const u32 t2 = S0 + mj;
+        hh = g, g = f, f = e, e = d + t1, d = c, c = b, b = a, a = t1 + t2;
+    }
+    h[0] += a, h[1] += b, h[2] += c, h[3] += d, h[4] += e, h[5] += f, h[6] += g, h[7] += hh;
+}
+
+__host__ __device__ __forceinline__ u32 bswap32(u32 x) {
+    return (x >> 24) | ((x >> 8) & 0xff00) | ((x << 8) & 0xff0000) | (x << 24);
+}
+
+// one thread per leaf: the leaf is the 16-byte header followed by `words` u64
+__global__ void k_leaf_sha256(const u64 *__restrict__ set, size_t words, uint32_t count, uint32_t nl,
+                              uint32_t N, uint8_t *__restrict__ digests) {
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= count) return;
+    const u64 *d = set + (size_t)leaf * words;
+    u32 h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    u32 w[16];
+    // block 0: header + first 6 words
+    w[0] = bswap32(0x54434d4cu), w[1] = bswap32(2u), w[2] = bswap32(nl), w[3] = bswap32(N);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const u64 x = d[k];
+        w[4 + 2 * k] = bswap32((u32)x);
+        w[5 + 2 * k] = bswap32((u32)(x >> 32));
+    }
+    sha256_compress(h, w, c_k256);
+    const size_t full = (words - 6) / 8; // whole 64-byte blocks after the first
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(d + 6);
+    for (size_t b = 0; b < full; b++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const ulonglong2 v = p[b * 4 + k];
+            w[4 * k] = bswap32((u32)v.x), w[4 * k + 1] = bswap32((u32)(v.x >> 32));
+            w[4 * k + 2] = bswap32((u32)v.y), w[4 * k + 3] = bswap32((u32)(v.y >> 32));
+        }
+        sha256_compress(h, w, c_k256);
+    }
+    // tail: the remaining (words - 6) % 8 words (2 for every ring degree >= 8), padding, length
+    const size_t rem = (words - 6) % 8;
+    const u64 *tail = d + 6 + full * 8;
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = 0;
+    for (size_t k = 0; k < rem; k++) {
+        const u64 x = tail[k];
+        w[2 * k] = bswap32((u32)x);
+        w[2 * k + 1] = bswap32((u32)(x >> 32));
+    }
+    w[2 * rem] = 0x80000000u;
+    const u64 bits = ((u64)words * 8 + 16) * 8;
+    if (rem > 6) { // no room for the length: one more block
+        sha256_compress(h, w, c_k256);
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[k] = 0;
+    }
+    w[14] = (u32)(bits >> 32);
+    w[15] = (u32)bits;
+    sha256_compress(h, w, c_k256);
+    uint8_t *o = digests + (size_t)leaf * 32;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        o[4 * k] = (uint8_t)(h[k] >> 24), o[4 * k + 1] = (uint8_t)(h[k] >> 16);
+        o[4 * k + 2] = (uint8_t)(h[k] >> 8), o[4 * k + 3] = (uint8_t)h[k];
+    }
+}
+
+extern "C" int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8_t *digests) {
+    LM_CHECK(nullptr, ctx && level1 && digests, "lumen_leaf_digests: NULL argument");
+    if (!level1->count) return 0;
+    const size_t words = (size_t)2 * level1->nl * ctx->N;
+    LM_CHECK(ctx, words >= 6, "ciphertext too small to serialise");
+    uint8_t *dd = (uint8_t *)lm_scratch(ctx, "digests", (size_t)level1->count * 32);
+    if (!dd) return 1;
+    {
+        lm_prof_scope ps(ctx, "leaf_sha256", level1->count);
+        hipLaunchKernelGGL(k_leaf_sha256, dim3((level1->count + 63) / 64), dim3(64), 0, ctx->stream,
+                           level1->d, words, level1->count, level1->nl, ctx->N, dd);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    LM_HIP(ctx, hipMemcpyAsync(digests, dd, (size_t)level1->count * 32, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static void host_sha256_64(const uint8_t in[64], uint8_t out[32]) {
+    // SHA-256 of exactly 64 bytes (two child digests): one data block + one padding block
+    u32 h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    u32 w[16];
+    for (int k = 0; k < 16; k++)
+        w[k] = ((u32)in[4 * k] << 24) | ((u32)in[4 * k + 1] << 16) | ((u32)in[4 * k + 2] << 8) | in[4 * k + 3];
+    sha256_compress(h, w, h_k256);
+    memset(w, 0, sizeof(w));
+    w[0] = 0x80000000u;
+    w[15] = 512;
+    sha256_compress(h, w, h_k256);
+    for (int k = 0; k < 8; k++) {
+        out[4 * k] = (uint8_t)(h[k] >> 24), out[4 * k + 1] = (uint8_t)(h[k] >> 16);
+        out[4 * k + 2] = (uint8_t)(h[k] >> 8), out[4 * k + 3] = (uint8_t)h[k];
+    }
+}
+
+extern "C" int lumen_merkle_build(lumen_ctx *ctx, const uint8_t *leaf_digests, uint32_t n_leaves,
+                                  uint8_t *nodes, size_t nodes_cap, size_t *n_nodes, uint8_t *root) {
+    // core/tree.go:113-163: pair adjacent nodes level by level; an unpaired
+    // last node is hashed with itself (tree.go:127-131).  S*32 bytes of input
+    // (256 KiB at S = 8192): host work.
+    LM_CHECK(nullptr, ctx && leaf_digests && nodes && n_nodes && root, "lumen_merkle_build: NULL argument");
+    LM_CHECK(ctx, n_leaves > 0, "cannot build a tree over zero leaves");
+    size_t total = 0;
+    for (uint32_t n = n_leaves;; n = (n + 1) / 2) {
+        total += n;
+        if (n == 1) break;
+    }
+    LM_CHECK(ctx, total <= nodes_cap, "nodes buffer too small: need %zu entries", total);
+    memcpy(nodes, leaf_digests, (size_t)n_leaves * 32);
+    uint8_t *cur = nodes;
+    uint32_t n = n_leaves;
+    while (n > 1) {
+        uint8_t *next = cur + (size_t)n * 32;
+        const uint32_t m = (n + 1) / 2;
+        for (uint32_t i = 0; i < m; i++) {
+            uint8_t buf[64];
+            memcpy(buf, cur + (size_t)(2 * i) * 32, 32);
+            const uint32_t r = 2 * i + 1 < n ? 2 * i + 1 : 2 * i;
+            memcpy(buf + 32, cur + (size_t)r * 32, 32);
+            host_sha256_64(buf, next + (size_t)i * 32);
+        }
+        cur = next;
+        n = m;
+    }
+    memcpy(root, cur, 32);
+    *n_nodes = total;
+    return 0;
+}
+
+// ---- query loop: gather ciphertexts by index (fhe/ligero.go:268-279)
+__global__ void k_gather(const u64 *__restrict__ src, u64 *__restrict__ dst, const uint32_t *__restrict__ idx,
+                         size_t ctw2 /* ulonglong2 per ct */) {
+    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(src) + (size_t)idx[blockIdx.y] * ctw2;
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(dst) + (size_t)blockIdx.y * ctw2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ctw2; i += (size_t)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
+extern "C" int lumen_gather(lumen_ctx *ctx, const lumen_set *src, const uint32_t *idx, uint32_t n,
+                            lumen_set **out) {
+    LM_CHECK(nullptr, ctx && src && out && (idx || !n), "lumen_gather: NULL argument");
+    for (uint32_t i = 0; i < n; i++)
+        LM_CHECK(ctx, idx[i] < src->count, "gather index %u out of range (%u ciphertexts)", idx[i], src->count);
+    lumen_set *o = nullptr;
+    if (int rc = lumen_set_create(ctx, n, src->nl, &o)) return rc;
+    if (n) {
+        uint32_t *didx = (uint32_t *)lm_scratch(ctx, "gather_idx", (size_t)n * 4);
+        if (!didx) {
+            lumen_set_destroy(ctx, o);
+            return 1;
+        }
+        LM_HIP(ctx, hipMemcpyAsync(didx, idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        const size_t ctw2 = (size_t)src->nl * ctx->N; // 2*nl*N u64 = nl*N ulonglong2
+        LM_CHECK(ctx, n <= 65535, "gather of %u ciphertexts exceeds the grid", n);
+        hipLaunchKernelGGL(k_gather, dim3(32, n), dim3(256), 0, ctx->stream, src->d, o->d, didx, ctw2);
+        LM_HIP(ctx, hipGetLastError());
+        LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // idx is caller memory
+    }
+    *out = o;
+    return 0;
+}

@@ -1,0 +1,527 @@
+// matrixInnerSumEval (fhe/ligero.go:299-370): per input column
+//     MulNew(ct, pt) -> InnerSum(., 1, rows) -> Rescale to level 1
+// batched over columns.  InnerSum is log2(rows) rounds of
+//     acc += Rot(acc)       (hoisted key-switch + NTT-domain automorphism)
+// with Lattigo's hybrid (RNS-digit, alpha = #P) key switching
+// [LATTIGO-RECALL]:
+//   1. c1 -> coefficient domain (INTT on the L limbs)
+//   2. per digit d (alpha consecutive Q limbs): extend the digit to every
+//      other Q limb and to the P limbs with the float64-corrected RNS
+//      reconstruction, NTT each extended limb (own limbs reuse the NTT values)
+//   3. (u0,u1) = sum_d digit_d (.) evk_d  over all L+K limbs
+//   4. ModDown: INTT the P limbs, extend P -> Q, NTT, (u_Q - lift) * P^-1
+//   5. add c0, permute both polynomials by the automorphism table, accumulate.
+// Everything but the correction term v is exact modular arithmetic; v is
+// computed in IEEE double exactly as the oracle does (this file is compiled
+// with -ffp-contract=off).
+//
+// Kernel shapes: the NTT-bearing steps reuse the LDS-resident limb transform
+// with the basis extension fused into its load phase (k_modup_ntt,
+// k_moddown_ntt: the extended limb never exists in HBM in coefficient form);
+// the gadget product keeps key material in Montgomery form and accumulates
+// the beta products of a coefficient in 128 bits, one reduction per output.
+#include <cstring>
+
+#include "lm_ntt_dev.h"
+
+#define LM_KS_BATCH 64 // columns processed together (scratch ~ 172 limbs per column)
+
+// constants of one basis extension (sources m_0..m_{ns-1} -> target t)
+struct bx_t {
+    tw_t hat_inv[2];   // (M/m_a)^-1 mod m_a
+    tw_t hat_mod_t[2]; // (M/m_a) mod t
+    tw_t m_mod_t;      // M mod t
+    u64 src_mod[2];
+    uint32_t ns;       // 1: plain reduction, 2: float-corrected reconstruction
+    uint32_t own;      // target limb belongs to the digit: no extension
+};
+
+__device__ __forceinline__ u64 bx_apply(const bx_t &c, u64 x0, u64 x1, u64 t, u64 tinv64) {
+    if (c.ns == 1) return lm_reduce(x0, t, tinv64);
+    const u64 y0 = lm_shoup(x0, c.hat_inv[0], c.src_mod[0]);
+    const u64 y1 = lm_shoup(x1, c.hat_inv[1], c.src_mod[1]);
+    double vf = 0.0;
+    vf += (double)y0 / (double)c.src_mod[0];
+    vf += (double)y1 / (double)c.src_mod[1];
+    const u64 v = (u64)vf;
+    u64 acc = lm_shoup(y0, c.hat_mod_t[0], t) + lm_shoup(y1, c.hat_mod_t[1], t); // < 2t
+    acc = lm_csub(acc, t);
+    const u64 corr = lm_shoup(v, c.m_mod_t, t);
+    return lm_submod(acc, corr, t);
+}
+
+// ---- step 0: MulNew(ct, pt): out = ct (.) (pt * T)
+__global__ void k_mul_plain(const u64 *__restrict__ ct, u64 *__restrict__ out, const tw_t *__restrict__ ptT,
+                            size_t words, uint32_t logN, uint32_t nl, lm_mods mods) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t N = (size_t)1 << logN;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
+        const uint32_t limb = (uint32_t)((i >> logN) % nl);
+        const size_t k = i & (N - 1);
+        out[i] = lm_shoup(ct[i], ptT[(size_t)limb * N + k], mods.m[limb].q);
+    }
+}
+
+// ---- step 2: digit extension + NTT.  One workgroup per (column b, digit d, target t).
+// coef: [B][L][N] coefficient-domain c1; c1ntt: acc c1 (NTT) with poly stride; ext: [B][beta][L+K][N]
+__global__ __launch_bounds__(1024) void k_modup_ntt(const u64 *__restrict__ coef, const u64 *__restrict__ acc,
+                                                    u64 *__restrict__ ext, const bx_t *__restrict__ bx,
+                                                    uint32_t B, uint32_t L, uint32_t K, uint32_t beta,
+                                                    uint32_t logN, lm_mods mods,
+                                                    const tw_t *__restrict__ tw_all) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm[];
+    const uint32_t N = 1u << logN, tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
+    // target-major order keeps one twiddle table hot per XCD L2
+    uint32_t r = blockIdx.x;
+    const uint32_t b = r % B;
+    r /= B;
+    const uint32_t d = r % beta;
+    const uint32_t t = r / beta; // modulus index (Q limbs then P limbs)
+    const bx_t c = bx[d * LK + t];
+    u64 *o = ext + (((size_t)b * beta + d) * LK + t) * N;
+    if (c.own) { // own limb: the original NTT-domain values
+        const u64 *s = acc + ((size_t)(b * 2 + 1) * L + t) * N;
+        for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads)
+            *reinterpret_cast<ulonglong2 *>(o + i) = *reinterpret_cast<const ulonglong2 *>(s + i);
+        return;
+    }
+    const u64 q = mods.m[t].q, qinv64 = mods.m[t].qinv64;
+    const u64 *s0 = coef + ((size_t)b * L + d * K) * N;
+    const u64 *s1 = s0 + N; // second limb of the digit (unused when ns == 1)
+    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(s0 + i);
+        ulonglong2 bb = a;
+        if (c.ns == 2) bb = *reinterpret_cast<const ulonglong2 *>(s1 + i);
+        sm[LM_PAD(i)] = bx_apply(c, a.x, bb.x, q, qinv64);
+        sm[LM_PAD(i + 1)] = bx_apply(c, a.y, bb.y, q, qinv64);
+    }
+    __syncthreads();
+    lds_fwd_transform(sm, logN, tw_all + (size_t)t * N, q, tid, nthreads);
+    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
+        ulonglong2 v;
+        v.x = lm_reduce(sm[LM_PAD(i)], q, qinv64);
+        v.y = lm_reduce(sm[LM_PAD(i + 1)], q, qinv64);
+        *reinterpret_cast<ulonglong2 *>(o + i) = v;
+    }
+}
+
+// ---- step 3: gadget product.  u[b][w][t][i] = sum_d ext[b][d][t][i] * key[d][w][t][i]
+// key in Montgomery form (k * 2^64 mod q): 128-bit accumulation, one Montgomery reduction.
+#define LM_MAC_COLS 4
+__global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, const u64 *__restrict__ key,
+                                                u64 *__restrict__ u, uint32_t B, uint32_t LK,
+                                                uint32_t beta, uint32_t logN, lm_mods mods) {
+    const uint32_t N = 1u << logN;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // coefficient
+    const uint32_t t = blockIdx.y;                            // modulus index
+    const uint32_t b0 = blockIdx.z * LM_MAC_COLS;
+    if (i >= N) return;
+    const mod_t md = mods.m[t];
+    u128 a0[LM_MAC_COLS], a1[LM_MAC_COLS];
+#pragma unroll
+    for (int c = 0; c < LM_MAC_COLS; c++) a0[c] = 0, a1[c] = 0;
+    for (uint32_t d = 0; d < beta; d++) {
+        const u64 k0 = key[(((size_t)d * 2 + 0) * LK + t) * N + i];
+        const u64 k1 = key[(((size_t)d * 2 + 1) * LK + t) * N + i];
+#pragma unroll
+        for (int c = 0; c < LM_MAC_COLS; c++) {
+            if (b0 + c < B) {
+                const u64 x = ext[(((size_t)(b0 + c) * beta + d) * LK + t) * N + i];
+                a0[c] += (u128)x * k0;
+                a1[c] += (u128)x * k1;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LM_MAC_COLS; c++) {
+        if (b0 + c < B) {
+            u64 *o = u + ((size_t)(b0 + c) * 2 * LK + t) * N + i;
+            o[0] = lm_mont_reduce((u64)a0[c], (u64)(a0[c] >> 64), md.q, md.qneg);
+            o[(size_t)LK * N] = lm_mont_reduce((u64)a1[c], (u64)(a1[c] >> 64), md.q, md.qneg);
+        }
+    }
+}
+
+// ---- step 4: ModDown.  One workgroup per (column b, poly w, Q limb t):
+// lift of the (coefficient-domain) P limbs into q_t fused into the load, NTT in
+// LDS, then d = (u_t - lift) * P^-1 (+ c0 for w == 0) fused into the store.
+__global__ __launch_bounds__(1024) void k_moddown_ntt(const u64 *__restrict__ u, const u64 *__restrict__ acc,
+                                                      u64 *__restrict__ dout, const bx_t *__restrict__ bxp,
+                                                      const tw_t *__restrict__ pinv, uint32_t B, uint32_t L,
+                                                      uint32_t K, uint32_t logN, lm_mods mods,
+                                                      const tw_t *__restrict__ tw_all) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm[];
+    const uint32_t N = 1u << logN, tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
+    uint32_t r = blockIdx.x;
+    const uint32_t pw = r % (B * 2); // b*2 + w
+    const uint32_t t = r / (B * 2);
+    const uint32_t w = pw & 1;
+    const bx_t c = bxp[t];
+    const u64 q = mods.m[t].q, qinv64 = mods.m[t].qinv64;
+    const u64 *up = u + ((size_t)pw * LK + L) * N; // P limbs of u, coefficient domain
+    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(up + i);
+        ulonglong2 bb = a;
+        if (c.ns == 2) bb = *reinterpret_cast<const ulonglong2 *>(up + N + i);
+        sm[LM_PAD(i)] = bx_apply(c, a.x, bb.x, q, qinv64);
+        sm[LM_PAD(i + 1)] = bx_apply(c, a.y, bb.y, q, qinv64);
+    }
+    __syncthreads();
+    lds_fwd_transform(sm, logN, tw_all + (size_t)t * N, q, tid, nthreads);
+    const u64 *uq = u + ((size_t)pw * LK + t) * N;
+    const u64 *c0 = acc + ((size_t)pw * L + t) * N; // only read when w == 0
+    u64 *o = dout + ((size_t)pw * L + t) * N;
+    const tw_t pi = pinv[t];
+    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
+        const ulonglong2 uv = *reinterpret_cast<const ulonglong2 *>(uq + i);
+        ulonglong2 v;
+        v.x = lm_shoup(lm_submod(uv.x, lm_reduce(sm[LM_PAD(i)], q, qinv64), q), pi, q);
+        v.y = lm_shoup(lm_submod(uv.y, lm_reduce(sm[LM_PAD(i + 1)], q, qinv64), q), pi, q);
+        if (w == 0) {
+            const ulonglong2 cv = *reinterpret_cast<const ulonglong2 *>(c0 + i);
+            v.x = lm_addmod(v.x, cv.x, q);
+            v.y = lm_addmod(v.y, cv.y, q);
+        }
+        *reinterpret_cast<ulonglong2 *>(o + i) = v;
+    }
+}
+
+// ---- step 5: acc[k][i] += d[k][index[i]]  (NTT-domain automorphism gather)
+__global__ void k_automorph_add(u64 *__restrict__ acc, const u64 *__restrict__ d,
+                                const uint32_t *__restrict__ index, size_t nlimbs, uint32_t logN,
+                                uint32_t nl, lm_mods mods) {
+    const uint32_t N = 1u << logN;
+    const size_t total = nlimbs << logN, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t limb_idx = g >> logN;
+        const uint32_t i = (uint32_t)(g & (N - 1));
+        const u64 q = mods.m[limb_idx % nl].q;
+        acc[g] = lm_addmod(acc[g], d[(limb_idx << logN) + index[i]], q);
+    }
+}
+
+// -------------------------------------------------------------------- host side
+namespace {
+
+struct KsTables {
+    bx_t *d_bx = nullptr;    // [beta][L+K]
+    bx_t *d_bxp = nullptr;   // [L]  (P -> q_t)
+    tw_t *d_pinv = nullptr;  // [L]  P^-1 mod q_t
+    uint32_t beta = 0;
+};
+std::map<lumen_ctx *, KsTables> g_ks;
+
+bx_t make_bx(const uint64_t *src, uint32_t ns, uint64_t t) {
+    bx_t c;
+    memset(&c, 0, sizeof(c));
+    c.ns = ns;
+    uint64_t m_mod_t = 1;
+    for (uint32_t a = 0; a < ns; a++) {
+        uint64_t h = 1, ht = 1;
+        for (uint32_t b = 0; b < ns; b++) {
+            if (b == a) continue;
+            h = h_mulmod(h, src[b] % src[a], src[a]);
+            ht = h_mulmod(ht, src[b] % t, t);
+        }
+        c.hat_inv[a] = h_tw(h_invmod(h, src[a]), src[a]);
+        c.hat_mod_t[a] = h_tw(ht, t);
+        c.src_mod[a] = src[a];
+        m_mod_t = h_mulmod(m_mod_t, src[a] % t, t);
+    }
+    c.m_mod_t = h_tw(m_mod_t, t);
+    return c;
+}
+
+int get_tables(lumen_ctx *ctx, KsTables **out) {
+    auto it = g_ks.find(ctx);
+    if (it != g_ks.end()) {
+        *out = &it->second;
+        return 0;
+    }
+    const uint32_t L = ctx->L, K = ctx->K, LK = L + K;
+    LM_CHECK(ctx, K >= 1 && K <= 2, "key switching supports 1 or 2 special primes (have %u)", K);
+    KsTables tb;
+    tb.beta = (L + K - 1) / K;
+    std::vector<bx_t> bx((size_t)tb.beta * LK);
+    for (uint32_t d = 0; d < tb.beta; d++) {
+        const uint32_t lo = d * K, hi = std::min(lo + K, L), ns = hi - lo;
+        for (uint32_t t = 0; t < LK; t++) {
+            bx_t c = make_bx(ctx->mod + lo, ns, ctx->mod[t]);
+            c.own = (t >= lo && t < hi) ? 1 : 0;
+            bx[(size_t)d * LK + t] = c;
+        }
+    }
+    std::vector<bx_t> bxp(L);
+    std::vector<tw_t> pinv(L);
+    for (uint32_t t = 0; t < L; t++) {
+        bxp[t] = make_bx(ctx->mod + L, K, ctx->mod[t]);
+        uint64_t q = ctx->mod[t], P = 1;
+        for (uint32_t a = 0; a < K; a++) P = h_mulmod(P, ctx->mod[L + a] % q, q);
+        pinv[t] = h_tw(h_invmod(P, q), q);
+    }
+    LM_HIP(ctx, hipMalloc((void **)&tb.d_bx, bx.size() * sizeof(bx_t)));
+    LM_HIP(ctx, hipMalloc((void **)&tb.d_bxp, bxp.size() * sizeof(bx_t)));
+    LM_HIP(ctx, hipMalloc((void **)&tb.d_pinv, pinv.size() * sizeof(tw_t)));
+    LM_HIP(ctx, hipMemcpy(tb.d_bx, bx.data(), bx.size() * sizeof(bx_t), hipMemcpyHostToDevice));
+    LM_HIP(ctx, hipMemcpy(tb.d_bxp, bxp.data(), bxp.size() * sizeof(bx_t), hipMemcpyHostToDevice));
+    LM_HIP(ctx, hipMemcpy(tb.d_pinv, pinv.data(), pinv.size() * sizeof(tw_t), hipMemcpyHostToDevice));
+    g_ks[ctx] = tb;
+    *out = &g_ks[ctx];
+    return 0;
+}
+
+struct KsScratch {
+    u64 *coef, *ext, *u, *dout;
+};
+
+int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s) {
+    const size_t N = ctx->N, L = ctx->L, LK = ctx->L + ctx->K;
+    s->coef = (u64 *)lm_scratch(ctx, "ks_coef", (size_t)B * L * N * 8);
+    s->ext = (u64 *)lm_scratch(ctx, "ks_ext", (size_t)B * beta * LK * N * 8);
+    s->u = (u64 *)lm_scratch(ctx, "ks_u", (size_t)B * 2 * LK * N * 8);
+    s->dout = (u64 *)lm_scratch(ctx, "ks_d", (size_t)B * 2 * L * N * 8);
+    return (s->coef && s->ext && s->u && s->dout) ? 0 : 1;
+}
+
+// acc: [B][2][L][N] at top level; performs acc += Rot_galEl(acc) for every column
+int rotate_accumulate(lumen_ctx *ctx, u64 *acc, uint32_t B, const lm_galois_key &gk, KsTables *tb,
+                      const KsScratch &s) {
+    const uint32_t N = ctx->N, L = ctx->L, K = ctx->K, LK = L + K, beta = tb->beta;
+    const size_t lds = lm_ntt_lds_bytes(N);
+    const uint32_t threads = lm_ntt_threads(N);
+    // 1. c1 -> coefficient domain
+    if (int rc = lm_launch_ntt_strided(ctx, acc + (size_t)L * N, (size_t)2 * L * N, s.coef, (size_t)L * N, B,
+                                       lm_map_q(L), true, "ks_intt_c1"))
+        return rc;
+    // 2. digit extension + NTT
+    {
+        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_modup_ntt),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint64_t nb = (uint64_t)B * beta * LK;
+        lm_prof_scope ps(ctx, "ks_modup_ntt", (uint64_t)B * (beta * LK - L));
+        hipLaunchKernelGGL(k_modup_ntt, dim3((uint32_t)nb), dim3(threads), lds, ctx->stream, s.coef, acc, s.ext,
+                           tb->d_bx, B, L, K, beta, ctx->logN, ctx->mods, ctx->d_tw_fwd);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    // 3. gadget product
+    {
+        lm_prof_scope ps(ctx, "ks_mac", (uint64_t)B);
+        dim3 grid((N + 255) / 256, LK, (B + LM_MAC_COLS - 1) / LM_MAC_COLS);
+        hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, s.ext, gk.d_key, s.u, B, LK, beta,
+                           ctx->logN, ctx->mods);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    // 4a. P limbs of u -> coefficient domain (in place)
+    {
+        lm_modmap mp;
+        mp.period = K;
+        for (uint32_t i = 0; i < LM_MAX_LIMBS; i++) mp.idx[i] = (uint8_t)(L + (i < K ? i : 0));
+        if (int rc = lm_launch_ntt_strided(ctx, s.u + (size_t)L * N, (size_t)LK * N, s.u + (size_t)L * N,
+                                           (size_t)LK * N, B * 2, mp, true, "ks_intt_p"))
+            return rc;
+    }
+    // 4b. lift to Q, NTT, combine
+    {
+        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_moddown_ntt),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lm_prof_scope ps(ctx, "ks_moddown_ntt", (uint64_t)B * 2 * L);
+        hipLaunchKernelGGL(k_moddown_ntt, dim3(B * 2 * L), dim3(threads), lds, ctx->stream, s.u, acc, s.dout,
+                           tb->d_bxp, tb->d_pinv, B, L, K, ctx->logN, ctx->mods, ctx->d_tw_fwd);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    // 5. automorphism + accumulate
+    {
+        lm_prof_scope ps(ctx, "ks_automorph_add", (uint64_t)B);
+        hipLaunchKernelGGL(k_automorph_add, dim3(4096), dim3(256), 0, ctx->stream, acc, s.dout, gk.d_index,
+                           (size_t)B * 2 * L, ctx->logN, L, ctx->mods);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
+int inner_sum_batch(lumen_ctx *ctx, u64 *acc, uint32_t B, uint32_t n, KsTables *tb, const KsScratch &s) {
+    uint64_t gal[64];
+    const uint32_t cnt = lumen_inner_sum_galois_elements(ctx, n, gal);
+    for (uint32_t r = 0; r < cnt; r++) {
+        auto it = ctx->gkeys.find(gal[r]);
+        LM_CHECK(ctx, it != ctx->gkeys.end(), "Galois key for element %llu not loaded",
+                 (unsigned long long)gal[r]);
+        if (int rc = rotate_accumulate(ctx, acc, B, it->second, tb, s)) return rc;
+    }
+    return 0;
+}
+
+int upload_ptT(lumen_ctx *ctx, const uint64_t *pt, uint32_t nl, tw_t **out) {
+    // pt * T with Shoup companion: the multiplier MulNew(ct, pt) applies
+    // ([LATTIGO-RECALL] bgv tensorStandard, ciphertext x plaintext branch)
+    const uint32_t N = ctx->N;
+    std::vector<tw_t> tab((size_t)nl * N);
+    for (uint32_t l = 0; l < nl; l++) {
+        const uint64_t q = ctx->mod[l], t = ctx->T % q;
+        for (uint32_t k = 0; k < N; k++) {
+            const uint64_t x = pt[(size_t)l * N + k];
+            if (x >= q) return lm_fail(ctx, "plaintext residue out of range at limb %u coeff %u", l, k);
+            tab[(size_t)l * N + k] = h_tw(h_mulmod(x, t, q), q);
+        }
+    }
+    tw_t *d = (tw_t *)lm_scratch(ctx, "ptT", tab.size() * sizeof(tw_t));
+    if (!d) return 1;
+    LM_HIP(ctx, hipMemcpyAsync(d, tab.data(), tab.size() * sizeof(tw_t), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // tab is a local
+    *out = d;
+    return 0;
+}
+
+int launch_mul_plain(lumen_ctx *ctx, const u64 *ct, u64 *out, const tw_t *ptT, size_t words, uint32_t nl,
+                     uint32_t ncts) {
+    lm_prof_scope ps(ctx, "mul_plain", ncts);
+    hipLaunchKernelGGL(k_mul_plain, dim3(4096), dim3(256), 0, ctx->stream, ct, out, ptT, words, ctx->logN, nl,
+                       ctx->mods);
+    LM_HIP(ctx, hipGetLastError());
+    ctx->mul_counter += ncts;
+    return 0;
+}
+
+} // namespace
+
+extern "C" uint32_t lumen_inner_sum_galois_elements(const lumen_ctx *ctx, uint32_t n, uint64_t *gal_els) {
+    // InnerSum(ct, 1, n), n a power of two: rotations by 2^i; when n == N the
+    // column rotations span one slot row (N/2) and the rows are folded with the
+    // row-swap element 2N-1.  5 generates the column group.
+    if (!ctx || !gal_els || n == 0 || (n & (n - 1))) return 0;
+    const uint64_t two_n = 2ull * ctx->N;
+    const uint32_t span = n == ctx->N ? n >> 1 : n;
+    uint32_t cnt = 0;
+    uint64_t g = 5; // 5^(2^i)
+    for (uint32_t r = 1; r < span; r <<= 1) {
+        gal_els[cnt++] = g;
+        g = (g * g) & (two_n - 1);
+    }
+    if (n == ctx->N) gal_els[cnt++] = two_n - 1;
+    return cnt;
+}
+
+extern "C" int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint64_t *evk) {
+    LM_CHECK(nullptr, ctx && evk, "lumen_load_galois_key: NULL argument");
+    const uint32_t N = ctx->N, L = ctx->L, K = ctx->K, LK = L + K;
+    LM_CHECK(ctx, K >= 1, "parameters have no special primes: key switching unavailable");
+    LM_CHECK(ctx, (gal_el & 1) && gal_el < 2ull * N, "Galois element %llu is not an odd residue mod 2N",
+             (unsigned long long)gal_el);
+    const uint32_t beta = (L + K - 1) / K;
+    const size_t words = (size_t)beta * 2 * LK * N;
+    // to Montgomery form on the host (one-off per key)
+    std::vector<u64> mont(words);
+    for (uint32_t d = 0; d < beta; d++)
+        for (uint32_t w = 0; w < 2; w++)
+            for (uint32_t t = 0; t < LK; t++) {
+                const uint64_t q = ctx->mod[t];
+                const uint64_t r = (uint64_t)((((u128)1) << 64) % q);
+                const size_t off = (((size_t)d * 2 + w) * LK + t) * N;
+                for (uint32_t k = 0; k < N; k++) {
+                    const uint64_t x = evk[off + k];
+                    if (x >= q) return lm_fail(ctx, "key residue out of range (digit %u limb %u)", d, t);
+                    mont[off + k] = h_mulmod(x, r, q);
+                }
+            }
+    std::vector<uint32_t> index(N);
+    const uint64_t mask = 2ull * N - 1;
+    for (uint32_t i = 0; i < N; i++) { // [LATTIGO-RECALL] ring.AutomorphismNTTIndex
+        const uint64_t t1 = 2ull * h_bitrev(i, (int)ctx->logN) + 1;
+        const uint64_t t2 = ((gal_el * t1 & mask) - 1) >> 1;
+        index[i] = h_bitrev((uint32_t)t2, (int)ctx->logN);
+    }
+    lm_galois_key &gk = ctx->gkeys[gal_el];
+    if (!gk.d_key) LM_HIP(ctx, hipMalloc((void **)&gk.d_key, words * 8));
+    if (!gk.d_index) LM_HIP(ctx, hipMalloc((void **)&gk.d_index, (size_t)N * 4));
+    LM_HIP(ctx, hipMemcpy(gk.d_key, mont.data(), words * 8, hipMemcpyHostToDevice));
+    LM_HIP(ctx, hipMemcpy(gk.d_index, index.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int lumen_mul_plain(lumen_ctx *ctx, const lumen_set *in, const uint64_t *pt, lumen_set **out) {
+    LM_CHECK(nullptr, ctx && in && pt && out, "lumen_mul_plain: NULL argument");
+    tw_t *ptT = nullptr;
+    if (int rc = upload_ptT(ctx, pt, in->nl, &ptT)) return rc;
+    lumen_set *o = nullptr;
+    if (int rc = lumen_set_create(ctx, in->count, in->nl, &o)) return rc;
+    if (in->words)
+        if (int rc = launch_mul_plain(ctx, in->d, o->d, ptT, in->words, in->nl, in->count)) {
+            lumen_set_destroy(ctx, o);
+            return rc;
+        }
+    *out = o;
+    return 0;
+}
+
+extern "C" int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, lumen_set **out) {
+    LM_CHECK(nullptr, ctx && in && out, "lumen_inner_sum: NULL argument");
+    LM_CHECK(ctx, in->nl == ctx->L, "InnerSum is implemented at the top level only (set has %u of %u limbs)",
+             in->nl, ctx->L);
+    LM_CHECK(ctx, n && !(n & (n - 1)) && n <= ctx->N, "InnerSum length %u is not a power of two <= N", n);
+    KsTables *tb = nullptr;
+    if (int rc = get_tables(ctx, &tb)) return rc;
+    lumen_set *o = nullptr;
+    if (int rc = lumen_set_create(ctx, in->count, in->nl, &o)) return rc;
+    if (in->words)
+        LM_HIP(ctx, hipMemcpyAsync(o->d, in->d, in->words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    const uint32_t Bmax = std::min<uint32_t>(LM_KS_BATCH, std::max(in->count, 1u));
+    KsScratch s;
+    if (get_scratch(ctx, Bmax, tb->beta, &s)) {
+        lumen_set_destroy(ctx, o);
+        return 1;
+    }
+    const size_t ctw = (size_t)2 * in->nl * ctx->N;
+    for (uint32_t first = 0; first < in->count; first += Bmax) {
+        const uint32_t B = std::min(Bmax, in->count - first);
+        if (int rc = inner_sum_batch(ctx, o->d + (size_t)first * ctw, B, n, tb, s)) {
+            lumen_set_destroy(ctx, o);
+            return rc;
+        }
+    }
+    *out = o;
+    return 0;
+}
+
+extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *pt,
+                                      uint32_t rows, lumen_set **out) {
+    LM_CHECK(nullptr, ctx && matrix && pt && out, "lumen_matrix_inner_sum: NULL argument");
+    LM_CHECK(ctx, matrix->nl == ctx->L, "matrix must be at the top level (%u of %u limbs)", matrix->nl, ctx->L);
+    LM_CHECK(ctx, rows && !(rows & (rows - 1)) && rows <= ctx->N, "rows=%u is not a power of two <= N", rows);
+    KsTables *tb = nullptr;
+    if (int rc = get_tables(ctx, &tb)) return rc;
+    tw_t *ptT = nullptr;
+    if (int rc = upload_ptT(ctx, pt, matrix->nl, &ptT)) return rc;
+    const uint32_t N = ctx->N, L = ctx->L;
+    const uint32_t target = std::min<uint32_t>(2, L);
+    lumen_set *o = nullptr;
+    if (int rc = lumen_set_create(ctx, matrix->count, target, &o)) return rc;
+    const uint32_t Bmax = std::min<uint32_t>(LM_KS_BATCH, std::max(matrix->count, 1u));
+    KsScratch s;
+    const size_t ctw = (size_t)2 * L * N, octw = (size_t)2 * target * N;
+    u64 *acc = (u64 *)lm_scratch(ctx, "ks_acc", (size_t)Bmax * ctw * 8);
+    u64 *work = (u64 *)lm_scratch(ctx, "rescale_work", (size_t)Bmax * ctw * 8);
+    u64 *tbuf = (u64 *)lm_scratch(ctx, "rescale_t", (size_t)Bmax * 2 * N * 8);
+    if (get_scratch(ctx, Bmax, tb->beta, &s) || !acc || !work || !tbuf) {
+        lumen_set_destroy(ctx, o);
+        return 1;
+    }
+    int rc = 0;
+    for (uint32_t first = 0; first < matrix->count && !rc; first += Bmax) {
+        const uint32_t B = std::min(Bmax, matrix->count - first);
+        rc = launch_mul_plain(ctx, matrix->d + (size_t)first * ctw, acc, ptT, (size_t)B * ctw, L, B); // ligero.go:319
+        if (!rc) rc = inner_sum_batch(ctx, acc, B, rows, tb, s);                                       // ligero.go:325
+        if (!rc) {                                                                                     // ligero.go:331-333
+            if (L > target)
+                rc = lm_rescale_polys(ctx, acc, L, o->d + (size_t)first * octw, target, B * 2, work, tbuf);
+            else
+                rc = hipMemcpyAsync(o->d + (size_t)first * octw, acc, (size_t)B * ctw * 8, hipMemcpyDeviceToDevice,
+                                    ctx->stream) != hipSuccess;
+        }
+    }
+    if (rc) {
+        lumen_set_destroy(ctx, o);
+        return rc;
+    }
+    *out = o;
+    return 0;
+}

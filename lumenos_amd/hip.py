@@ -1,0 +1,290 @@
+"""ctypes binding of the C-ABI library declared in include/lumenos_hip.h.
+
+This is plumbing for the Python test/bench harness only; the product is the
+shared library (lumenos_amd/csrc/liblumenos_hip.so).  There is no CPU
+fallback: if the library is missing, or no HIP device is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+LUMEN_MAX_LIMBS = 24
+LUMEN_ABI_VERSION = 1
+
+
+class LumenError(RuntimeError):
+    pass
+
+
+class ParamsDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("log_n", C.c_uint32),
+        ("num_q", C.c_uint32),
+        ("num_p", C.c_uint32),
+        ("plaintext_modulus", C.c_uint64),
+        ("moduli", C.c_uint64 * LUMEN_MAX_LIMBS),
+        ("psi", C.c_uint64 * LUMEN_MAX_LIMBS),
+        ("device", C.c_int32),
+    ]
+
+
+# every symbol include/lumenos_hip.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "lumen_ctx_create": (C.c_int, [C.POINTER(ParamsDesc), _vpp]),
+    "lumen_ctx_destroy": (None, [_vp]),
+    "lumen_last_error": (C.c_char_p, [_vp]),
+    "lumen_sync": (C.c_int, [_vp]),
+    "lumen_mul_counter": (C.c_uint64, [_vp]),
+    "lumen_set_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vpp]),
+    "lumen_set_destroy": (None, [_vp, _vp]),
+    "lumen_set_count": (C.c_uint32, [_vp]),
+    "lumen_set_limbs": (C.c_uint32, [_vp]),
+    "lumen_set_device_ptr": (_vp, [_vp]),
+    "lumen_set_upload": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _u64p]),
+    "lumen_set_download": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _u64p]),
+    "lumen_set_fill_random": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "lumen_set_ntt": (C.c_int, [_vp, _vp, C.c_int]),
+    "lumen_field_set": (C.c_int, [_vp, _u64p, C.c_uint32]),
+    "lumen_ct_ntt": (C.c_int, [_vp, _vp, C.c_uint32]),
+    "lumen_encode": (C.c_int, [_vp, _vp, _u64p, C.c_uint32, _vpp]),
+    "lumen_rescale": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
+    "lumen_leaf_digests": (C.c_int, [_vp, _vp, _u8p]),
+    "lumen_merkle_build": (C.c_int, [_vp, _u8p, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t), _u8p]),
+    "lumen_load_galois_key": (C.c_int, [_vp, C.c_uint64, _u64p]),
+    "lumen_inner_sum_galois_elements": (C.c_uint32, [_vp, C.c_uint32, _u64p]),
+    "lumen_matrix_inner_sum": (C.c_int, [_vp, _vp, _u64p, C.c_uint32, _vpp]),
+    "lumen_mul_plain": (C.c_int, [_vp, _vp, _u64p, _vpp]),
+    "lumen_inner_sum": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
+    "lumen_gather": (C.c_int, [_vp, _vp, _u32p, C.c_uint32, _vpp]),
+    "lumen_timer_start": (C.c_int, [_vp]),
+    "lumen_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "lumen_prof_enable": (C.c_int, [_vp, C.c_int]),
+    "lumen_prof_read": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "lumen_prof_reset": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def load(build=True):
+    """Load liblumenos_hip.so (building it first if sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build:
+        path = _build.build()
+    if not os.path.exists(path):
+        raise LumenError(f"{path} is missing: build it with `python -m lumenos_amd._build` "
+                         "(there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _p64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "need a contiguous uint64 array"
+    return a.ctypes.data_as(_u64p)
+
+
+class DeviceSet:
+    """An HBM-resident array of ciphertexts [count][2][nl][N] (lumen_set)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+        lib = ctx.lib
+        self.count = lib.lumen_set_count(handle)
+        self.nl = lib.lumen_set_limbs(handle)
+
+    @property
+    def shape(self):
+        return (self.count, 2, self.nl, self.ctx.N)
+
+    def upload(self, host, first=0):
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        n = host.shape[0]
+        assert host.shape[1:] == self.shape[1:], (host.shape, self.shape)
+        self.ctx._ck(self.ctx.lib.lumen_set_upload(self.ctx.h, self.h, first, n, _p64(host)))
+        return self
+
+    def download(self, first=0, n=None):
+        n = self.count - first if n is None else n
+        out = np.empty((n, 2, self.nl, self.ctx.N), dtype=np.uint64)
+        if n:
+            self.ctx._ck(self.ctx.lib.lumen_set_download(self.ctx.h, self.h, first, n, _p64(out)))
+        return out
+
+    def fill_random(self, seed):
+        self.ctx._ck(self.ctx.lib.lumen_set_fill_random(self.ctx.h, self.h, seed))
+        return self
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.lumen_set_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """lumen_ctx: the device-side counterpart of fhe.ServerBFV (fhe/bfv.go:13-58)."""
+
+    def __init__(self, log_n, q, p, psi, plaintext_modulus, device=0):
+        self.lib = load()
+        d = ParamsDesc()
+        d.abi_version = LUMEN_ABI_VERSION
+        d.log_n = log_n
+        d.num_q = len(q)
+        d.num_p = len(p)
+        d.plaintext_modulus = plaintext_modulus
+        for i, m in enumerate(list(q) + list(p)):
+            d.moduli[i] = m
+        for i, r in enumerate(psi):
+            d.psi[i] = r
+        d.device = device
+        h = C.c_void_p()
+        rc = self.lib.lumen_ctx_create(C.byref(d), C.byref(h))
+        if rc:
+            raise LumenError(self.lib.lumen_last_error(None).decode())
+        self.h = h
+        self.log_n, self.N = log_n, 1 << log_n
+        self.L, self.K = len(q), len(p)
+        self.q, self.p, self.T = list(q), list(p), plaintext_modulus
+
+    def _ck(self, rc):
+        if rc:
+            raise LumenError(self.lib.lumen_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.lumen_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self._ck(self.lib.lumen_sync(self.h))
+
+    def new_set(self, count, nl):
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_set_create(self.h, count, nl, C.byref(h)))
+        return DeviceSet(self, h)
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        s = self.new_set(host.shape[0], host.shape[2])
+        return s.upload(host)
+
+    def set_ntt(self, s, inverse=False):
+        self._ck(self.lib.lumen_set_ntt(self.h, s.h, 1 if inverse else 0))
+
+    def field_set(self, roots):
+        roots = np.ascontiguousarray(roots, dtype=np.uint64)
+        self._ck(self.lib.lumen_field_set(self.h, _p64(roots), len(roots)))
+
+    def ct_ntt(self, s, size):
+        self._ck(self.lib.lumen_ct_ntt(self.h, s.h, size))
+
+    def encode(self, matrix, zero_ct, rho_inv):
+        zero_ct = np.ascontiguousarray(zero_ct, dtype=np.uint64)
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_encode(self.h, matrix.h, _p64(zero_ct), rho_inv, C.byref(h)))
+        return DeviceSet(self, h)
+
+    def rescale(self, s, target_limbs=2):
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_rescale(self.h, s.h, target_limbs, C.byref(h)))
+        return DeviceSet(self, h)
+
+    def leaf_digests(self, s):
+        out = np.zeros((s.count, 32), dtype=np.uint8)
+        self._ck(self.lib.lumen_leaf_digests(self.h, s.h, out.ctypes.data_as(_u8p)))
+        return out
+
+    def merkle_build(self, digests):
+        digests = np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 32)
+        n = digests.shape[0]
+        nodes = np.zeros((2 * n + 64, 32), dtype=np.uint8)
+        root = np.zeros(32, dtype=np.uint8)
+        cnt = C.c_size_t()
+        self._ck(self.lib.lumen_merkle_build(self.h, digests.ctypes.data_as(_u8p), n,
+                                             nodes.ctypes.data_as(_u8p), nodes.shape[0], C.byref(cnt),
+                                             root.ctypes.data_as(_u8p)))
+        return nodes[:cnt.value].copy(), root.tobytes()
+
+    def load_galois_key(self, gal_el, evk):
+        evk = np.ascontiguousarray(evk, dtype=np.uint64)
+        self._ck(self.lib.lumen_load_galois_key(self.h, gal_el, _p64(evk)))
+
+    def inner_sum_galois_elements(self, n):
+        g = np.zeros(64, dtype=np.uint64)
+        cnt = self.lib.lumen_inner_sum_galois_elements(self.h, n, _p64(g))
+        return [int(x) for x in g[:cnt]]
+
+    def mul_plain(self, s, pt):
+        pt = np.ascontiguousarray(pt, dtype=np.uint64)
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_mul_plain(self.h, s.h, _p64(pt), C.byref(h)))
+        return DeviceSet(self, h)
+
+    def inner_sum(self, s, n):
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_inner_sum(self.h, s.h, n, C.byref(h)))
+        return DeviceSet(self, h)
+
+    def matrix_inner_sum(self, matrix, pt, rows):
+        pt = np.ascontiguousarray(pt, dtype=np.uint64)
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_matrix_inner_sum(self.h, matrix.h, _p64(pt), rows, C.byref(h)))
+        return DeviceSet(self, h)
+
+    def gather(self, s, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_gather(self.h, s.h, idx.ctypes.data_as(_u32p), len(idx), C.byref(h)))
+        return DeviceSet(self, h)
+
+    def mul_counter(self):
+        return int(self.lib.lumen_mul_counter(self.h))
+
+    # timing / profiling
+    def timer_start(self):
+        self._ck(self.lib.lumen_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self.lib.lumen_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def prof_enable(self, on=True):
+        self._ck(self.lib.lumen_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._ck(self.lib.lumen_prof_reset(self.h))
+
+    def prof_read(self, kernel):
+        ms, n, u = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.lumen_prof_read(self.h, kernel.encode(), C.byref(ms), C.byref(n), C.byref(u)))
+        return ms.value, n.value, u.value
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

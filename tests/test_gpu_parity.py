@@ -1,0 +1,161 @@
+"""-m gpu: HIP path vs CPU oracle through the C ABI, bit-exact (integer work)."""
+import numpy as np
+import pytest
+
+from helpers import T_REF, make_context, make_params, random_cts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small(oracle):
+    P = make_params(oracle, 10, 4)
+    ctx = make_context(P)
+    yield P, ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("log_n,num_q", [(10, 3), (11, 2), (12, 4), (13, 2), (14, 2)])
+def test_limb_ntt_matches_oracle(oracle, log_n, num_q):
+    P = make_params(oracle, log_n, num_q)
+    ctx = make_context(P)
+    cts = random_cts(P, 3, num_q, seed=log_n)
+    s = ctx.upload(cts)
+    ctx.set_ntt(s, inverse=False)
+    got = s.download()
+    for c in range(3):
+        for k in range(2):
+            for l in range(num_q):
+                assert np.array_equal(got[c, k, l], P.limb_ntt(cts[c, k, l], l)), (c, k, l)
+    ctx.set_ntt(s, inverse=True)
+    assert np.array_equal(s.download(), cts)  # INTT(NTT(x)) == x
+    # INTT alone against the oracle
+    s2 = ctx.upload(cts)
+    ctx.set_ntt(s2, inverse=True)
+    got = s2.download()
+    for l in range(num_q):
+        assert np.array_equal(got[1, 0, l], P.limb_intt(cts[1, 0, l], l))
+    ctx.close()
+
+
+@pytest.mark.parametrize("S", [2, 4, 8, 16, 32, 64, 128, 256, 512])
+def test_ct_ntt_matches_oracle(oracle, small, S):
+    P, ctx = small
+    roots = oracle.field_roots(T_REF, max(S, 16))
+    ctx.field_set(roots)
+    cts = random_cts(P, S, 3, seed=S)
+    s = ctx.upload(cts)
+    ctx.ct_ntt(s, S)
+    assert np.array_equal(s.download(), P.ct_ntt(cts, S, roots))
+
+
+def test_ct_ntt_multi_chunk(oracle, small):
+    """len(values) > size: `step` leaks from chunk to chunk (ntt.go:249,263)."""
+    P, ctx = small
+    roots = oracle.field_roots(T_REF, 128)
+    ctx.field_set(roots)
+    cts = random_cts(P, 128, 2, seed=5)
+    for size in (16, 32, 64):
+        s = ctx.upload(cts)
+        ctx.ct_ntt(s, size)
+        assert np.array_equal(s.download(), P.ct_ntt(cts, size, roots)), size
+
+
+def test_encode_matches_oracle(oracle, small):
+    P, ctx = small
+    cols, rho = 64, 2
+    roots = oracle.field_roots(T_REF, cols * rho)
+    ctx.field_set(roots)
+    m = random_cts(P, cols, 4, seed=11)
+    zero = random_cts(P, 1, 4, seed=12)[0]
+    before = ctx.mul_counter()
+    enc = ctx.encode(ctx.upload(m), zero, rho)
+    assert np.array_equal(enc.download(), P.ct_encode(m, rho, zero, roots))
+    assert ctx.mul_counter() - before == len(oracle.twiddle_trace(cols * rho, cols * rho))
+
+
+def test_rescale_matches_oracle(oracle, small):
+    P, ctx = small
+    cts = random_cts(P, 5, 4, seed=21)
+    s = ctx.upload(cts)
+    for target in (3, 2, 1):
+        got = ctx.rescale(s, target).download()
+        for c in range(5):
+            ref = cts[c]
+            while ref.shape[1] > target:
+                ref = P.rescale(ref)
+            assert np.array_equal(got[c], ref), (target, c)
+
+
+def test_leaf_digests_and_merkle(oracle, small):
+    P, ctx = small
+    cts = random_cts(P, 37, 2, seed=31)  # odd count: unpaired node duplicated (tree.go:127-131)
+    s = ctx.upload(cts)
+    dig = ctx.leaf_digests(s)
+    for c in range(37):
+        assert dig[c].tobytes() == oracle.sha256(P.ct_serialize(cts[c])), c
+    nodes, root = ctx.merkle_build(dig)
+    onodes, oroot = oracle.merkle(dig)
+    assert root == oroot and np.array_equal(nodes, onodes)
+
+
+def test_gather(oracle, small):
+    P, ctx = small
+    cts = random_cts(P, 9, 2, seed=41)
+    idx = np.array([3, 3, 0, 8, 5], dtype=np.uint32)
+    assert np.array_equal(ctx.gather(ctx.upload(cts), idx).download(), cts[idx])
+
+
+@pytest.fixture(scope="module")
+def keyed(oracle):
+    P = make_params(oracle, 10, 5)
+    P.seed(99)
+    sk = P.keygen_secret()
+    ctx = make_context(P)
+    yield P, ctx, sk
+    ctx.close()
+
+
+def test_mul_plain_matches_oracle(oracle, keyed):
+    P, ctx, sk = keyed
+    cts = random_cts(P, 3, 5, seed=51)
+    pt = P.encode(np.arange(1, P.N + 1, dtype=np.uint64))
+    got = ctx.mul_plain(ctx.upload(cts), pt).download()
+    for c in range(3):
+        assert np.array_equal(got[c], P.mul_plain(cts[c], pt))
+
+
+@pytest.mark.parametrize("n", [8, 512, 1024])
+def test_inner_sum_matches_oracle(oracle, keyed, n):
+    P, ctx, sk = keyed
+    gl = P.inner_sum_galois_elements(n)
+    assert ctx.inner_sum_galois_elements(n) == gl
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    cts = random_cts(P, 3, 5, seed=n)
+    got = ctx.inner_sum(ctx.upload(cts), n).download()
+    for c in range(3):
+        assert np.array_equal(got[c], P.inner_sum(cts[c], n, evks)), c
+
+
+def test_matrix_inner_sum_matches_oracle_and_decrypts(oracle, keyed):
+    """matrixInnerSumEval (ligero.go:299-370): bit-exact vs oracle, and slot 0 decrypts to sum_i pt_i*M[i][j]."""
+    P, ctx, sk = keyed
+    rows, cols = 512, 6
+    pk = P.keygen_public(sk)
+    W = oracle.witness(rows, cols, T_REF)
+    cts = np.stack([P.encrypt(pk, P.encode(W[:, j])) for j in range(cols)])
+    r = np.random.default_rng(7).integers(0, 2**63, size=rows, dtype=np.uint64)
+    pt = P.encode(r)
+    gl = P.inner_sum_galois_elements(rows)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    got = ctx.matrix_inner_sum(ctx.upload(cts), pt, rows).download()
+    ref = P.matrix_inner_sum(cts, pt, rows, evks)
+    assert np.array_equal(got, ref)
+    scale = P.rescale_scale(P.L, 2)
+    for j in range(cols):
+        want = int(np.sum(W[:, j].astype(object) * (r.astype(object) % T_REF)) % T_REF)
+        assert int(P.decrypt(sk, got[j], 1, scale)[0]) == want, j

@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Benchmark of the server-side homomorphic Ligero prover hot path on MI355X.
+
+A "step" is one pass of Encode + Commit + InnerProduct(r) + InnerProduct(b) +
+QueryCols (fhe/ligero.go:95-291) over one synthetic encrypted witness matrix
+that is already resident in HBM.  Default workload = the configuration
+BASELINE.json's metric is quoted on: 16384 x 4096, LogN = 14 (12 Q limbs, 2 P
+limbs, rhoInv = 2, 309 queries).  It fits one GPU (about 75 GB of the 288 GB).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 (strong scaling, fixed job): the transform along the ciphertext axis is
+replicated, the per-column work (rescale + leaf hashing; ct x pt + InnerSum +
+rescale; query gather) is sharded by column over the ranks, and the one data
+exchange is an RCCL all-gather of the 32-byte leaf digests for the Merkle tree.
+
+Rank 0 prints ONE JSON line (see the keys at the bottom of main()).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from lumenos_amd import params as lp  # noqa: E402
+
+CONFIGS = {
+    # name: rows, cols, logN   (BASELINE.json configs / README shapes)
+    "2048x1024": (2048, 1024, 12),
+    "4096x2048": (4096, 2048, 12),
+    "8192x4096": (8192, 4096, 13),
+    "16384x4096": (16384, 4096, 14),
+}
+RHO_INV = 2
+SECURITY_BITS = 128
+# published CPU number for this exact metric (Encode+Commit+Prove,
+# 16384x4096, m7i.8xlarge 32 vCPU, pure-Go Lattigo)
+PUBLISHED_SECONDS = {"16384x4096": 416.6, "8192x4096": 189.1, "4096x2048": 38.84, "2048x1024": 15.81}
+
+
+def limb_ntt_census(rows, cols, L, K, log_n):
+    """Polynomial limb-NTT count of one step (SURVEY 8a formulas)."""
+    S = cols * RHO_INV
+    beta = (L + K - 1) // K
+    rescale = sum(2 * (1 + l) for l in range(2, L))  # per ciphertext, level L-1 -> 1
+    rot = (rows.bit_length() - 1)
+    per_rot = L + (beta * (L + K) - L) + 2 * K + 2 * L
+    commit = S * rescale
+    inner = 2 * cols * (rot * per_rot + rescale)
+    return commit + inner
+
+
+class Job:
+    """Device-resident inputs of one prover run + the step function."""
+
+    def __init__(self, cfg, rank, world, device):
+        from lumenos_amd.hip import Context
+        self.rows, self.cols, self.log_n = CONFIGS[cfg]
+        self.rank, self.world = rank, world
+        P = lp.generate_bgv_params_for_ntt(self.cols, self.log_n)
+        self.P = P
+        self.L, self.K, self.N = len(P.q), len(P.p), P.N
+        self.S = self.cols * RHO_INV
+        self.queries = lp.calculate_queries(SECURITY_BITS, RHO_INV)
+        self.ctx = ctx = Context(P.log_n, P.q, P.p, P.psi, P.T, device=device)
+        ctx.field_set(np.array(lp.field_roots_forward(P.T, self.S), dtype=np.uint64))
+        rng = np.random.default_rng(1)
+        # synthetic inputs: uniform residues (kernels are data-independent)
+        self.matrix = ctx.new_set(self.cols, self.L).fill_random(1)
+
+        def rand_limbs(mods, shape_tail):
+            out = np.empty((len(mods),) + shape_tail, dtype=np.uint64)
+            for i, m in enumerate(mods):
+                out[i] = rng.integers(0, m, size=shape_tail, dtype=np.uint64)
+            return out
+
+        self.zero_ct = np.ascontiguousarray(rand_limbs(P.q, (2, self.N)).transpose(1, 0, 2))
+        self.r_pt = rand_limbs(P.q, (self.N,))
+        self.b_pt = rand_limbs(P.q, (self.N,))
+        beta = (self.L + self.K - 1) // self.K
+        for g in ctx.inner_sum_galois_elements(self.rows):
+            evk = np.ascontiguousarray(
+                rand_limbs(P.q + P.p, (beta, 2, self.N)).transpose(1, 2, 0, 3))  # [beta][2][L+K][N]
+            ctx.load_galois_key(g, evk)
+        self.query_idx = rng.integers(0, self.S, size=self.queries).astype(np.uint32)
+        # column shards
+        self.enc_lo, self.enc_hi = self.S * rank // world, self.S * (rank + 1) // world
+        self.col_lo, self.col_hi = self.cols * rank // world, self.cols * (rank + 1) // world
+        ctx.sync()
+
+    def step(self, dist=None):
+        ctx = self.ctx
+        # ---- Commit: Encode (fhe/code.go:8-34)
+        enc = ctx.encode(self.matrix, self.zero_ct, RHO_INV)
+        # ---- Commit: leaves (fhe/ligero.go:126-183) on this rank's columns
+        mine = enc.slice(self.enc_lo, self.enc_hi - self.enc_lo)
+        lvl1 = ctx.rescale(mine, 2)
+        mine.free()
+        enc.free()
+        dig = ctx.leaf_digests(lvl1)
+        if dist is not None and self.world > 1:
+            import torch
+            t = torch.from_numpy(dig).cuda()
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(parts, t)  # the one exchange: S x 32 B of leaf digests over RCCL
+            dig = torch.cat(parts).cpu().numpy()
+        nodes, root = ctx.merkle_build(dig)  # core/tree.go:113-163
+        # ---- Prove: <r, M> and <b, M> (fhe/ligero.go:231-242, 299-370) on this rank's columns
+        cols = self.matrix.slice(self.col_lo, self.col_hi - self.col_lo)
+        mat_r = ctx.matrix_inner_sum(cols, self.r_pt, self.rows)
+        mat_z = ctx.matrix_inner_sum(cols, self.b_pt, self.rows)
+        cols.free()
+        # ---- Prove: query columns (fhe/ligero.go:261-280): already at level 1 from Commit
+        own = self.query_idx[(self.query_idx >= self.enc_lo) & (self.query_idx < self.enc_hi)] - self.enc_lo
+        q = ctx.gather(lvl1, own.astype(np.uint32))
+        ctx.sync()
+        for s in (q, mat_r, mat_z, lvl1):
+            s.free()
+        return root
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """Time the CPU oracle (a port, not the Go reference) on a bounded sample of the same
+    workload and extrapolate to one step.  Test infrastructure used as a reported baseline only."""
+    # a 1-GPU box owns a 16-core share of the host (os.cpu_count() reports the whole machine)
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # before libgomp starts
+    from oracle.loader import Oracle, Params
+    rows, cols, log_n = CONFIGS[cfg]
+    o = Oracle()
+    P = Params.for_ntt(o, cols, log_n, lp.T_REFERENCE)
+    L, N, S = P.L, P.N, cols * RHO_INV
+    rng = np.random.default_rng(3)
+
+    def rand_ct(n, nl, NN=N):
+        out = np.empty((n, 2, nl, NN), dtype=np.uint64)
+        for l in range(nl):
+            out[:, :, l, :] = rng.integers(0, P.moduli[l], size=(n, 2, NN), dtype=np.uint64)
+        return out
+
+    # Encode: single-threaded in the reference; sample = 1 limb of a
+    # small ring (lanes scale linearly), full ciphertext count
+    from tests.helpers import make_params
+    Ps = make_params(o, 8, 1, num_p=0)
+    roots = o.field_roots(lp.T_REFERENCE, S)
+    m = np.empty((cols, 2, 1, Ps.N), dtype=np.uint64)
+    m[:] = rng.integers(0, Ps.moduli[0], size=m.shape, dtype=np.uint64)
+    z = m[0].copy()
+    t0 = time.time()
+    Ps.ct_encode(m, RHO_INV, z, roots)
+    t_enc = (time.time() - t0) * (2 * L * N) / (2 * 1 * Ps.N)
+    # Commit leaves: rescale + serialise + SHA-256 on `cores` columns (OpenMP over columns)
+    n_c = cores
+    enc = rand_ct(n_c, L)
+    t0 = time.time()
+    P.commit_leaves(enc)
+    t_commit = (time.time() - t0) * S / n_c
+    # InnerProduct: MulNew + InnerSum + rescale on `cores` columns, one vector
+    gl = P.inner_sum_galois_elements(rows)
+    evk = np.empty(P.evk_shape(), dtype=np.uint64)
+    for t_i, mod in enumerate(P.moduli):
+        evk[:, :, t_i, :] = rng.integers(0, mod, size=(evk.shape[0], 2, N), dtype=np.uint64)
+    evks = [evk] * len(gl)
+    pt = np.stack([rng.integers(0, P.moduli[l], size=N, dtype=np.uint64) for l in range(L)])
+    n_i = cores
+    mat = rand_ct(n_i, L)
+    t0 = time.time()
+    P.matrix_inner_sum(mat, pt, rows, evks)
+    t_inner = (time.time() - t0) * (2 * cols) / n_i
+    total = t_enc + t_commit + t_inner
+    return {
+        "value": round(total, 2), "unit": "s", "cores": cores, "kind": "port",
+        "sample": (f"oracle (C restatement, OpenMP over columns): Encode on 1/{(2 * L * N) // (2 * Ps.N)} of the lanes "
+                   f"(1 thread, as the reference), Commit leaves on {n_c}/{S} columns, InnerProduct on {n_i}/{2 * cols} "
+                   f"column-vectors; extrapolated linearly; query reuses Commit's level-1 columns"),
+        "stages_s": {"encode": round(t_enc, 2), "commit": round(t_commit, 2), "inner_product": round(t_inner, 2)},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="16384x4096", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device: the lumenos HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL on ROCm
+
+    job = Job(args.config, rank, world, local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        job.ctx.sync()
+
+    for _ in range(args.warmup):
+        job.step(dist)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.step(dist)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sec_per_step = elapsed / args.steps
+
+    # ---- dominant-kernel roofline: one more (untimed) step with HIP events around every launch
+    roofline, stages = None, None
+    if not args.no_kernel_profile:
+        job.ctx.prof_reset()
+        job.ctx.prof_enable(True)
+        job.step(dist)
+        job.ctx.prof_enable(False)
+        tab = {k: job.ctx.prof_read(k) for k in job.ctx.prof_names()}
+        stages = {k: {"ms": round(v[0], 3), "launches": v[1], "units": v[2]} for k, v in sorted(tab.items())}
+        ntt_kernels = {k: v for k, v in tab.items()
+                       if k in ("ks_modup_ntt", "ks_moddown_ntt", "rescale_limb_ntt", "rescale_last_intt",
+                                "ks_intt_c1", "ks_intt_p", "limb_ntt", "limb_intt")}
+        if ntt_kernels:
+            dom = max(ntt_kernels, key=lambda k: ntt_kernels[k][0])
+            ms, launches, units = ntt_kernels[dom]
+            alg_bytes_per_launch = 16.0 * job.N * units / launches  # 16*N B per limb transform
+            achieved = alg_bytes_per_launch / (ms / launches * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                        "avg_launch_ms": round(ms / launches, 4), "limb_ntts_per_launch": units // launches}
+    if rank == 0:
+        census = limb_ntt_census(job.rows, job.cols, job.L, job.K, job.log_n)
+        out = {
+            "metric": f"prove_eval_seconds_{args.config}",
+            "value": round(sec_per_step, 4),
+            "unit": "s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(sec_per_step * 1e3, 2),
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": round(sec_per_step / PUBLISHED_SECONDS[args.config], 6),
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"Encode+Commit+InnerProduct(r,b)+QueryCols {args.config} LogN={job.log_n} "
+                                   f"L={job.L} K={job.K} rhoInv={RHO_INV} queries={job.queries}",
+                       "parallelism": f"columns sharded over {world} GPU(s); encode replicated",
+                       "baseline_ref": "BASELINE.md: reference Go/Lattigo CPU, m7i.8xlarge 32 vCPU"},
+            "limb_ntts_per_s": round(census / sec_per_step, 1),
+            "ct_ntts_per_s": round(census / sec_per_step / (2 * job.L), 1),
+            "roofline": roofline,
+            "kernels": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

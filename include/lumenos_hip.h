@@ -64,6 +64,10 @@ int lumen_set_create(lumen_ctx *ctx, uint32_t count, uint32_t num_limbs, lumen_s
 void lumen_set_destroy(lumen_ctx *ctx, lumen_set *set);
 uint32_t lumen_set_count(const lumen_set *set);
 uint32_t lumen_set_limbs(const lumen_set *set);
+/* non-owning view of ciphertexts [first, first+n) of `set` (a Go sub-slice
+ * matrix[a:b]); destroy the view before the parent */
+int lumen_set_slice(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,
+                    lumen_set **view);
 /* device pointer of the set's storage (for callers that own HIP interop) */
 void *lumen_set_device_ptr(const lumen_set *set);
 int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, uint32_t n,
@@ -139,6 +143,9 @@ int lumen_prof_enable(lumen_ctx *ctx, int on);
 int lumen_prof_read(lumen_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches,
                     uint64_t *units);
 int lumen_prof_reset(lumen_ctx *ctx);
+/* comma-separated names of the kernels that have profile entries; returns the
+ * length needed (excluding NUL) */
+size_t lumen_prof_names(lumen_ctx *ctx, char *buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,7 @@ struct lumen_set {
     uint32_t nl = 0;
     u64 *d = nullptr;
     size_t words = 0;
+    bool owner = true;
 };
 
 struct lumen_ctx {
@@ -64,10 +66,22 @@ struct lumen_ctx {
     std::map<uint64_t, lm_galois_key> gkeys;
     // scratch
     std::map<std::string, std::pair<void *, size_t>> scratch;
+    // per-context derived tables owned by other translation units (key-switch constants,
+    // ciphertext-transform plans); released with the context
+    std::map<std::string, std::shared_ptr<void>> ext;
     // profiling
     bool prof = false;
     std::map<std::string, lm_prof_entry> prof_tab;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, tm0 = nullptr, tm1 = nullptr;
+    // event pairs recorded around launches while profiling; resolved lazily so
+    // that measuring does not serialise the stream
+    struct pending_ev {
+        std::string name;
+        hipEvent_t a, b;
+        uint64_t units;
+    };
+    std::vector<pending_ev> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t tm0 = nullptr, tm1 = nullptr;
     std::string err;
 };
 
@@ -95,9 +109,11 @@ struct lm_prof_scope {
     lumen_ctx *ctx;
     const char *name;
     uint64_t units;
+    hipEvent_t a = nullptr;
     lm_prof_scope(lumen_ctx *c, const char *n, uint64_t u);
     ~lm_prof_scope();
 };
+void lm_prof_resolve(lumen_ctx *ctx);
 
 // host modular helpers
 static inline uint64_t h_mulmod(uint64_t a, uint64_t b, uint64_t q) {

@@ -136,6 +136,14 @@ struct Plan {
     };
     std::vector<Dev> dev;
     uint32_t *d_out_pos = nullptr;
+    ~Plan() {
+        for (Dev &d : dev) {
+            hipFree(d.d_slots);
+            hipFree(d.d_ops);
+            hipFree(d.d_layer);
+        }
+        hipFree(d_out_pos);
+    }
 };
 
 struct UF {
@@ -310,19 +318,18 @@ int upload_plan(lumen_ctx *ctx, Plan *plan, uint32_t count) {
     return 0;
 }
 
-std::map<std::pair<lumen_ctx *, std::pair<uint64_t, uint32_t>>, Plan *> g_plans;
-
 int get_plan(lumen_ctx *ctx, uint32_t count, uint32_t size, Plan **out) {
-    auto key = std::make_pair(ctx, std::make_pair(((uint64_t)count << 32) | size, ctx->fieldN));
-    auto it = g_plans.find(key);
-    if (it != g_plans.end()) {
-        *out = it->second;
+    char key[96];
+    snprintf(key, sizeof(key), "ct_plan:%u:%u:%u", count, size, ctx->fieldN);
+    auto it = ctx->ext.find(key);
+    if (it != ctx->ext.end()) {
+        *out = static_cast<Plan *>(it->second.get());
         return 0;
     }
-    Plan *p = build_plan(count, size, ctx->fieldN);
-    if (int rc = upload_plan(ctx, p, count)) return rc;
-    g_plans[key] = p;
-    *out = p;
+    std::shared_ptr<Plan> p(build_plan(count, size, ctx->fieldN));
+    if (int rc = upload_plan(ctx, p.get(), count)) return rc;
+    ctx->ext[key] = p;
+    *out = p.get();
     return 0;
 }
 

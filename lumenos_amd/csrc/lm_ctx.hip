@@ -41,19 +41,43 @@ void *lm_scratch(lumen_ctx *ctx, const char *name, size_t bytes) {
     return p;
 }
 
+static hipEvent_t ev_get(lumen_ctx *ctx) {
+    if (!ctx->ev_pool.empty()) {
+        hipEvent_t e = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
 lm_prof_scope::lm_prof_scope(lumen_ctx *c, const char *n, uint64_t u) : ctx(c), name(n), units(u) {
-    if (ctx->prof) hipEventRecord(ctx->ev0, ctx->stream);
+    if (!ctx->prof) return;
+    a = ev_get(ctx);
+    hipEventRecord(a, ctx->stream);
 }
 lm_prof_scope::~lm_prof_scope() {
-    if (!ctx->prof) return;
-    hipEventRecord(ctx->ev1, ctx->stream);
-    hipEventSynchronize(ctx->ev1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    auto &e = ctx->prof_tab[name];
-    e.total_ms += ms;
-    e.launches += 1;
-    e.units += units;
+    if (!ctx->prof || !a) return;
+    hipEvent_t b = ev_get(ctx);
+    hipEventRecord(b, ctx->stream);
+    ctx->prof_pending.push_back({name, a, b, units});
+}
+
+void lm_prof_resolve(lumen_ctx *ctx) {
+    if (ctx->prof_pending.empty()) return;
+    hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->prof_pending) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, p.a, p.b);
+        auto &e = ctx->prof_tab[p.name];
+        e.total_ms += ms;
+        e.launches += 1;
+        e.units += p.units;
+        ctx->ev_pool.push_back(p.a);
+        ctx->ev_pool.push_back(p.b);
+    }
+    ctx->prof_pending.clear();
 }
 
 lm_modmap lm_map_q(uint32_t nl) {
@@ -104,10 +128,12 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
     uint64_t two_n = 2ull * N;
     for (uint32_t i = 0; i < LK; i++) {
         uint64_t q = desc->moduli[i], psi = desc->psi[i];
-        if (q < (1ull << 20) || q >= (1ull << 61) || (q & (two_n - 1)) != 1) {
+        // the lazy forward NTT lets values grow to (2*logN + 1) * q before its one reduction
+        const uint64_t qmax = UINT64_MAX / (2ull * desc->log_n + 2);
+        if (q < (1ull << 20) || q > qmax || (q & (two_n - 1)) != 1) {
             delete ctx;
-            return lm_fail(nullptr, "modulus %u (%llu) is not an NTT-friendly prime < 2^61", i,
-                           (unsigned long long)q);
+            return lm_fail(nullptr, "modulus %u (%llu) must be == 1 mod 2N and below %llu", i,
+                           (unsigned long long)q, (unsigned long long)qmax);
         }
         // psi must be a primitive 2N-th root: psi^N == -1
         if (h_powmod(psi, N, q) != q - 1) {
@@ -136,8 +162,6 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
         LM_HIP(ctx, hipMemcpy(ctx->d_tw_fwd + (size_t)i * N, f.data(), N * sizeof(tw_t), hipMemcpyHostToDevice));
         LM_HIP(ctx, hipMemcpy(ctx->d_tw_inv + (size_t)i * N, b.data(), N * sizeof(tw_t), hipMemcpyHostToDevice));
     }
-    LM_HIP(ctx, hipEventCreate(&ctx->ev0));
-    LM_HIP(ctx, hipEventCreate(&ctx->ev1));
     LM_HIP(ctx, hipEventCreate(&ctx->tm0));
     LM_HIP(ctx, hipEventCreate(&ctx->tm1));
     *out = ctx;
@@ -156,8 +180,9 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
         hipFree(kv.second.d_index);
     }
     for (auto &kv : ctx->scratch) hipFree(kv.second.first);
-    hipEventDestroy(ctx->ev0);
-    hipEventDestroy(ctx->ev1);
+    ctx->ext.clear();
+    lm_prof_resolve(ctx);
+    for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
     hipEventDestroy(ctx->tm0);
     hipEventDestroy(ctx->tm1);
     hipStreamDestroy(ctx->stream);
@@ -199,8 +224,23 @@ extern "C" int lumen_set_create(lumen_ctx *ctx, uint32_t count, uint32_t num_lim
 extern "C" void lumen_set_destroy(lumen_ctx *ctx, lumen_set *set) {
     if (!set) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
-    hipFree(set->d);
+    if (set->owner) hipFree(set->d);
     delete set;
+}
+
+extern "C" int lumen_set_slice(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,
+                               lumen_set **view) {
+    LM_CHECK(nullptr, ctx && set && view, "lumen_set_slice: NULL argument");
+    LM_CHECK(ctx, (uint64_t)first + n <= set->count, "slice [%u,%u) exceeds set of %u", first, first + n, set->count);
+    lumen_set *v = new lumen_set();
+    const size_t ctw = (size_t)2 * set->nl * ctx->N;
+    v->count = n;
+    v->nl = set->nl;
+    v->d = set->d + (size_t)first * ctw;
+    v->words = (size_t)n * ctw;
+    v->owner = false;
+    *view = v;
+    return 0;
 }
 
 extern "C" uint32_t lumen_set_count(const lumen_set *set) { return set ? set->count : 0; }
@@ -268,19 +308,38 @@ extern "C" int lumen_timer_stop(lumen_ctx *ctx, float *elapsed_ms) {
 
 extern "C" int lumen_prof_enable(lumen_ctx *ctx, int on) {
     LM_CHECK(nullptr, ctx, "NULL ctx");
+    if (!on) lm_prof_resolve(ctx);
     ctx->prof = on != 0;
     return 0;
 }
 
 extern "C" int lumen_prof_reset(lumen_ctx *ctx) {
     LM_CHECK(nullptr, ctx, "NULL ctx");
+    lm_prof_resolve(ctx);
     ctx->prof_tab.clear();
     return 0;
+}
+
+extern "C" size_t lumen_prof_names(lumen_ctx *ctx, char *buf, size_t cap) {
+    if (!ctx) return 0;
+    lm_prof_resolve(ctx);
+    std::string all;
+    for (auto &kv : ctx->prof_tab) {
+        if (!all.empty()) all += ",";
+        all += kv.first;
+    }
+    if (buf && cap) {
+        size_t n = std::min(cap - 1, all.size());
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return all.size();
 }
 
 extern "C" int lumen_prof_read(lumen_ctx *ctx, const char *kernel, double *total_ms,
                                uint64_t *launches, uint64_t *units) {
     LM_CHECK(nullptr, ctx && kernel, "NULL argument");
+    lm_prof_resolve(ctx);
     auto it = ctx->prof_tab.find(kernel);
     lm_prof_entry e;
     if (it != ctx->prof_tab.end()) e = it->second;

@@ -208,8 +208,12 @@ struct KsTables {
     bx_t *d_bxp = nullptr;   // [L]  (P -> q_t)
     tw_t *d_pinv = nullptr;  // [L]  P^-1 mod q_t
     uint32_t beta = 0;
+    ~KsTables() {
+        hipFree(d_bx);
+        hipFree(d_bxp);
+        hipFree(d_pinv);
+    }
 };
-std::map<lumen_ctx *, KsTables> g_ks;
 
 bx_t make_bx(const uint64_t *src, uint32_t ns, uint64_t t) {
     bx_t c;
@@ -233,14 +237,15 @@ bx_t make_bx(const uint64_t *src, uint32_t ns, uint64_t t) {
 }
 
 int get_tables(lumen_ctx *ctx, KsTables **out) {
-    auto it = g_ks.find(ctx);
-    if (it != g_ks.end()) {
-        *out = &it->second;
+    auto it = ctx->ext.find("ks_tables");
+    if (it != ctx->ext.end()) {
+        *out = static_cast<KsTables *>(it->second.get());
         return 0;
     }
     const uint32_t L = ctx->L, K = ctx->K, LK = L + K;
     LM_CHECK(ctx, K >= 1 && K <= 2, "key switching supports 1 or 2 special primes (have %u)", K);
-    KsTables tb;
+    auto sp = std::make_shared<KsTables>();
+    KsTables &tb = *sp;
     tb.beta = (L + K - 1) / K;
     std::vector<bx_t> bx((size_t)tb.beta * LK);
     for (uint32_t d = 0; d < tb.beta; d++) {
@@ -265,8 +270,8 @@ int get_tables(lumen_ctx *ctx, KsTables **out) {
     LM_HIP(ctx, hipMemcpy(tb.d_bx, bx.data(), bx.size() * sizeof(bx_t), hipMemcpyHostToDevice));
     LM_HIP(ctx, hipMemcpy(tb.d_bxp, bxp.data(), bxp.size() * sizeof(bx_t), hipMemcpyHostToDevice));
     LM_HIP(ctx, hipMemcpy(tb.d_pinv, pinv.data(), pinv.size() * sizeof(tw_t), hipMemcpyHostToDevice));
-    g_ks[ctx] = tb;
-    *out = &g_ks[ctx];
+    ctx->ext["ks_tables"] = sp;
+    *out = sp.get();
     return 0;
 }
 

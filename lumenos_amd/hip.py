@@ -49,6 +49,7 @@ SYMBOLS = {
     "lumen_set_count": (C.c_uint32, [_vp]),
     "lumen_set_limbs": (C.c_uint32, [_vp]),
     "lumen_set_device_ptr": (_vp, [_vp]),
+    "lumen_set_slice": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vpp]),
     "lumen_set_upload": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _u64p]),
     "lumen_set_download": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _u64p]),
     "lumen_set_fill_random": (C.c_int, [_vp, _vp, C.c_uint64]),
@@ -70,6 +71,7 @@ SYMBOLS = {
     "lumen_prof_enable": (C.c_int, [_vp, C.c_int]),
     "lumen_prof_read": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "lumen_prof_reset": (C.c_int, [_vp]),
+    "lumen_prof_names": (C.c_size_t, [_vp, C.c_char_p, C.c_size_t]),
 }
 
 _lib = None
@@ -127,6 +129,13 @@ class DeviceSet:
         if n:
             self.ctx._ck(self.ctx.lib.lumen_set_download(self.ctx.h, self.h, first, n, _p64(out)))
         return out
+
+    def slice(self, first, n):
+        h = C.c_void_p()
+        self.ctx._ck(self.ctx.lib.lumen_set_slice(self.ctx.h, self.h, first, n, C.byref(h)))
+        v = DeviceSet(self.ctx, h)
+        v._parent = self  # keep the storage alive
+        return v
 
     def fill_random(self, seed):
         self.ctx._ck(self.ctx.lib.lumen_set_fill_random(self.ctx.h, self.h, seed))
@@ -277,6 +286,11 @@ class Context:
 
     def prof_reset(self):
         self._ck(self.lib.lumen_prof_reset(self.h))
+
+    def prof_names(self):
+        buf = C.create_string_buffer(4096)
+        self.lib.lumen_prof_names(self.h, buf, 4096)
+        return [x for x in buf.value.decode().split(",") if x]
 
     def prof_read(self, kernel):
         ms, n, u = C.c_double(), C.c_uint64(), C.c_uint64()

@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/lumenos_hip.h declares
+(no compute calls -- there is no GPU here), and fails loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lumenos_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lumen_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    from lumenos_amd import hip
+    lib = hip.load()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/lumenos_hip.h but not exported"
+    assert set(names) == set(hip.SYMBOLS), set(names) ^ set(hip.SYMBOLS)
+
+
+def test_params_desc_layout_matches_header():
+    from lumenos_amd import hip
+    assert C.sizeof(hip.ParamsDesc) == 4 * 4 + 8 + 24 * 8 * 2 + 8  # incl. tail padding of int32 device
+
+
+def test_no_cpu_fallback_without_device():
+    """The product path must fail loudly when no HIP device exists (it never routes to the oracle)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from lumenos_amd import hip, params
+    P = params.generate_bgv_params_for_ntt(16, 10)
+    with pytest.raises(hip.LumenError):
+        hip.Context(P.log_n, P.q, P.p, P.psi, P.T)
+
+
+def test_product_never_imports_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|#\s*include\s*[\"<][^\">]*oracle/)", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lumenos_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not pat.search(src), os.path.join(dirpath, f)
+                assert "liblumen_oracle" not in src, os.path.join(dirpath, f)

@@ -159,3 +159,114 @@ def test_matrix_inner_sum_matches_oracle_and_decrypts(oracle, keyed):
     for j in range(cols):
         want = int(np.sum(W[:, j].astype(object) * (r.astype(object) % T_REF)) % T_REF)
         assert int(P.decrypt(sk, got[j], 1, scale)[0]) == want, j
+
+
+# ------------------------------------------------------------------ golden fixtures
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _ctx_from_golden(g):
+    from lumenos_amd.hip import Context
+    return Context(int(g["log_n"]), [int(x) for x in g["q"]], [int(x) for x in g["p"]],
+                   [int(x) for x in g["psi"]], int(g["T"]))
+
+
+@pytest.mark.parametrize("S", [16, 32, 64])
+def test_golden_encode_gpu(S):
+    g = np.load(os.path.join(GOLD, f"encode_S{S}.npz"))
+    ctx = _ctx_from_golden(g)
+    ctx.field_set(g["roots"])
+    assert np.array_equal(ctx.encode(ctx.upload(g["matrix"]), g["zero"], 2).download(), g["encoded"])
+    ctx.close()
+
+
+def test_golden_evaluator_gpu():
+    g = np.load(os.path.join(GOLD, "evaluator.npz"))
+    ctx = _ctx_from_golden(g)
+    s = ctx.upload(g["cts"])
+    lvl1 = ctx.rescale(s, 2)
+    assert np.array_equal(lvl1.download(), g["level1"])
+    assert np.array_equal(ctx.leaf_digests(lvl1), g["digests"])
+    for ge, evk in zip(g["gal_els"], g["evks"]):
+        ctx.load_galois_key(int(ge), evk)
+    assert np.array_equal(ctx.matrix_inner_sum(s, g["pt"], int(g["rows"])).download(), g["matrix_inner_sum"])
+    ctx.close()
+
+
+# ------------------------------------------------------------------ BASELINE.json full sizes
+@pytest.mark.parametrize("S", [2048, 4096, 8192])
+def test_encode_full_ciphertext_count(oracle, S):
+    """The README shapes' transform sizes (S = 2*cols) on a narrow ring: every lane replays the
+    same DAG, so a small N exercises the full schedule (two HBM passes, leaking `step`)."""
+    P = make_params(oracle, 8, 2, num_p=0)
+    ctx = make_context(P)
+    roots = oracle.field_roots(T_REF, S)
+    ctx.field_set(roots)
+    m = random_cts(P, S // 2, 2, seed=S)
+    zero = random_cts(P, 1, 2, seed=S + 1)[0]
+    got = ctx.encode(ctx.upload(m), zero, 2).download()
+    assert np.array_equal(got, P.ct_encode(m, 2, zero, roots))
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def full_d(oracle):
+    """16384x4096 / LogN=14 parameters (12 Q limbs, 2 P limbs) exactly as bench.py builds them."""
+    from lumenos_amd import params as lp
+    from oracle.loader import Params
+    B = lp.generate_bgv_params_for_ntt(4096, 14)
+    P = Params.from_moduli(oracle, 14, B.q, B.p, B.T)
+    assert P.psi == B.psi
+    P.seed(14)
+    ctx = make_context(P)
+    yield P, ctx
+    ctx.close()
+
+
+def test_full_size_ntt_roundtrip_and_linearity(full_d):
+    P, ctx = full_d
+    a = random_cts(P, 2, P.L, seed=1)
+    b = random_cts(P, 2, P.L, seed=2)
+    q = np.array(P.moduli[:P.L], dtype=np.uint64)[None, None, :, None]
+    ab = (a + b) % q  # values < 2^59: no 64-bit wrap
+    sa, sb, sab = ctx.upload(a), ctx.upload(b), ctx.upload(ab)
+    for s in (sa, sb, sab):
+        ctx.set_ntt(s, inverse=False)
+    A, Bv, AB = sa.download(), sb.download(), sab.download()
+    assert np.array_equal((A + Bv) % q, AB)                       # linearity
+    assert np.array_equal(A[0, 0, 3], P.limb_ntt(a[0, 0, 3], 3))  # one limb against the oracle
+    ctx.set_ntt(sa, inverse=True)
+    assert np.array_equal(sa.download(), a)                       # INTT(NTT(x)) == x
+
+
+def test_full_size_rescale_and_digest(oracle, full_d):
+    P, ctx = full_d
+    cts = random_cts(P, 2, P.L, seed=3)
+    lvl1 = ctx.rescale(ctx.upload(cts), 2)
+    ref_l1, ref_dig = P.commit_leaves(cts)
+    assert np.array_equal(lvl1.download(), ref_l1)
+    assert np.array_equal(ctx.leaf_digests(lvl1), ref_dig)
+
+
+def test_full_size_matrix_inner_sum(oracle, full_d):
+    """rows = N = 16384: 13 column rotations + the row swap, real keys."""
+    P, ctx = full_d
+    rows = 16384
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    gl = P.inner_sum_galois_elements(rows)
+    assert len(gl) == 14 and gl[-1] == 2 * P.N - 1
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    rng = np.random.default_rng(4)
+    col = rng.integers(0, T_REF, size=rows, dtype=np.uint64)
+    r = rng.integers(0, 2**63, size=rows, dtype=np.uint64)
+    cts = P.encrypt(pk, P.encode(col))[None]
+    pt = P.encode(r)
+    got = ctx.matrix_inner_sum(ctx.upload(cts), pt, rows).download()
+    assert np.array_equal(got, P.matrix_inner_sum(cts, pt, rows, evks))
+    want = int(np.sum(col.astype(object) * (r.astype(object) % T_REF)) % T_REF)
+    assert int(P.decrypt(sk, got[0], 1, P.rescale_scale(P.L, 2))[0]) == want

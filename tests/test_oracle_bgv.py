@@ -1,0 +1,146 @@
+"""CPU: the decrypted-value equalities the reference's own tests assert, re-run on the oracle
+(fhe/code_test.go:87-116 TestEncode, fhe/ligero_test.go:128-174 TestLigeroE2E), plus golden
+regression vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import T_REF, make_params
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def bgv(oracle):
+    P = make_params(oracle, 10, 6)  # LogQ = [58, 56 x 5], LogP = [55, 55]
+    P.seed(3)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    return P, sk, pk
+
+
+def test_encrypt_decrypt_rescale(bgv):
+    P, sk, pk = bgv
+    vals = np.random.default_rng(1).integers(0, T_REF, size=P.N, dtype=np.uint64)
+    ct = P.encrypt(pk, P.encode(vals))
+    assert np.array_equal(P.decrypt(sk, ct, P.N), vals)
+    assert np.array_equal(P.decrypt(sk, P.rescale(ct), P.N, P.rescale_scale(P.L, P.L - 1)), vals)
+    assert np.array_equal(P.decrypt(sk, P.rescale_to_level1(ct), P.N, P.rescale_scale(P.L, 2)), vals)
+
+
+def test_mul_plain_is_slotwise_product(bgv):
+    P, sk, pk = bgv
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, T_REF, size=P.N, dtype=np.uint64)
+    b = rng.integers(0, T_REF, size=P.N, dtype=np.uint64)
+    got = P.decrypt(sk, P.mul_plain(P.encrypt(pk, P.encode(a)), P.encode(b)), P.N)
+    assert np.array_equal(got, np.array([int(x) * int(y) % T_REF for x, y in zip(a, b)], dtype=np.uint64))
+
+
+def test_rotation_and_row_swap(bgv):
+    P, sk, pk = bgv
+    vals = np.random.default_rng(3).integers(0, T_REF, size=P.N, dtype=np.uint64)
+    ct = P.encrypt(pk, P.encode(vals))
+    half = P.N // 2
+    g = P.galois_element(1)
+    d = P.decrypt(sk, P.automorphism(ct, g, P.keygen_galois(sk, g)), P.N)
+    assert np.array_equal(d[:half], np.roll(vals[:half], -1)) and np.array_equal(d[half:], np.roll(vals[half:], -1))
+    g = 2 * P.N - 1
+    d = P.decrypt(sk, P.automorphism(ct, g, P.keygen_galois(sk, g)), P.N)
+    assert np.array_equal(d[:half], vals[half:]) and np.array_equal(d[half:], vals[:half])
+
+
+@pytest.mark.parametrize("n", [64, 512, 1024])
+def test_inner_sum_contract(bgv, n):
+    """InnerSum(ct, 1, n): slot 0 = sum of the first n slots, including n == N."""
+    P, sk, pk = bgv
+    vals = np.random.default_rng(n).integers(0, T_REF, size=P.N, dtype=np.uint64)
+    ct = P.encrypt(pk, P.encode(vals))
+    gl = P.inner_sum_galois_elements(n)
+    assert len(gl) == n.bit_length() - 1
+    out = P.inner_sum(ct, n, [P.keygen_galois(sk, g) for g in gl])
+    assert int(P.decrypt(sk, out, 1)[0]) == int(np.sum(vals[:n].astype(object)) % T_REF)
+
+
+def test_fhe_encode_decrypts_to_plain_encode(oracle, bgv):
+    """TestEncode (fhe/code_test.go:14-123): Dec(fhe.Encode(Enc(M))) == core.Encode(M) row by row."""
+    P, sk, pk = bgv
+    rows, cols, rho = P.N // 2, 16, 2
+    W = oracle.witness(rows, cols, T_REF)
+    roots = oracle.field_roots(T_REF, cols * rho)
+    cts = np.stack([P.encrypt(pk, P.encode(W[:, j])) for j in range(cols)])
+    zero = P.encrypt(pk, P.encode(np.zeros(rows, dtype=np.uint64)))
+    enc = P.ct_encode(cts, rho, zero, roots)
+    dec = np.stack([P.decrypt(sk, enc[j], rows) for j in range(cols * rho)], axis=1)
+    ref = np.stack([oracle.plain_encode(W[i], rho, T_REF, roots) for i in range(rows)])
+    assert np.array_equal(dec, ref)
+
+
+def test_ligero_e2e_on_oracle(oracle, bgv):
+    """TestLigeroE2E (fhe/ligero_test.go:70-176) on a small shape: Commit + Prove on ciphertexts,
+    decrypt, then the checks of Proof.Verify (ligero.go:517-574) and the MatR/MatZ comparison
+    against the plain prover (ligero.go:799-953)."""
+    from oracle.loader import Transcript
+    P, sk, pk = bgv
+    rows, cols, rho, queries = P.N // 2, 16, 2, 12
+    S = cols * rho
+    W = oracle.witness(rows, cols, T_REF)
+    roots = oracle.field_roots(T_REF, S)
+    cts = np.stack([P.encrypt(pk, P.encode(W[:, j])) for j in range(cols)])
+    zero = P.encrypt(pk, P.encode(np.zeros(rows, dtype=np.uint64)))
+    # Commit
+    enc = P.ct_encode(cts, rho, zero, roots)
+    lvl1, dig = P.commit_leaves(enc)
+    nodes, root = oracle.merkle(dig)
+    # Prove
+    tr = Transcript(oracle, "test")
+    r = np.array([tr.sample_u64("r") for _ in range(rows)], dtype=np.uint64)  # raw u64 (ligero.go:202-203)
+    z = 1
+    b = np.array([pow(pow(z, cols, T_REF), i, T_REF) for i in range(rows)], dtype=np.uint64)
+    gl = P.inner_sum_galois_elements(rows)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    mat_r = P.matrix_inner_sum(cts, P.encode(r), rows, evks)
+    mat_z = P.matrix_inner_sum(cts, P.encode(b), rows, evks)
+    tr.append("point", int(z).to_bytes(8, "little"))
+    qidx = [tr.sample_u64("query") % S for _ in range(queries)]
+    # client: decrypt
+    sc = P.rescale_scale(P.L, 2)
+    R = np.array([int(P.decrypt(sk, mat_r[j], 1, sc)[0]) for j in range(cols)], dtype=np.uint64)
+    Z = np.array([int(P.decrypt(sk, mat_z[j], 1, sc)[0]) for j in range(cols)], dtype=np.uint64)
+    # plain prover equality (ligero_test.go:164-174)
+    rT = r.astype(object) % T_REF
+    Wo = W.astype(object)
+    assert [int(x) for x in R] == [int(np.sum(Wo[:, j] * rT) % T_REF) for j in range(cols)]
+    assert [int(x) for x in Z] == [int(np.sum(Wo[:, j] * b.astype(object)) % T_REF) for j in range(cols)]
+    # Verify (ligero.go:554-571)
+    encR = oracle.plain_encode(R, rho, T_REF, roots)
+    encZ = oracle.plain_encode(Z, rho, T_REF, roots)
+    for qi in qidx:
+        col = P.decrypt(sk, lvl1[qi], rows, sc).astype(object)
+        assert oracle.merkle_verify(dig[qi].tobytes(), oracle.merkle_path(nodes, S, qi), root, qi)
+        assert int(np.sum(col * rT) % T_REF) == int(encR[qi])
+        assert int(np.sum(col * b.astype(object)) % T_REF) == int(encZ[qi])
+    a = [pow(z, i, T_REF) for i in range(cols)]
+    value = int(np.sum(Wo.reshape(-1))) % T_REF  # P(1): Horner at z = 1 (core/poly.go:21-30)
+    assert sum(int(Z[j]) * a[j] for j in range(cols)) % T_REF == value
+
+
+@pytest.mark.parametrize("S", [16, 32, 64])
+def test_golden_encode(oracle, S):
+    from oracle.loader import Params
+    g = np.load(os.path.join(GOLD, f"encode_S{S}.npz"))
+    P = Params.from_moduli(oracle, int(g["log_n"]), [int(x) for x in g["q"]], [int(x) for x in g["p"]], int(g["T"]))
+    assert P.psi == [int(x) for x in g["psi"]]
+    assert np.array_equal(P.ct_encode(g["matrix"], 2, g["zero"], g["roots"]), g["encoded"])
+
+
+def test_golden_evaluator(oracle):
+    from oracle.loader import Params
+    g = np.load(os.path.join(GOLD, "evaluator.npz"))
+    P = Params.from_moduli(oracle, int(g["log_n"]), [int(x) for x in g["q"]], [int(x) for x in g["p"]], int(g["T"]))
+    lvl1, dig = P.commit_leaves(g["cts"])
+    assert np.array_equal(lvl1, g["level1"]) and np.array_equal(dig, g["digests"])
+    assert [int(x) for x in g["gal_els"]] == P.inner_sum_galois_elements(int(g["rows"]))
+    got = P.matrix_inner_sum(g["cts"], g["pt"], int(g["rows"]), list(g["evks"]))
+    assert np.array_equal(got, g["matrix_inner_sum"])

@@ -145,9 +145,11 @@ static inline uint32_t h_bitrev(uint32_t x, int bits) {
 // ---- cross-TU launch helpers
 // all limbs of `npoly` polynomials stored [npoly][period][N]; limb j uses modulus map.idx[j]
 int lm_launch_ntt(lumen_ctx *ctx, u64 *d, uint32_t npoly, const lm_modmap &map, bool inverse);
+struct lm_ninv_t;
+// inv_scale: per-modulus multiplier applied by the inverse transform instead of N^-1 (NULL = N^-1)
 int lm_launch_ntt_strided(lumen_ctx *ctx, const u64 *src, size_t src_poly_stride, u64 *dst,
                           size_t dst_poly_stride, uint32_t npoly, const lm_modmap &map, bool inverse,
-                          const char *prof_name);
+                          const char *prof_name, const lm_ninv_t *inv_scale = nullptr);
 int lm_rescale_polys(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
                      uint32_t npoly, u64 *work, u64 *tbuf);
 lm_modmap lm_map_q(uint32_t nl);

@@ -6,7 +6,7 @@
 // Montgomery form).
 #include <cstring>
 
-#include "lm_common.h"
+#include "lm_ntt_dev.h"
 
 thread_local std::string lm_global_err;
 
@@ -107,7 +107,8 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
     *out = nullptr;
     LM_CHECK(nullptr, desc->abi_version == LUMEN_ABI_VERSION, "ABI version mismatch: got %u want %u",
              desc->abi_version, LUMEN_ABI_VERSION);
-    LM_CHECK(nullptr, desc->log_n >= 6 && desc->log_n <= 16, "log_n %u out of range [6,16]", desc->log_n);
+    LM_CHECK(nullptr, lm_logn_supported(desc->log_n),
+             "log_n %u unsupported: kernels are instantiated for N = 2^8 and 2^10..2^16", desc->log_n);
     LM_CHECK(nullptr, desc->num_q >= 1 && desc->num_q + desc->num_p <= LM_MAX_LIMBS,
              "bad limb counts L=%u K=%u", desc->num_q, desc->num_p);
     int ndev = 0;
@@ -128,8 +129,9 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
     uint64_t two_n = 2ull * N;
     for (uint32_t i = 0; i < LK; i++) {
         uint64_t q = desc->moduli[i], psi = desc->psi[i];
-        // the lazy forward NTT lets values grow to (2*logN + 1) * q before its one reduction
-        const uint64_t qmax = UINT64_MAX / (2ull * desc->log_n + 2);
+        // the lazy forward NTT takes inputs below 7q (fused basis extension) and lets values grow
+        // by 3q per stage before its one reduction
+        const uint64_t qmax = UINT64_MAX / (3ull * desc->log_n + 8);
         if (q < (1ull << 20) || q > qmax || (q & (two_n - 1)) != 1) {
             delete ctx;
             return lm_fail(nullptr, "modulus %u (%llu) must be == 1 mod 2N and below %llu", i,

@@ -26,28 +26,58 @@
 
 #define LM_KS_BATCH 64 // columns processed together (scratch ~ 172 limbs per column)
 
-// constants of one basis extension (sources m_0..m_{ns-1} -> target t)
+// constants of one basis extension (sources m_0..m_{ns-1} -> target t).
+// The source-side factors y_a = x_a * (M/m_a)^-1 mod m_a do not depend on the target: they are
+// produced once, fused into the N^-1 scaling of the INTT that brings the sources to the
+// coefficient domain, and the correction term v is packed into bit 63 of y_0 (k_pack_v).
 struct bx_t {
-    tw_t hat_inv[2];   // (M/m_a)^-1 mod m_a
     tw_t hat_mod_t[2]; // (M/m_a) mod t
-    tw_t m_mod_t;      // M mod t
-    u64 src_mod[2];
+    u64 t_minus_m;     // t - (M mod t)
     uint32_t ns;       // 1: plain reduction, 2: float-corrected reconstruction
     uint32_t own;      // target limb belongs to the digit: no extension
 };
+#define LM_V_BIT 63
 
-__device__ __forceinline__ u64 bx_apply(const bx_t &c, u64 x0, u64 x1, u64 t, u64 tinv64) {
-    if (c.ns == 1) return lm_reduce(x0, t, tinv64);
-    const u64 y0 = lm_shoup(x0, c.hat_inv[0], c.src_mod[0]);
-    const u64 y1 = lm_shoup(x1, c.hat_inv[1], c.src_mod[1]);
+// lazy value (< 7t) congruent to the extension of the digit to modulus t
+__device__ __forceinline__ u64 bx_apply(const bx_t &c, u64 y0v, u64 y1, const lm_qc &qc) {
+    if (c.ns == 1) return lm_shoup3<true>(y0v, 1ull, qc.qinv64, qc.nq); // x mod t, lazily
+    const u64 y0 = y0v & ~(1ull << LM_V_BIT);
+    u64 r = lm_shoup3<true>(y0, c.hat_mod_t[0].w, c.hat_mod_t[0].wp, qc.nq) +
+            lm_shoup3<true>(y1, c.hat_mod_t[1].w, c.hat_mod_t[1].wp, qc.nq); // < 6t
+    if (y0v >> LM_V_BIT) r += c.t_minus_m;                                     // - v*M (mod t)
+    return r;
+}
+
+// v = uint64(float64(y0)/float64(m0) + float64(y1)/float64(m1))  ([LATTIGO-RECALL] reconstructRNS).
+// The double expression is within 2^-49 of S = (y0*m1 + y1*m0) / (m0*m1), so unless S is that close
+// to 1 its truncation equals [S >= 1], which is decided exactly in 128-bit integers; only the
+// (probability ~2^-46) near-tie falls back to the literal double computation.
+__device__ __forceinline__ u32 bx_v(u64 y0, u64 y1, u64 m0, u64 m1) {
+    const u128 A = (u128)y0 * m1 + (u128)y1 * m0, M = (u128)m0 * m1;
+    const u128 D = A >= M ? A - M : M - A;
+    if ((u64)(D >> 64) >= 8) return A >= M ? 1u : 0u;
     double vf = 0.0;
-    vf += (double)y0 / (double)c.src_mod[0];
-    vf += (double)y1 / (double)c.src_mod[1];
-    const u64 v = (u64)vf;
-    u64 acc = lm_shoup(y0, c.hat_mod_t[0], t) + lm_shoup(y1, c.hat_mod_t[1], t); // < 2t
-    acc = lm_csub(acc, t);
-    const u64 corr = lm_shoup(v, c.m_mod_t, t);
-    return lm_submod(acc, corr, t);
+    vf += (double)y0 / (double)m0;
+    vf += (double)y1 / (double)m1;
+    return (u32)(u64)vf;
+}
+
+// y0[b][i] |= v << 63 for every two-limb source group.  y: [npoly][stride] with the group's two
+// limbs at limb offsets lo, lo+1.
+__global__ void k_pack_v(u64 *__restrict__ y, size_t poly_stride, uint32_t npoly, uint32_t ngroups,
+                         uint32_t group_limbs, uint32_t first_mod, uint32_t nlimbs_total, uint32_t logN,
+                         lm_mods mods) {
+    const uint32_t N = 1u << logN;
+    const size_t total = (size_t)npoly * ngroups * N, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint32_t i = (uint32_t)(g & (N - 1));
+        const uint32_t grp = (uint32_t)((g >> logN) % ngroups), p = (uint32_t)((g >> logN) / ngroups);
+        const uint32_t l0 = grp * group_limbs;
+        if (l0 + 1 >= nlimbs_total) continue; // single-limb group: no correction term
+        u64 *y0 = y + (size_t)p * poly_stride + (size_t)l0 * N + i;
+        const u64 a = *y0, b = y0[N];
+        *y0 = a | ((u64)bx_v(a, b, mods.m[first_mod + l0].q, mods.m[first_mod + l0 + 1].q) << LM_V_BIT);
+    }
 }
 
 // ---- step 0: MulNew(ct, pt): out = ct (.) (pt * T)
@@ -63,14 +93,15 @@ __global__ void k_mul_plain(const u64 *__restrict__ ct, u64 *__restrict__ out, c
 }
 
 // ---- step 2: digit extension + NTT.  One workgroup per (column b, digit d, target t).
-// coef: [B][L][N] coefficient-domain c1; c1ntt: acc c1 (NTT) with poly stride; ext: [B][beta][L+K][N]
+// coef: [B][L][N] coefficient-domain c1; acc: [B][2][L][N] (c1 NTT values for own limbs); ext: [B][beta][L+K][N]
+template <int LOGN>
 __global__ __launch_bounds__(1024) void k_modup_ntt(const u64 *__restrict__ coef, const u64 *__restrict__ acc,
                                                     u64 *__restrict__ ext, const bx_t *__restrict__ bx,
                                                     uint32_t B, uint32_t L, uint32_t K, uint32_t beta,
-                                                    uint32_t logN, lm_mods mods,
-                                                    const tw_t *__restrict__ tw_all) {
+                                                    lm_mods mods, const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
-    const uint32_t N = 1u << logN, tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
     // target-major order keeps one twiddle table hot per XCD L2
     uint32_t r = blockIdx.x;
     const uint32_t b = r % B;
@@ -85,24 +116,18 @@ __global__ __launch_bounds__(1024) void k_modup_ntt(const u64 *__restrict__ coef
             *reinterpret_cast<ulonglong2 *>(o + i) = *reinterpret_cast<const ulonglong2 *>(s + i);
         return;
     }
-    const u64 q = mods.m[t].q, qinv64 = mods.m[t].qinv64;
+    const lm_qc qc = lm_make_qc(mods.m[t]);
     const u64 *s0 = coef + ((size_t)b * L + d * K) * N;
-    const u64 *s1 = s0 + N; // second limb of the digit (unused when ns == 1)
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(s0 + i);
-        ulonglong2 bb = a;
-        if (c.ns == 2) bb = *reinterpret_cast<const ulonglong2 *>(s1 + i);
-        sm[LM_PAD(i)] = bx_apply(c, a.x, bb.x, q, qinv64);
-        sm[LM_PAD(i + 1)] = bx_apply(c, a.y, bb.y, q, qinv64);
-    }
-    __syncthreads();
-    lds_fwd_transform(sm, logN, tw_all + (size_t)t * N, q, tid, nthreads);
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        ulonglong2 v;
-        v.x = lm_reduce(sm[LM_PAD(i)], q, qinv64);
-        v.y = lm_reduce(sm[LM_PAD(i + 1)], q, qinv64);
-        *reinterpret_cast<ulonglong2 *>(o + i) = v;
-    }
+    const u64 *s1 = c.ns == 2 ? s0 + N : s0; // second limb of the digit
+    auto ld = [&](uint32_t i) { return bx_apply(c, s0[i], s1[i], qc); };
+    auto st = [&](uint32_t i0, const u64 *v, int count) {
+        u64 rr[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < count) rr[k] = lm_reduce(v[k], qc.q, qc.qinv64);
+        lm_store_run(o, i0, rr, count);
+    };
+    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);
 }
 
 // ---- step 3: gadget product.  u[b][w][t][i] = sum_d ext[b][d][t][i] * key[d][w][t][i]
@@ -145,45 +170,41 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
 // ---- step 4: ModDown.  One workgroup per (column b, poly w, Q limb t):
 // lift of the (coefficient-domain) P limbs into q_t fused into the load, NTT in
 // LDS, then d = (u_t - lift) * P^-1 (+ c0 for w == 0) fused into the store.
+template <int LOGN>
 __global__ __launch_bounds__(1024) void k_moddown_ntt(const u64 *__restrict__ u, const u64 *__restrict__ acc,
                                                       u64 *__restrict__ dout, const bx_t *__restrict__ bxp,
                                                       const tw_t *__restrict__ pinv, uint32_t B, uint32_t L,
-                                                      uint32_t K, uint32_t logN, lm_mods mods,
-                                                      const tw_t *__restrict__ tw_all) {
+                                                      uint32_t K, lm_mods mods, const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
-    const uint32_t N = 1u << logN, tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
     uint32_t r = blockIdx.x;
     const uint32_t pw = r % (B * 2); // b*2 + w
     const uint32_t t = r / (B * 2);
     const uint32_t w = pw & 1;
     const bx_t c = bxp[t];
-    const u64 q = mods.m[t].q, qinv64 = mods.m[t].qinv64;
-    const u64 *up = u + ((size_t)pw * LK + L) * N; // P limbs of u, coefficient domain
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(up + i);
-        ulonglong2 bb = a;
-        if (c.ns == 2) bb = *reinterpret_cast<const ulonglong2 *>(up + N + i);
-        sm[LM_PAD(i)] = bx_apply(c, a.x, bb.x, q, qinv64);
-        sm[LM_PAD(i + 1)] = bx_apply(c, a.y, bb.y, q, qinv64);
-    }
-    __syncthreads();
-    lds_fwd_transform(sm, logN, tw_all + (size_t)t * N, q, tid, nthreads);
+    const lm_qc qc = lm_make_qc(mods.m[t]);
+    const u64 *up0 = u + ((size_t)pw * LK + L) * N; // P limbs of u, coefficient domain
+    const u64 *up1 = c.ns == 2 ? up0 + N : up0;
     const u64 *uq = u + ((size_t)pw * LK + t) * N;
     const u64 *c0 = acc + ((size_t)pw * L + t) * N; // only read when w == 0
     u64 *o = dout + ((size_t)pw * L + t) * N;
     const tw_t pi = pinv[t];
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        const ulonglong2 uv = *reinterpret_cast<const ulonglong2 *>(uq + i);
-        ulonglong2 v;
-        v.x = lm_shoup(lm_submod(uv.x, lm_reduce(sm[LM_PAD(i)], q, qinv64), q), pi, q);
-        v.y = lm_shoup(lm_submod(uv.y, lm_reduce(sm[LM_PAD(i + 1)], q, qinv64), q), pi, q);
-        if (w == 0) {
-            const ulonglong2 cv = *reinterpret_cast<const ulonglong2 *>(c0 + i);
-            v.x = lm_addmod(v.x, cv.x, q);
-            v.y = lm_addmod(v.y, cv.y, q);
-        }
-        *reinterpret_cast<ulonglong2 *>(o + i) = v;
-    }
+    auto ld = [&](uint32_t i) { return bx_apply(c, up0[i], up1[i], qc); };
+    auto st = [&](uint32_t i0, const u64 *v, int count) {
+        u64 uv[8], cv[8], rr[8];
+        lm_load_run(uq, i0, uv, count);
+        if (w == 0) lm_load_run(c0, i0, cv, count);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < count) {
+                u64 x = lm_shoup(lm_submod(uv[k], lm_reduce(v[k], qc.q, qc.qinv64), qc.q), pi, qc.q);
+                if (w == 0) x = lm_addmod(x, cv[k], qc.q);
+                rr[k] = x;
+            }
+        lm_store_run(o, i0, rr, count);
+    };
+    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);
 }
 
 // ---- step 5: acc[k][i] += d[k][index[i]]  (NTT-domain automorphism gather)
@@ -208,6 +229,7 @@ struct KsTables {
     bx_t *d_bxp = nullptr;   // [L]  (P -> q_t)
     tw_t *d_pinv = nullptr;  // [L]  P^-1 mod q_t
     uint32_t beta = 0;
+    lm_ninv_t yscale; // per modulus: N^-1 * (M/m)^-1 mod m of the source group the modulus sits in
     ~KsTables() {
         hipFree(d_bx);
         hipFree(d_bxp);
@@ -221,19 +243,22 @@ bx_t make_bx(const uint64_t *src, uint32_t ns, uint64_t t) {
     c.ns = ns;
     uint64_t m_mod_t = 1;
     for (uint32_t a = 0; a < ns; a++) {
-        uint64_t h = 1, ht = 1;
-        for (uint32_t b = 0; b < ns; b++) {
-            if (b == a) continue;
-            h = h_mulmod(h, src[b] % src[a], src[a]);
-            ht = h_mulmod(ht, src[b] % t, t);
-        }
-        c.hat_inv[a] = h_tw(h_invmod(h, src[a]), src[a]);
+        uint64_t ht = 1;
+        for (uint32_t b = 0; b < ns; b++)
+            if (b != a) ht = h_mulmod(ht, src[b] % t, t);
         c.hat_mod_t[a] = h_tw(ht, t);
-        c.src_mod[a] = src[a];
         m_mod_t = h_mulmod(m_mod_t, src[a] % t, t);
     }
-    c.m_mod_t = h_tw(m_mod_t, t);
+    c.t_minus_m = t - m_mod_t;
     return c;
+}
+
+// (M/m_a)^-1 mod m_a for source a of the group src[0..ns)
+uint64_t hat_inv(const uint64_t *src, uint32_t ns, uint32_t a) {
+    uint64_t h = 1;
+    for (uint32_t b = 0; b < ns; b++)
+        if (b != a) h = h_mulmod(h, src[b] % src[a], src[a]);
+    return h_invmod(h, src[a]);
 }
 
 int get_tables(lumen_ctx *ctx, KsTables **out) {
@@ -255,6 +280,18 @@ int get_tables(lumen_ctx *ctx, KsTables **out) {
             c.own = (t >= lo && t < hi) ? 1 : 0;
             bx[(size_t)d * LK + t] = c;
         }
+    }
+    for (uint32_t i = 0; i < LM_MAX_LIMBS; i++) tb.yscale.t[i] = ctx->ninv[i < LK ? i : 0];
+    for (uint32_t d = 0; d < tb.beta; d++) {
+        const uint32_t lo = d * K, hi = std::min(lo + K, L), ns = hi - lo;
+        for (uint32_t a = 0; a < ns; a++) {
+            const uint64_t m = ctx->mod[lo + a];
+            tb.yscale.t[lo + a] = h_tw(h_mulmod(ctx->ninv[lo + a].w, hat_inv(ctx->mod + lo, ns, a), m), m);
+        }
+    }
+    for (uint32_t a = 0; a < K; a++) {
+        const uint64_t m = ctx->mod[L + a];
+        tb.yscale.t[L + a] = h_tw(h_mulmod(ctx->ninv[L + a].w, hat_inv(ctx->mod + L, K, a), m), m);
     }
     std::vector<bx_t> bxp(L);
     std::vector<tw_t> pinv(L);
@@ -296,16 +333,31 @@ int rotate_accumulate(lumen_ctx *ctx, u64 *acc, uint32_t B, const lm_galois_key 
     const uint32_t threads = lm_ntt_threads(N);
     // 1. c1 -> coefficient domain
     if (int rc = lm_launch_ntt_strided(ctx, acc + (size_t)L * N, (size_t)2 * L * N, s.coef, (size_t)L * N, B,
-                                       lm_map_q(L), true, "ks_intt_c1"))
+                                       lm_map_q(L), true, "ks_intt_c1", &tb->yscale))
         return rc;
+    if (K == 2) {
+        lm_prof_scope ps(ctx, "ks_pack_v", (uint64_t)B);
+        hipLaunchKernelGGL(k_pack_v, dim3(2048), dim3(256), 0, ctx->stream, s.coef, (size_t)L * N, B, beta, K, 0u,
+                           L, ctx->logN, ctx->mods);
+        LM_HIP(ctx, hipGetLastError());
+    }
     // 2. digit extension + NTT
     {
-        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_modup_ntt),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const uint64_t nb = (uint64_t)B * beta * LK;
         lm_prof_scope ps(ctx, "ks_modup_ntt", (uint64_t)B * (beta * LK - L));
-        hipLaunchKernelGGL(k_modup_ntt, dim3((uint32_t)nb), dim3(threads), lds, ctx->stream, s.coef, acc, s.ext,
-                           tb->d_bx, B, L, K, beta, ctx->logN, ctx->mods, ctx->d_tw_fwd);
+        switch (ctx->logN) {
+#define LM_CASE(n)                                                                                            \
+    case n:                                                                                                   \
+        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_modup_ntt<n>),                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        hipLaunchKernelGGL(k_modup_ntt<n>, dim3((uint32_t)nb), dim3(threads), lds, ctx->stream, s.coef, acc,  \
+                           s.ext, tb->d_bx, B, L, K, beta, ctx->mods, ctx->d_tw_fwd);                         \
+        break;
+            LM_FOR_EACH_LOGN(LM_CASE)
+#undef LM_CASE
+        default:
+            return lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
+        }
         LM_HIP(ctx, hipGetLastError());
     }
     // 3. gadget product
@@ -322,16 +374,31 @@ int rotate_accumulate(lumen_ctx *ctx, u64 *acc, uint32_t B, const lm_galois_key 
         mp.period = K;
         for (uint32_t i = 0; i < LM_MAX_LIMBS; i++) mp.idx[i] = (uint8_t)(L + (i < K ? i : 0));
         if (int rc = lm_launch_ntt_strided(ctx, s.u + (size_t)L * N, (size_t)LK * N, s.u + (size_t)L * N,
-                                           (size_t)LK * N, B * 2, mp, true, "ks_intt_p"))
+                                           (size_t)LK * N, B * 2, mp, true, "ks_intt_p", &tb->yscale))
             return rc;
+        if (K == 2) {
+            lm_prof_scope ps(ctx, "ks_pack_v", (uint64_t)B);
+            hipLaunchKernelGGL(k_pack_v, dim3(2048), dim3(256), 0, ctx->stream, s.u + (size_t)L * N,
+                               (size_t)LK * N, B * 2, 1u, K, L, K, ctx->logN, ctx->mods);
+            LM_HIP(ctx, hipGetLastError());
+        }
     }
     // 4b. lift to Q, NTT, combine
     {
-        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_moddown_ntt),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lm_prof_scope ps(ctx, "ks_moddown_ntt", (uint64_t)B * 2 * L);
-        hipLaunchKernelGGL(k_moddown_ntt, dim3(B * 2 * L), dim3(threads), lds, ctx->stream, s.u, acc, s.dout,
-                           tb->d_bxp, tb->d_pinv, B, L, K, ctx->logN, ctx->mods, ctx->d_tw_fwd);
+        switch (ctx->logN) {
+#define LM_CASE(n)                                                                                            \
+    case n:                                                                                                   \
+        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_moddown_ntt<n>),                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        hipLaunchKernelGGL(k_moddown_ntt<n>, dim3(B * 2 * L), dim3(threads), lds, ctx->stream, s.u, acc,      \
+                           s.dout, tb->d_bxp, tb->d_pinv, B, L, K, ctx->mods, ctx->d_tw_fwd);                 \
+        break;
+            LM_FOR_EACH_LOGN(LM_CASE)
+#undef LM_CASE
+        default:
+            return lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
+        }
         LM_HIP(ctx, hipGetLastError());
     }
     // 5. automorphism + accumulate

@@ -15,47 +15,37 @@
 // pass (8 consecutive coefficients per lane) over all 64 banks.
 #include "lm_ntt_dev.h"
 
-template <bool INV>
-__global__ __launch_bounds__(1024) void k_limb_ntt(const u64 *src, size_t src_poly_stride,
-                                                   u64 *dst, size_t dst_poly_stride,
-                                                   uint32_t logN, uint32_t npoly, lm_modmap map,
+template <int LOGN, bool INV>
+__global__ __launch_bounds__(1024) void k_limb_ntt(const u64 *src, size_t src_poly_stride, u64 *dst,
+                                                   size_t dst_poly_stride, uint32_t npoly, lm_modmap map,
                                                    lm_mods mods, lm_ninv_t ninv,
                                                    const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
-    const uint32_t N = 1u << logN, tid = threadIdx.x, nthreads = blockDim.x;
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     // limb-major block order: consecutive workgroups share a modulus, so only
     // one or two twiddle tables are live in each XCD's L2 at a time
     const uint32_t limb = blockIdx.x / npoly, poly = blockIdx.x % npoly;
     const uint32_t mi = map.idx[limb];
-    const u64 q = mods.m[mi].q;
+    const lm_qc c = lm_make_qc(mods.m[mi]);
     const u64 *p = src + (size_t)poly * src_poly_stride + (size_t)limb * N;
     u64 *o = dst + (size_t)poly * dst_poly_stride + (size_t)limb * N;
     const tw_t *tw = tw_all + (size_t)mi * N;
-
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + i);
-        sm[LM_PAD(i)] = v.x;
-        sm[LM_PAD(i + 1)] = v.y;
-    }
-    __syncthreads();
-    if (INV)
-        lds_inv_transform(sm, logN, tw, q, tid, nthreads);
-    else
-        lds_fwd_transform(sm, logN, tw, q, tid, nthreads);
-    const u64 qinv64 = mods.m[mi].qinv64;
-    const tw_t ni = ninv.t[mi];
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        ulonglong2 v;
-        v.x = sm[LM_PAD(i)];
-        v.y = sm[LM_PAD(i + 1)];
-        if (INV) {
-            v.x = lm_shoup(v.x, ni, q);
-            v.y = lm_shoup(v.y, ni, q);
-        } else {
-            v.x = lm_reduce(v.x, q, qinv64);
-            v.y = lm_reduce(v.y, q, qinv64);
-        }
-        *reinterpret_cast<ulonglong2 *>(o + i) = v;
+    if (INV) {
+        const tw_t ni = ninv.t[mi];
+        auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
+        auto st = [&](uint32_t i, u64 v) { o[i] = lm_shoup(v, ni, c.q); };
+        lm_ntt_inverse<LOGN>(sm, tw, c, tid, nthreads, ld, st);
+    } else {
+        auto ld = [&](uint32_t i) { return p[i]; };
+        auto st = [&](uint32_t i0, const u64 *v, int count) {
+            u64 r[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < count) r[k] = lm_reduce(v[k], c.q, c.qinv64);
+            lm_store_run(o, i0, r, count);
+        };
+        lm_ntt_forward<LOGN>(sm, tw, c, tid, nthreads, ld, st);
     }
 }
 
@@ -64,35 +54,43 @@ __global__ __launch_bounds__(1024) void k_limb_ntt(const u64 *src, size_t src_po
 // (src == dst allowed) with modulus map.idx[j].
 int lm_launch_ntt_strided(lumen_ctx *ctx, const u64 *src, size_t src_poly_stride, u64 *dst,
                           size_t dst_poly_stride, uint32_t npoly, const lm_modmap &map, bool inverse,
-                          const char *prof_name) {
+                          const char *prof_name, const lm_ninv_t *inv_scale) {
     if (!npoly || !map.period) return 0;
     const uint32_t N = ctx->N;
-    const lm_ninv_t ninv = lm_ninv_of(ctx);
+    const lm_ninv_t ninv = inv_scale ? *inv_scale : lm_ninv_of(ctx);
     const size_t lds = lm_ntt_lds_bytes(N);
     const uint32_t threads = lm_ntt_threads(N);
     const uint64_t nblocks64 = (uint64_t)npoly * map.period;
     LM_CHECK(ctx, nblocks64 < (1ull << 31), "NTT grid too large: %llu", (unsigned long long)nblocks64);
     lm_prof_scope ps(ctx, prof_name ? prof_name : (inverse ? "limb_intt" : "limb_ntt"), nblocks64);
-    if (inverse) {
-        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_limb_ntt<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_limb_ntt<true>, dim3((uint32_t)nblocks64), dim3(threads), lds, ctx->stream, src,
-                           src_poly_stride, dst, dst_poly_stride, ctx->logN, npoly, map, ctx->mods, ninv,
-                           ctx->d_tw_inv);
-    } else {
-        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_limb_ntt<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_limb_ntt<false>, dim3((uint32_t)nblocks64), dim3(threads), lds, ctx->stream, src,
-                           src_poly_stride, dst, dst_poly_stride, ctx->logN, npoly, map, ctx->mods, ninv,
-                           ctx->d_tw_fwd);
+    const dim3 grid((uint32_t)nblocks64), block(threads);
+#define LM_LAUNCH(n)                                                                                          \
+    case n:                                                                                                   \
+        if (inverse) {                                                                                        \
+            LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_limb_ntt<n, true>),             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+            hipLaunchKernelGGL((k_limb_ntt<n, true>), grid, block, lds, ctx->stream, src, src_poly_stride,    \
+                               dst, dst_poly_stride, npoly, map, ctx->mods, ninv, ctx->d_tw_inv);             \
+        } else {                                                                                              \
+            LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_limb_ntt<n, false>),            \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+            hipLaunchKernelGGL((k_limb_ntt<n, false>), grid, block, lds, ctx->stream, src, src_poly_stride,   \
+                               dst, dst_poly_stride, npoly, map, ctx->mods, ninv, ctx->d_tw_fwd);             \
+        }                                                                                                     \
+        break;
+    switch (ctx->logN) {
+        LM_FOR_EACH_LOGN(LM_LAUNCH)
+    default:
+        return lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
     }
+#undef LM_LAUNCH
     LM_HIP(ctx, hipGetLastError());
     return 0;
 }
 
 int lm_launch_ntt(lumen_ctx *ctx, u64 *d, uint32_t npoly, const lm_modmap &map, bool inverse) {
     const size_t stride = (size_t)map.period * ctx->N;
-    return lm_launch_ntt_strided(ctx, d, stride, d, stride, npoly, map, inverse, nullptr);
+    return lm_launch_ntt_strided(ctx, d, stride, d, stride, npoly, map, inverse, nullptr, nullptr);
 }
 
 extern "C" int lumen_set_ntt(lumen_ctx *ctx, lumen_set *set, int inverse) {

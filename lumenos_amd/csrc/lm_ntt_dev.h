@@ -1,12 +1,53 @@
-// LDS-resident limb NTT building blocks (see lm_ntt.hip for the design notes).
+// LDS-resident limb NTT building blocks for gfx950 (design notes: lm_ntt.hip).
+//
+// v2 structure: a transform is a list of passes of R <= 3 butterfly stages.
+// A work item keeps 2^R coefficients in VGPRs for the R stages of a pass.
+//   * the FIRST pass reads its coefficients straight from global memory
+//     through a caller-supplied loader (which fuses e.g. an RNS basis extension
+//     or a modular reduction into the load) and leaves them in LDS;
+//   * middle passes go LDS -> LDS;
+//   * the LAST pass hands runs of finished coefficients to a caller-supplied
+//     storer (which fuses the final reduction and e.g. the rescale combine)
+//     that writes global memory.  So coefficients cross LDS P-1 times, not P+1.
+// Multiplications by twiddles are Shoup multiplications written as explicit
+// v_mad_u64_u32 chains (4.9 cycles per wave-op on MI355X against 8-10 for
+// v_mul_lo/hi_u32, profiles/r01_ubench_int_valu.txt), with the quotient
+// estimate truncated to three partial products: the result is in [0, 3q).
+// Twiddles of stages whose block index is wave-uniform are fetched with scalar
+// loads.
 #pragma once
+#include <cstring>
+
 #include "lm_common.h"
 
 #define LM_PAD(i) ((i) + ((i) >> 5))
+#define LM_MAX_PASSES 8
 
 struct lm_ninv_t {
     tw_t t[LM_MAX_LIMBS];
 };
+
+// Pass plan of a 2^logN transform, known at compile time (kernels are instantiated per ring
+// degree): as many radix-8 passes as possible, the remainder spread as radix-4 passes, big first.
+__host__ __device__ constexpr int lm_npasses(int logN) { return (logN + 2) / 3; }
+__host__ __device__ constexpr int lm_pass_r(int logN, int i) {
+    int n = lm_npasses(logN), rem = logN, r = 0;
+    for (int k = 0; k <= i; k++) {
+        const int left = n - k;
+        r = (rem + left - 1) / left;
+        if (r > 3) r = 3;
+        rem -= r;
+    }
+    return r;
+}
+// ring degrees the kernels are instantiated for
+#define LM_FOR_EACH_LOGN(X) X(8) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+static inline bool lm_logn_supported(uint32_t logN) {
+#define LM_CASE(n) if (logN == n) return true;
+    LM_FOR_EACH_LOGN(LM_CASE)
+#undef LM_CASE
+    return false;
+}
 
 static inline uint32_t lm_ntt_threads(uint32_t N) {
     uint32_t t = N / 8;
@@ -21,102 +62,303 @@ static inline lm_ninv_t lm_ninv_of(const lumen_ctx *ctx) {
     return n;
 }
 
-template <int R>
-__device__ __forceinline__ void fwd_pass(u64 *s, uint32_t logN, uint32_t s0, const tw_t *__restrict__ tw,
-                                         u64 q, uint32_t tid, uint32_t nthreads) {
-    const uint32_t log_tl = logN - s0 - R;
-    const uint32_t items = 1u << (logN - R);
-    const u64 twoq = 2 * q;
-    const uint32_t mA = 1u << s0;
+// ---- 32x32+64 multiply-add, forced onto v_mad_u64_u32.  One operand may live in an SGPR
+// (constant-bus limit of one scalar per VALU instruction on gfx9-family ISAs): wave-uniform
+// twiddles and the modulus words never occupy VGPRs or cost a v_mov.
+__device__ __forceinline__ u64 lm_mad(u32 a, u32 b, u64 c) {
+    u64 d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+}
+__device__ __forceinline__ u64 lm_mad0(u32 a, u32 b) {
+    u64 d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
+    return d;
+}
+__device__ __forceinline__ u64 lm_mad_s(u32 a, u32 b_uniform, u64 c) {
+    u64 d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c) : "vcc");
+    return d;
+}
+__device__ __forceinline__ u64 lm_mad0_s(u32 a, u32 b_uniform) {
+    u64 d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b_uniform) : "vcc");
+    return d;
+}
+
+// a*w mod q, lazily, for ANY a < 2^64: result in [0, 3q).  nq = 2^64 - q (wave-uniform).
+// t ~ floor(a*wp / 2^64) from three partial products (the a0*wp0 term and its
+// carry are dropped: t is exact or one short), then r = a*w + t*nq mod 2^64.
+// UW: the twiddle (w, wp) is wave-uniform (lives in SGPRs).
+template <bool UW>
+__device__ __forceinline__ u64 lm_shoup3(u64 a, u64 w, u64 wp, u64 nq) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
+    const u32 w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    u64 m1, m2, t, lo, acc;
+    if (UW) {
+        m1 = lm_mad0_s(a0, p1);
+        m2 = lm_mad_s(a1, p0, (u64)(u32)m1);
+        t = lm_mad_s(a1, p1, m1 >> 32) + (m2 >> 32);
+        lo = lm_mad0_s(a0, w0);
+    } else {
+        m1 = lm_mad0(a0, p1);
+        m2 = lm_mad(a1, p0, (u64)(u32)m1);
+        t = lm_mad(a1, p1, m1 >> 32) + (m2 >> 32);
+        lo = lm_mad0(a0, w0);
+    }
+    const u32 t0 = (u32)t, t1 = (u32)(t >> 32);
+    lo = lm_mad_s(t0, n0, lo);
+    if (UW) {
+        acc = lm_mad_s(a0, w1, lo >> 32);
+        acc = lm_mad_s(a1, w0, acc);
+    } else {
+        acc = lm_mad(a0, w1, lo >> 32);
+        acc = lm_mad(a1, w0, acc);
+    }
+    acc = lm_mad_s(t0, n1, acc);
+    acc = lm_mad_s(t1, n0, acc);
+    return (acc << 32) | (u32)lo;
+}
+// canonical a*w mod q for a constant multiplier held in SGPRs
+__device__ __forceinline__ u64 lm_shoup_cs(u64 a, tw_t W, u64 q, u64 nq) {
+    u64 r = lm_shoup3<true>(a, W.w, W.wp, nq);
+    r = lm_csub(r, 2 * q);
+    return lm_csub(r, q);
+}
+// x mod q for any x < 2^64 (mad-chain form of lm_reduce): Shoup step with w = 1
+__device__ __forceinline__ u64 lm_reduce_s(u64 x, u64 q, u64 nq, u64 qinv64) {
+    u64 r = lm_shoup3<true>(x, 1ull, qinv64, nq);
+    r = lm_csub(r, 2 * q);
+    return lm_csub(r, q);
+}
+
+struct lm_qc { // per-modulus constants of the lazy butterflies
+    u64 q, nq, q3, qinv64;
+};
+__device__ __forceinline__ lm_qc lm_make_qc(const mod_t &m) {
+    lm_qc c;
+    c.q = m.q;
+    c.nq = 0 - m.q;
+    c.q3 = 3 * m.q;
+    c.qinv64 = m.qinv64;
+    return c;
+}
+
+// forward (Cooley-Tukey) butterfly, fully lazy: both outputs grow by < 3q
+template <bool UW>
+__device__ __forceinline__ void lm_bfly_fwd(u64 &x, u64 &y, const tw_t W, const lm_qc &c) {
+    const u64 v = lm_shoup3<UW>(y, W.w, W.wp, c.nq);
+    y = x + c.q3 - v;
+    x = x + v;
+}
+// inverse (Gentleman-Sande) butterfly on values in [0, 3q), outputs in [0, 3q)
+template <bool UW>
+__device__ __forceinline__ void lm_bfly_inv(u64 &x, u64 &y, const tw_t W, const lm_qc &c) {
+    const u64 u = x, v = y;
+    x = lm_csub(u + v, c.q3);
+    y = lm_shoup3<UW>(u + c.q3 - v, W.w, W.wp, c.nq);
+}
+
+template <bool UW>
+__device__ __forceinline__ tw_t lm_tw_load(const tw_t *__restrict__ tw, uint32_t idx) {
+    if (UW) idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx); // -> scalar load
+    return tw[idx];
+}
+
+// R forward stages on e[0 .. 2^R), first stage index s0, block index blk
+template <int R, bool UW>
+__device__ __forceinline__ void lm_fwd_stages(u64 *e, uint32_t s0, uint32_t blk, const tw_t *__restrict__ tw,
+                                              const lm_qc &c) {
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int span = (1 << R) >> st, half = span >> 1;
+#pragma unroll
+        for (int g = 0; g < (1 << st); g++) {
+            const tw_t W = lm_tw_load<UW>(tw, ((1u << s0) << st) + (blk << st) + g);
+#pragma unroll
+            for (int k = 0; k < half; k++) lm_bfly_fwd<UW>(e[g * span + k], e[g * span + k + half], W, c);
+        }
+    }
+}
+
+// R inverse stages; log_t0 = log2 of the first stage's butterfly distance
+template <int R, bool UW>
+__device__ __forceinline__ void lm_inv_stages(u64 *e, uint32_t logN, uint32_t log_t0, uint32_t blk,
+                                              const tw_t *__restrict__ tw, const lm_qc &c) {
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int half = 1 << st, span = half << 1;
+        const uint32_t m = 1u << (logN - log_t0 - st - 1);
+#pragma unroll
+        for (int g = 0; g < ((1 << R) / span); g++) {
+            const tw_t W = lm_tw_load<UW>(tw, m + (blk << (R - st - 1)) + g);
+#pragma unroll
+            for (int k = 0; k < half; k++) lm_bfly_inv<UW>(e[g * span + k], e[g * span + k + half], W, c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ forward
+// Loader: u64 operator()(uint32_t i) -> coefficient i in [0, q)
+// Storer: void operator()(uint32_t i0, const u64 *v, int count) -> `count` consecutive lazy
+//         results (values < (3*logN+1)*q) starting at coefficient i0
+template <int R, class Loader>
+__device__ __forceinline__ void lm_fwd_first(u64 *s, uint32_t logN, const tw_t *tw, const lm_qc &c,
+                                             uint32_t tid, uint32_t nthreads, Loader &ld) {
+    const uint32_t log_tl = logN - R, items = 1u << log_tl;
+    for (uint32_t w = tid; w < items; w += nthreads) {
+        u64 e[1 << R];
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) e[k] = ld(w + ((uint32_t)k << log_tl));
+        lm_fwd_stages<R, true>(e, 0, 0, tw, c);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) s[LM_PAD(w + ((uint32_t)k << log_tl))] = e[k];
+    }
+}
+
+template <int R, bool UW>
+__device__ __forceinline__ void lm_fwd_mid(u64 *s, uint32_t logN, uint32_t s0, const tw_t *tw, const lm_qc &c,
+                                           uint32_t tid, uint32_t nthreads) {
+    const uint32_t log_tl = logN - s0 - R, items = 1u << (logN - R);
     for (uint32_t w = tid; w < items; w += nthreads) {
         const uint32_t blk = w >> log_tl, off = w & ((1u << log_tl) - 1);
         const uint32_t base = (blk << (log_tl + R)) + off;
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_tl))];
-#pragma unroll
-        for (int st = 0; st < R; st++) {
-            const int span = (1 << R) >> st, half = span >> 1;
-#pragma unroll
-            for (int g = 0; g < (1 << st); g++) {
-                const tw_t W = tw[(mA << st) + (blk << st) + g];
-#pragma unroll
-                for (int k = 0; k < half; k++) {
-                    const int i0 = g * span + k, i1 = i0 + half;
-                    const u64 v = lm_shoup_lazy(e[i1], W, q);
-                    e[i1] = e[i0] - v + twoq;
-                    e[i0] = e[i0] + v;
-                }
-            }
-        }
+        lm_fwd_stages<R, UW>(e, s0, blk, tw, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_tl))] = e[k];
     }
 }
 
-template <int R>
-__device__ __forceinline__ void inv_pass(u64 *s, uint32_t logN, uint32_t log_t0, const tw_t *__restrict__ tw,
-                                         u64 q, uint32_t tid, uint32_t nthreads) {
+template <int R, class Storer>
+__device__ __forceinline__ void lm_fwd_last(const u64 *s, uint32_t logN, const tw_t *tw, const lm_qc &c,
+                                            uint32_t tid, uint32_t nthreads, Storer &st) {
+    const uint32_t s0 = logN - R, items = 1u << (logN - R);
+    for (uint32_t w = tid; w < items; w += nthreads) {
+        const uint32_t base = w << R;
+        u64 e[1 << R];
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + k)];
+        lm_fwd_stages<R, false>(e, s0, w, tw, c);
+        st(base, e, 1 << R);
+    }
+}
+
+template <int LOGN, int P, int S0, class Loader, class Storer>
+__device__ __forceinline__ void lm_fwd_rec(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
+                                           uint32_t nthreads, Loader &ld, Storer &st) {
+    constexpr int NP = lm_npasses(LOGN), R = lm_pass_r(LOGN, P);
+    if constexpr (P == 0)
+        lm_fwd_first<R>(sm, LOGN, tw, c, tid, nthreads, ld);
+    else if constexpr (P == NP - 1)
+        lm_fwd_last<R>(sm, LOGN, tw, c, tid, nthreads, st);
+    else
+        lm_fwd_mid<R, (LOGN - S0 - R >= 6)>(sm, LOGN, S0, tw, c, tid, nthreads);
+    if constexpr (P + 1 < NP) {
+        __syncthreads();
+        lm_fwd_rec<LOGN, P + 1, S0 + R>(sm, tw, c, tid, nthreads, ld, st);
+    }
+}
+template <int LOGN, class Loader, class Storer>
+__device__ __forceinline__ void lm_ntt_forward(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
+                                               uint32_t nthreads, Loader &ld, Storer &st) {
+    lm_fwd_rec<LOGN, 0, 0>(sm, tw, c, tid, nthreads, ld, st);
+}
+
+// ------------------------------------------------------------------ inverse
+// Loader: void operator()(uint32_t i0, u64 *v, int count) -> `count` consecutive coefficients in [0, q)
+// Storer: void operator()(uint32_t i, u64 v) -> lazy result (< 3q, before the N^-1 scaling)
+template <int R, class Loader>
+__device__ __forceinline__ void lm_inv_first(u64 *s, uint32_t logN, const tw_t *tw, const lm_qc &c,
+                                             uint32_t tid, uint32_t nthreads, Loader &ld) {
     const uint32_t items = 1u << (logN - R);
-    const u64 twoq = 2 * q;
+    for (uint32_t w = tid; w < items; w += nthreads) {
+        const uint32_t base = w << R;
+        u64 e[1 << R];
+        ld(base, e, 1 << R);
+        lm_inv_stages<R, false>(e, logN, 0, w, tw, c);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + k)] = e[k];
+    }
+}
+
+template <int R, bool UW>
+__device__ __forceinline__ void lm_inv_mid(u64 *s, uint32_t logN, uint32_t log_t0, const tw_t *tw,
+                                           const lm_qc &c, uint32_t tid, uint32_t nthreads) {
+    const uint32_t items = 1u << (logN - R);
     for (uint32_t w = tid; w < items; w += nthreads) {
         const uint32_t blk = w >> log_t0, off = w & ((1u << log_t0) - 1);
         const uint32_t base = (blk << (log_t0 + R)) + off;
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_t0))];
-#pragma unroll
-        for (int st = 0; st < R; st++) {
-            const int half = 1 << st, span = half << 1;
-            const uint32_t m = 1u << (logN - log_t0 - st - 1);
-#pragma unroll
-            for (int g = 0; g < ((1 << R) / span); g++) {
-                const tw_t W = tw[m + (blk << (R - st - 1)) + g];
-#pragma unroll
-                for (int k = 0; k < half; k++) {
-                    const int i0 = g * span + k, i1 = i0 + half;
-                    const u64 u = e[i0], v = e[i1];
-                    e[i0] = lm_csub(u + v, twoq);
-                    e[i1] = lm_shoup_lazy(u - v + twoq, W, q);
-                }
-            }
-        }
+        lm_inv_stages<R, UW>(e, logN, log_t0, blk, tw, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_t0))] = e[k];
     }
 }
 
-__device__ __forceinline__ void lds_fwd_transform(u64 *sm, uint32_t logN, const tw_t *tw, u64 q,
-                                                  uint32_t tid, uint32_t nthreads) {
-    uint32_t s0 = 0;
-    while (logN - s0 >= 3) {
-        fwd_pass<3>(sm, logN, s0, tw, q, tid, nthreads);
-        s0 += 3;
-        __syncthreads();
-    }
-    if (logN - s0 == 2) {
-        fwd_pass<2>(sm, logN, s0, tw, q, tid, nthreads);
-        __syncthreads();
-    } else if (logN - s0 == 1) {
-        fwd_pass<1>(sm, logN, s0, tw, q, tid, nthreads);
-        __syncthreads();
+template <int R, class Storer>
+__device__ __forceinline__ void lm_inv_last(const u64 *s, uint32_t logN, const tw_t *tw, const lm_qc &c,
+                                            uint32_t tid, uint32_t nthreads, Storer &st) {
+    const uint32_t log_t0 = logN - R, items = 1u << log_t0;
+    for (uint32_t w = tid; w < items; w += nthreads) {
+        u64 e[1 << R];
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(w + ((uint32_t)k << log_t0))];
+        lm_inv_stages<R, true>(e, logN, log_t0, 0, tw, c);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) st(w + ((uint32_t)k << log_t0), e[k]);
     }
 }
 
-__device__ __forceinline__ void lds_inv_transform(u64 *sm, uint32_t logN, const tw_t *tw, u64 q,
-                                                  uint32_t tid, uint32_t nthreads) {
-    uint32_t lt = 0;
-    while (logN - lt >= 3) {
-        inv_pass<3>(sm, logN, lt, tw, q, tid, nthreads);
-        lt += 3;
+// the inverse runs the pass list backwards so that its stage grouping mirrors the forward one
+template <int LOGN, int P, int LT, class Loader, class Storer>
+__device__ __forceinline__ void lm_inv_rec(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
+                                           uint32_t nthreads, Loader &ld, Storer &st) {
+    constexpr int NP = lm_npasses(LOGN), R = lm_pass_r(LOGN, NP - 1 - P);
+    if constexpr (P == 0)
+        lm_inv_first<R>(sm, LOGN, tw, c, tid, nthreads, ld);
+    else if constexpr (P == NP - 1)
+        lm_inv_last<R>(sm, LOGN, tw, c, tid, nthreads, st);
+    else
+        lm_inv_mid<R, (LT >= 6)>(sm, LOGN, LT, tw, c, tid, nthreads);
+    if constexpr (P + 1 < NP) {
         __syncthreads();
-    }
-    if (logN - lt == 2) {
-        inv_pass<2>(sm, logN, lt, tw, q, tid, nthreads);
-        __syncthreads();
-    } else if (logN - lt == 1) {
-        inv_pass<1>(sm, logN, lt, tw, q, tid, nthreads);
-        __syncthreads();
+        lm_inv_rec<LOGN, P + 1, LT + R>(sm, tw, c, tid, nthreads, ld, st);
     }
 }
+template <int LOGN, class Loader, class Storer>
+__device__ __forceinline__ void lm_ntt_inverse(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
+                                               uint32_t nthreads, Loader &ld, Storer &st) {
+    lm_inv_rec<LOGN, 0, 0>(sm, tw, c, tid, nthreads, ld, st);
+}
 
+// ---- stock loaders / storers
+// consecutive coefficients move as 16-byte vectors
+__device__ __forceinline__ void lm_load_run(const u64 *p, uint32_t i0, u64 *v, int count) {
+    if (count == 2) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p + i0);
+        v[0] = a.x, v[1] = a.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            if (k < count) {
+                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p + i0 + k);
+                v[k] = a.x, v[k + 1] = a.y;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void lm_store_run(u64 *p, uint32_t i0, const u64 *v, int count) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        if (k < count) {
+            ulonglong2 a;
+            a.x = v[k], a.y = v[k + 1];
+            *reinterpret_cast<ulonglong2 *>(p + i0 + k) = a;
+        }
+    }
+}

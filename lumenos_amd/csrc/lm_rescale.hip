@@ -24,72 +24,57 @@ struct rescale_consts {
     tw_t qlinv[LM_MAX_LIMBS];   // q_l^-1 mod q_i
 };
 
+template <int LOGN>
 __global__ __launch_bounds__(1024) void k_rescale_last(const u64 *__restrict__ src, size_t src_poly_stride,
-                                                       uint32_t last, u64 *__restrict__ tbuf, uint32_t logN,
-                                                       mod_t md, tw_t ninv, u64 half,
-                                                       const tw_t *__restrict__ tw) {
+                                                       uint32_t last, u64 *__restrict__ tbuf, mod_t md,
+                                                       tw_t ninv, u64 half, const tw_t *__restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
-    const uint32_t N = 1u << logN, tid = threadIdx.x, nthreads = blockDim.x;
-    const u64 q = md.q;
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    const lm_qc c = lm_make_qc(md);
     const u64 *p = src + (size_t)blockIdx.x * src_poly_stride + (size_t)last * N;
     u64 *o = tbuf + (size_t)blockIdx.x * N;
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + i);
-        sm[LM_PAD(i)] = v.x;
-        sm[LM_PAD(i + 1)] = v.y;
-    }
-    __syncthreads();
-    lds_inv_transform(sm, logN, tw, q, tid, nthreads);
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        ulonglong2 v;
-        v.x = lm_addmod(lm_shoup(sm[LM_PAD(i)], ninv, q), half, q);
-        v.y = lm_addmod(lm_shoup(sm[LM_PAD(i + 1)], ninv, q), half, q);
-        *reinterpret_cast<ulonglong2 *>(o + i) = v;
-    }
+    auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
+    auto st = [&](uint32_t i, u64 v) { o[i] = lm_addmod(lm_shoup(v, ninv, c.q), half, c.q); };
+    lm_ntt_inverse<LOGN>(sm, tw, c, tid, nthreads, ld, st);
 }
 
-__global__ __launch_bounds__(1024) void k_rescale_limb(const u64 *__restrict__ src, size_t src_poly_stride,
-                                                       u64 *__restrict__ dst, size_t dst_poly_stride,
-                                                       const u64 *__restrict__ tbuf, uint32_t npoly,
-                                                       uint32_t logN, lm_mods mods, rescale_consts rc,
+template <int LOGN>
+__global__ __launch_bounds__(1024) void k_rescale_limb(const u64 *src, size_t src_poly_stride, u64 *dst,
+                                                       size_t dst_poly_stride, const u64 *__restrict__ tbuf,
+                                                       uint32_t npoly, lm_mods mods, rescale_consts rc,
                                                        const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
-    const uint32_t N = 1u << logN, tid = threadIdx.x, nthreads = blockDim.x;
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const uint32_t limb = blockIdx.x / npoly, poly = blockIdx.x % npoly; // limb-major (L2-friendly twiddles)
-    const u64 q = mods.m[limb].q, qinv64 = mods.m[limb].qinv64;
+    const lm_qc c = lm_make_qc(mods.m[limb]);
     const u64 hm = rc.half_mod[limb];
     const tw_t qlinv = rc.qlinv[limb];
     const u64 *t = tbuf + (size_t)poly * N;
-    const u64 *c = src + (size_t)poly * src_poly_stride + (size_t)limb * N;
+    const u64 *cin = src + (size_t)poly * src_poly_stride + (size_t)limb * N;
     u64 *o = dst + (size_t)poly * dst_poly_stride + (size_t)limb * N;
-    const tw_t *tw = tw_all + (size_t)limb * N;
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(t + i);
-        sm[LM_PAD(i)] = lm_submod(lm_reduce(v.x, q, qinv64), hm, q);
-        sm[LM_PAD(i + 1)] = lm_submod(lm_reduce(v.y, q, qinv64), hm, q);
-    }
-    __syncthreads();
-    lds_fwd_transform(sm, logN, tw, q, tid, nthreads);
-    for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads) {
-        const ulonglong2 cv = *reinterpret_cast<const ulonglong2 *>(c + i);
-        ulonglong2 v;
-        v.x = lm_shoup(lm_submod(cv.x, lm_reduce(sm[LM_PAD(i)], q, qinv64), q), qlinv, q);
-        v.y = lm_shoup(lm_submod(cv.y, lm_reduce(sm[LM_PAD(i + 1)], q, qinv64), q), qlinv, q);
-        *reinterpret_cast<ulonglong2 *>(o + i) = v;
-    }
+    auto ld = [&](uint32_t i) { return lm_submod(lm_reduce(t[i], c.q, c.qinv64), hm, c.q); };
+    auto st = [&](uint32_t i0, const u64 *v, int count) {
+        u64 cv[8], r[8];
+        lm_load_run(cin, i0, cv, count);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < count) r[k] = lm_shoup(lm_submod(cv[k], lm_reduce(v[k], c.q, c.qinv64), c.q), qlinv, c.q);
+        lm_store_run(o, i0, r, count);
+    };
+    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)limb * N, c, tid, nthreads, ld, st);
 }
 
-// Rescale `npoly` polynomials from `nl` limbs down to `target` limbs.
-// src layout [npoly][nl][N]; dst layout [npoly][target][N]; work: scratch with
-// the src layout (may be NULL when nl - target == 1); tbuf: [npoly][N].
-int lm_rescale_polys(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
-                     uint32_t npoly, u64 *work, u64 *tbuf) {
+template <int LOGN>
+static int rescale_polys_t(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
+                           uint32_t npoly, u64 *work, u64 *tbuf) {
     const uint32_t N = ctx->N;
     const size_t lds = lm_ntt_lds_bytes(N);
     const uint32_t threads = lm_ntt_threads(N);
-    LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rescale_last),
+    LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rescale_last<LOGN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rescale_limb),
+    LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rescale_limb<LOGN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const u64 *cur = src;
     for (uint32_t cur_nl = nl; cur_nl > target; cur_nl--) {
@@ -107,21 +92,36 @@ int lm_rescale_polys(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint
         }
         {
             lm_prof_scope ps(ctx, "rescale_last_intt", npoly);
-            hipLaunchKernelGGL(k_rescale_last, dim3(npoly), dim3(threads), lds, ctx->stream, cur,
-                               (size_t)nl * N, last, tbuf, ctx->logN, ctx->mods.m[last], ctx->ninv[last],
-                               (u64)rc.half, ctx->d_tw_inv + (size_t)last * N);
+            hipLaunchKernelGGL(k_rescale_last<LOGN>, dim3(npoly), dim3(threads), lds, ctx->stream, cur,
+                               (size_t)nl * N, last, tbuf, ctx->mods.m[last], ctx->ninv[last], (u64)rc.half,
+                               ctx->d_tw_inv + (size_t)last * N);
             LM_HIP(ctx, hipGetLastError());
         }
         {
             lm_prof_scope ps(ctx, "rescale_limb_ntt", (uint64_t)npoly * last);
-            hipLaunchKernelGGL(k_rescale_limb, dim3(npoly * last), dim3(threads), lds, ctx->stream, cur,
-                               (size_t)nl * N, out, out_stride, tbuf, npoly, ctx->logN, ctx->mods, rc,
-                               ctx->d_tw_fwd);
+            hipLaunchKernelGGL(k_rescale_limb<LOGN>, dim3(npoly * last), dim3(threads), lds, ctx->stream, cur,
+                               (size_t)nl * N, out, out_stride, tbuf, npoly, ctx->mods, rc, ctx->d_tw_fwd);
             LM_HIP(ctx, hipGetLastError());
         }
         cur = work;
     }
     return 0;
+}
+
+// Rescale `npoly` polynomials from `nl` limbs down to `target` limbs.
+// src layout [npoly][nl][N]; dst layout [npoly][target][N]; work: scratch with
+// the src layout (may be NULL when nl - target == 1); tbuf: [npoly][N].
+int lm_rescale_polys(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
+                     uint32_t npoly, u64 *work, u64 *tbuf) {
+    switch (ctx->logN) {
+#define LM_CASE(n) \
+    case n:        \
+        return rescale_polys_t<n>(ctx, src, nl, dst, target, npoly, work, tbuf);
+        LM_FOR_EACH_LOGN(LM_CASE)
+#undef LM_CASE
+    default:
+        return lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
+    }
 }
 
 extern "C" int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t target_limbs, lumen_set **out) {

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -34,7 +35,8 @@ struct lm_prof_entry {
 
 struct lm_galois_key {
     u64 *d_key = nullptr;   // [beta][2][L+K][N], Montgomery form
-    uint32_t *d_index = nullptr; // automorphism gather table, N entries
+    uint32_t *d_index = nullptr; // automorphism gather table, N entries: out[i] = in[index[i]]
+    uint32_t *d_inv_index = nullptr; // its inverse: out[inv_index[p]] = in[p]
 };
 
 struct lumen_set {
@@ -66,6 +68,8 @@ struct lumen_ctx {
     std::map<uint64_t, lm_galois_key> gkeys;
     // scratch
     std::map<std::string, std::pair<void *, size_t>> scratch;
+    // kernels whose dynamic-LDS limit has already been raised on this device
+    std::set<const void *> lds_attr_done;
     // per-context derived tables owned by other translation units (key-switch constants,
     // ciphertext-transform plans); released with the context
     std::map<std::string, std::shared_ptr<void>> ext;
@@ -99,6 +103,16 @@ extern thread_local std::string lm_global_err;
 #define LM_CHECK(ctx, cond, ...)                    \
     do {                                            \
         if (!(cond)) return lm_fail(ctx, __VA_ARGS__); \
+    } while (0)
+
+// raise a kernel's dynamic-LDS limit once (hipFuncSetAttribute is not free on the launch path)
+#define LM_LDS_ATTR(ctx, kernel, bytes)                                                                   \
+    do {                                                                                                  \
+        const void *fp_ = reinterpret_cast<const void *>(&kernel);                                        \
+        if (!(ctx)->lds_attr_done.count(fp_)) {                                                           \
+            LM_HIP(ctx, hipFuncSetAttribute(fp_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            (ctx)->lds_attr_done.insert(fp_);                                                             \
+        }                                                                                                 \
     } while (0)
 
 // scratch buffer that persists in the context and only grows

@@ -180,6 +180,7 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
     for (auto &kv : ctx->gkeys) {
         hipFree(kv.second.d_key);
         hipFree(kv.second.d_index);
+        hipFree(kv.second.d_inv_index);
     }
     for (auto &kv : ctx->scratch) hipFree(kv.second.first);
     ctx->ext.clear();

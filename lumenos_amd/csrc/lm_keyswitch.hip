@@ -167,14 +167,20 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
     }
 }
 
-// ---- step 4: ModDown.  One workgroup per (column b, poly w, Q limb t):
-// lift of the (coefficient-domain) P limbs into q_t fused into the load, NTT in
-// LDS, then d = (u_t - lift) * P^-1 (+ c0 for w == 0) fused into the store.
+// ---- steps 4+5: ModDown, add c0, automorphism, accumulate.  One workgroup per (column b,
+// poly w, Q limb t): the lift of the (coefficient-domain) P limbs into q_t is fused into the load,
+// the NTT runs in LDS, d = (u_t - lift) * P^-1 (+ c0 for w == 0) is formed in the last pass and
+// parked in LDS; after a barrier (every c0 has been read) the limb is added into acc through the
+// inverse automorphism table: acc[inv[p]] += d[p].  In the bit-reversed NTT domain the
+// automorphism maps aligned blocks of 2^k consecutive indices onto aligned blocks, so this
+// scatter touches exactly the cache lines a linear pass would.
 template <int LOGN>
-__global__ __launch_bounds__(1024) void k_moddown_ntt(const u64 *__restrict__ u, const u64 *__restrict__ acc,
-                                                      u64 *__restrict__ dout, const bx_t *__restrict__ bxp,
-                                                      const tw_t *__restrict__ pinv, uint32_t B, uint32_t L,
-                                                      uint32_t K, lm_mods mods, const tw_t *__restrict__ tw_all) {
+__global__ __launch_bounds__(1024) void k_moddown_ntt(const u64 *__restrict__ u, u64 *acc,
+                                                      const bx_t *__restrict__ bxp,
+                                                      const tw_t *__restrict__ pinv,
+                                                      const uint32_t *__restrict__ inv_index, uint32_t B,
+                                                      uint32_t L, uint32_t K, lm_mods mods,
+                                                      const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
     constexpr uint32_t N = 1u << LOGN;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
@@ -187,37 +193,34 @@ __global__ __launch_bounds__(1024) void k_moddown_ntt(const u64 *__restrict__ u,
     const u64 *up0 = u + ((size_t)pw * LK + L) * N; // P limbs of u, coefficient domain
     const u64 *up1 = c.ns == 2 ? up0 + N : up0;
     const u64 *uq = u + ((size_t)pw * LK + t) * N;
-    const u64 *c0 = acc + ((size_t)pw * L + t) * N; // only read when w == 0
-    u64 *o = dout + ((size_t)pw * L + t) * N;
+    u64 *a = acc + ((size_t)pw * L + t) * N; // c0 (w == 0) / c1 (w == 1) limb of the accumulator
     const tw_t pi = pinv[t];
     auto ld = [&](uint32_t i) { return bx_apply(c, up0[i], up1[i], qc); };
     auto st = [&](uint32_t i0, const u64 *v, int count) {
-        u64 uv[8], cv[8], rr[8];
+        u64 uv[8], cv[8];
         lm_load_run(uq, i0, uv, count);
-        if (w == 0) lm_load_run(c0, i0, cv, count);
+        if (w == 0) lm_load_run(a, i0, cv, count);
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (k < count) {
-                u64 x = lm_shoup(lm_submod(uv[k], lm_reduce(v[k], qc.q, qc.qinv64), qc.q), pi, qc.q);
+                u64 x = lm_shoup_cs(lm_submod(uv[k], lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64), qc.q), pi, qc.q, qc.nq);
                 if (w == 0) x = lm_addmod(x, cv[k], qc.q);
-                rr[k] = x;
+                sm[LM_PAD(i0 + k)] = x; // the slots this work item just consumed
             }
-        lm_store_run(o, i0, rr, count);
     };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);
-}
-
-// ---- step 5: acc[k][i] += d[k][index[i]]  (NTT-domain automorphism gather)
-__global__ void k_automorph_add(u64 *__restrict__ acc, const u64 *__restrict__ d,
-                                const uint32_t *__restrict__ index, size_t nlimbs, uint32_t logN,
-                                uint32_t nl, lm_mods mods) {
-    const uint32_t N = 1u << logN;
-    const size_t total = nlimbs << logN, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const size_t limb_idx = g >> logN;
-        const uint32_t i = (uint32_t)(g & (N - 1));
-        const u64 q = mods.m[limb_idx % nl].q;
-        acc[g] = lm_addmod(acc[g], d[(limb_idx << logN) + index[i]], q);
+    __syncthreads();
+    // 8 independent gather/scatter chains in flight per thread
+    for (uint32_t p0 = tid; p0 < N; p0 += 8 * nthreads) {
+        uint32_t j[8];
+        u64 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) j[k] = p0 + k * nthreads < N ? inv_index[p0 + k * nthreads] : 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = a[j[k]];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (p0 + k * nthreads < N) a[j[k]] = lm_addmod(x[k], sm[LM_PAD(p0 + k * nthreads)], qc.q);
     }
 }
 
@@ -313,7 +316,7 @@ int get_tables(lumen_ctx *ctx, KsTables **out) {
 }
 
 struct KsScratch {
-    u64 *coef, *ext, *u, *dout;
+    u64 *coef, *ext, *u;
 };
 
 int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s) {
@@ -321,8 +324,7 @@ int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s) {
     s->coef = (u64 *)lm_scratch(ctx, "ks_coef", (size_t)B * L * N * 8);
     s->ext = (u64 *)lm_scratch(ctx, "ks_ext", (size_t)B * beta * LK * N * 8);
     s->u = (u64 *)lm_scratch(ctx, "ks_u", (size_t)B * 2 * LK * N * 8);
-    s->dout = (u64 *)lm_scratch(ctx, "ks_d", (size_t)B * 2 * L * N * 8);
-    return (s->coef && s->ext && s->u && s->dout) ? 0 : 1;
+    return (s->coef && s->ext && s->u) ? 0 : 1;
 }
 
 // acc: [B][2][L][N] at top level; performs acc += Rot_galEl(acc) for every column
@@ -348,8 +350,7 @@ int rotate_accumulate(lumen_ctx *ctx, u64 *acc, uint32_t B, const lm_galois_key 
         switch (ctx->logN) {
 #define LM_CASE(n)                                                                                            \
     case n:                                                                                                   \
-        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_modup_ntt<n>),                      \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        LM_LDS_ATTR(ctx, k_modup_ntt<n>, lds);               \
         hipLaunchKernelGGL(k_modup_ntt<n>, dim3((uint32_t)nb), dim3(threads), lds, ctx->stream, s.coef, acc,  \
                            s.ext, tb->d_bx, B, L, K, beta, ctx->mods, ctx->d_tw_fwd);                         \
         break;
@@ -383,29 +384,21 @@ int rotate_accumulate(lumen_ctx *ctx, u64 *acc, uint32_t B, const lm_galois_key 
             LM_HIP(ctx, hipGetLastError());
         }
     }
-    // 4b. lift to Q, NTT, combine
+    // 4b + 5. lift to Q, NTT, combine, automorphism, accumulate
     {
         lm_prof_scope ps(ctx, "ks_moddown_ntt", (uint64_t)B * 2 * L);
         switch (ctx->logN) {
 #define LM_CASE(n)                                                                                            \
     case n:                                                                                                   \
-        LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_moddown_ntt<n>),                    \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        LM_LDS_ATTR(ctx, k_moddown_ntt<n>, lds);               \
         hipLaunchKernelGGL(k_moddown_ntt<n>, dim3(B * 2 * L), dim3(threads), lds, ctx->stream, s.u, acc,      \
-                           s.dout, tb->d_bxp, tb->d_pinv, B, L, K, ctx->mods, ctx->d_tw_fwd);                 \
+                           tb->d_bxp, tb->d_pinv, gk.d_inv_index, B, L, K, ctx->mods, ctx->d_tw_fwd);         \
         break;
             LM_FOR_EACH_LOGN(LM_CASE)
 #undef LM_CASE
         default:
             return lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
         }
-        LM_HIP(ctx, hipGetLastError());
-    }
-    // 5. automorphism + accumulate
-    {
-        lm_prof_scope ps(ctx, "ks_automorph_add", (uint64_t)B);
-        hipLaunchKernelGGL(k_automorph_add, dim3(4096), dim3(256), 0, ctx->stream, acc, s.dout, gk.d_index,
-                           (size_t)B * 2 * L, ctx->logN, L, ctx->mods);
         LM_HIP(ctx, hipGetLastError());
     }
     return 0;
@@ -505,6 +498,10 @@ extern "C" int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint
     lm_galois_key &gk = ctx->gkeys[gal_el];
     if (!gk.d_key) LM_HIP(ctx, hipMalloc((void **)&gk.d_key, words * 8));
     if (!gk.d_index) LM_HIP(ctx, hipMalloc((void **)&gk.d_index, (size_t)N * 4));
+    if (!gk.d_inv_index) LM_HIP(ctx, hipMalloc((void **)&gk.d_inv_index, (size_t)N * 4));
+    std::vector<uint32_t> inv_index(N);
+    for (uint32_t i = 0; i < N; i++) inv_index[index[i]] = i;
+    LM_HIP(ctx, hipMemcpy(gk.d_inv_index, inv_index.data(), (size_t)N * 4, hipMemcpyHostToDevice));
     LM_HIP(ctx, hipMemcpy(gk.d_key, mont.data(), words * 8, hipMemcpyHostToDevice));
     LM_HIP(ctx, hipMemcpy(gk.d_index, index.data(), (size_t)N * 4, hipMemcpyHostToDevice));
     return 0;

@@ -67,13 +67,11 @@ int lm_launch_ntt_strided(lumen_ctx *ctx, const u64 *src, size_t src_poly_stride
 #define LM_LAUNCH(n)                                                                                          \
     case n:                                                                                                   \
         if (inverse) {                                                                                        \
-            LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_limb_ntt<n, true>),             \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+            LM_LDS_ATTR(ctx, (k_limb_ntt<n, true>), lds);           \
             hipLaunchKernelGGL((k_limb_ntt<n, true>), grid, block, lds, ctx->stream, src, src_poly_stride,    \
                                dst, dst_poly_stride, npoly, map, ctx->mods, ninv, ctx->d_tw_inv);             \
         } else {                                                                                              \
-            LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_limb_ntt<n, false>),            \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+            LM_LDS_ATTR(ctx, (k_limb_ntt<n, false>), lds);           \
             hipLaunchKernelGGL((k_limb_ntt<n, false>), grid, block, lds, ctx->stream, src, src_poly_stride,   \
                                dst, dst_poly_stride, npoly, map, ctx->mods, ninv, ctx->d_tw_fwd);             \
         }                                                                                                     \

@@ -62,61 +62,35 @@ static inline lm_ninv_t lm_ninv_of(const lumen_ctx *ctx) {
     return n;
 }
 
-// ---- 32x32+64 multiply-add, forced onto v_mad_u64_u32.  One operand may live in an SGPR
-// (constant-bus limit of one scalar per VALU instruction on gfx9-family ISAs): wave-uniform
-// twiddles and the modulus words never occupy VGPRs or cost a v_mov.
-__device__ __forceinline__ u64 lm_mad(u32 a, u32 b, u64 c) {
-    u64 d;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
-    return d;
-}
-__device__ __forceinline__ u64 lm_mad0(u32 a, u32 b) {
-    u64 d;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
-    return d;
-}
-__device__ __forceinline__ u64 lm_mad_s(u32 a, u32 b_uniform, u64 c) {
-    u64 d;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c) : "vcc");
-    return d;
-}
-__device__ __forceinline__ u64 lm_mad0_s(u32 a, u32 b_uniform) {
-    u64 d;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b_uniform) : "vcc");
-    return d;
+// ---- Shoup multiplication as a chain of 32x32+64 multiply-adds (v_mad_u64_u32: 4.9 cycles per
+// wave-op on MI355X against 8-10 for v_mul_lo/hi_u32, profiles/r01_ubench_int_valu.txt).
+// Written in plain C so the scheduler can interleave independent butterflies and place
+// wave-uniform operands (twiddles of uniform stages, the modulus) in SGPRs; lm_keep() is an empty
+// asm that marks all 64 bits of a partial sum as used, which stops the compiler from narrowing the
+// low-word products back to the slower v_mul_lo_u32.
+__device__ __forceinline__ u64 lm_keep(u64 x) {
+    asm("" : "+v"(x));
+    return x;
 }
 
 // a*w mod q, lazily, for ANY a < 2^64: result in [0, 3q).  nq = 2^64 - q (wave-uniform).
 // t ~ floor(a*wp / 2^64) from three partial products (the a0*wp0 term and its
 // carry are dropped: t is exact or one short), then r = a*w + t*nq mod 2^64.
-// UW: the twiddle (w, wp) is wave-uniform (lives in SGPRs).
+// UW documents that the twiddle (w, wp) is wave-uniform (it then lives in SGPRs).
 template <bool UW>
 __device__ __forceinline__ u64 lm_shoup3(u64 a, u64 w, u64 wp, u64 nq) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
     const u32 w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
-    u64 m1, m2, t, lo, acc;
-    if (UW) {
-        m1 = lm_mad0_s(a0, p1);
-        m2 = lm_mad_s(a1, p0, (u64)(u32)m1);
-        t = lm_mad_s(a1, p1, m1 >> 32) + (m2 >> 32);
-        lo = lm_mad0_s(a0, w0);
-    } else {
-        m1 = lm_mad0(a0, p1);
-        m2 = lm_mad(a1, p0, (u64)(u32)m1);
-        t = lm_mad(a1, p1, m1 >> 32) + (m2 >> 32);
-        lo = lm_mad0(a0, w0);
-    }
+    const u64 m1 = (u64)a0 * p1;
+    const u64 m2 = lm_keep((u64)a1 * p0 + (u32)m1);
+    const u64 t = (u64)a1 * p1 + (m1 >> 32) + (m2 >> 32);
     const u32 t0 = (u32)t, t1 = (u32)(t >> 32);
-    lo = lm_mad_s(t0, n0, lo);
-    if (UW) {
-        acc = lm_mad_s(a0, w1, lo >> 32);
-        acc = lm_mad_s(a1, w0, acc);
-    } else {
-        acc = lm_mad(a0, w1, lo >> 32);
-        acc = lm_mad(a1, w0, acc);
-    }
-    acc = lm_mad_s(t0, n1, acc);
-    acc = lm_mad_s(t1, n0, acc);
+    const u64 lo = (u64)a0 * w0 + (u64)t0 * n0;
+    u64 acc = (u64)a0 * w1 + (lo >> 32);
+    acc += (u64)a1 * w0;
+    acc += (u64)t0 * n1;
+    acc += (u64)t1 * n0;
+    acc = lm_keep(acc);
     return (acc << 32) | (u32)lo;
 }
 // canonical a*w mod q for a constant multiplier held in SGPRs

@@ -72,10 +72,8 @@ static int rescale_polys_t(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst
     const uint32_t N = ctx->N;
     const size_t lds = lm_ntt_lds_bytes(N);
     const uint32_t threads = lm_ntt_threads(N);
-    LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rescale_last<LOGN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    LM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rescale_limb<LOGN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LM_LDS_ATTR(ctx, k_rescale_last<LOGN>, lds);
+    LM_LDS_ATTR(ctx, k_rescale_limb<LOGN>, lds);
     const u64 *cur = src;
     for (uint32_t cur_nl = nl; cur_nl > target; cur_nl--) {
         const uint32_t last = cur_nl - 1;

@@ -95,7 +95,7 @@ __global__ void k_mul_plain(const u64 *__restrict__ ct, u64 *__restrict__ out, c
 // ---- step 2: digit extension + NTT.  One workgroup per (column b, digit d, target t).
 // coef: [B][L][N] coefficient-domain c1; acc: [B][2][L][N] (c1 NTT values for own limbs); ext: [B][beta][L+K][N]
 template <int LOGN>
-__global__ __launch_bounds__(1024) void k_modup_ntt(const u64 *__restrict__ coef, const u64 *__restrict__ acc,
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *__restrict__ coef, const u64 *__restrict__ acc,
                                                     u64 *__restrict__ ext, const bx_t *__restrict__ bx,
                                                     uint32_t B, uint32_t L, uint32_t K, uint32_t beta,
                                                     lm_mods mods, const tw_t *__restrict__ tw_all) {
@@ -175,12 +175,12 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
 // automorphism maps aligned blocks of 2^k consecutive indices onto aligned blocks, so this
 // scatter touches exactly the cache lines a linear pass would.
 template <int LOGN>
-__global__ __launch_bounds__(1024) void k_moddown_ntt(const u64 *__restrict__ u, u64 *acc,
-                                                      const bx_t *__restrict__ bxp,
-                                                      const tw_t *__restrict__ pinv,
-                                                      const uint32_t *__restrict__ inv_index, uint32_t B,
-                                                      uint32_t L, uint32_t K, lm_mods mods,
-                                                      const tw_t *__restrict__ tw_all) {
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 *__restrict__ u, const u64 *__restrict__ acc_in,
+                                                     u64 *__restrict__ acc_out, const bx_t *__restrict__ bxp,
+                                                     const tw_t *__restrict__ pinv,
+                                                     const uint32_t *__restrict__ inv_index, uint32_t B,
+                                                     uint32_t L, uint32_t K, lm_mods mods,
+                                                     const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
     constexpr uint32_t N = 1u << LOGN;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
@@ -193,35 +193,40 @@ __global__ __launch_bounds__(1024) void k_moddown_ntt(const u64 *__restrict__ u,
     const u64 *up0 = u + ((size_t)pw * LK + L) * N; // P limbs of u, coefficient domain
     const u64 *up1 = c.ns == 2 ? up0 + N : up0;
     const u64 *uq = u + ((size_t)pw * LK + t) * N;
-    u64 *a = acc + ((size_t)pw * L + t) * N; // c0 (w == 0) / c1 (w == 1) limb of the accumulator
+    const u64 *ain = acc_in + ((size_t)pw * L + t) * N; // c0 (w == 0) / c1 (w == 1) limb of the accumulator
+    u64 *aout = acc_out + ((size_t)pw * L + t) * N;
     const tw_t pi = pinv[t];
+    uint32_t part0 = 0; // first coefficient of the part of the transform currently parked in LDS
     auto ld = [&](uint32_t i) { return bx_apply(c, up0[i], up1[i], qc); };
     auto st = [&](uint32_t i0, const u64 *v, int count) {
         u64 uv[8], cv[8];
         lm_load_run(uq, i0, uv, count);
-        if (w == 0) lm_load_run(a, i0, cv, count);
+        if (w == 0) lm_load_run(ain, i0, cv, count);
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (k < count) {
                 u64 x = lm_shoup_cs(lm_submod(uv[k], lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64), qc.q), pi, qc.q, qc.nq);
                 if (w == 0) x = lm_addmod(x, cv[k], qc.q);
-                sm[LM_PAD(i0 + k)] = x; // the slots this work item just consumed
+                sm[LM_PAD(i0 - part0 + k)] = x; // the slots this work item just consumed
             }
     };
-    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);
-    __syncthreads();
-    // 8 independent gather/scatter chains in flight per thread
-    for (uint32_t p0 = tid; p0 < N; p0 += 8 * nthreads) {
-        uint32_t j[8];
-        u64 x[8];
+    // acc_out[inv[p]] = acc_in[inv[p]] + d[p] for the coefficients [i0, i0 + n) now parked in LDS
+    auto after = [&](uint32_t i0, uint32_t n) {
+        __syncthreads();
+        for (uint32_t p0 = tid; p0 < n; p0 += 8 * nthreads) {
+            uint32_t j[8];
+            u64 x[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) j[k] = p0 + k * nthreads < N ? inv_index[p0 + k * nthreads] : 0;
+            for (int k = 0; k < 8; k++) j[k] = p0 + k * nthreads < n ? inv_index[i0 + p0 + k * nthreads] : 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = a[j[k]];
+            for (int k = 0; k < 8; k++) x[k] = ain[j[k]];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (p0 + k * nthreads < N) a[j[k]] = lm_addmod(x[k], sm[LM_PAD(p0 + k * nthreads)], qc.q);
-    }
+            for (int k = 0; k < 8; k++)
+                if (p0 + k * nthreads < n) aout[j[k]] = lm_addmod(x[k], sm[LM_PAD(p0 + k * nthreads)], qc.q);
+        }
+        part0 = i0 + n; // the next part (if any) starts here
+    };
+    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st, after);
 }
 
 // -------------------------------------------------------------------- host side
@@ -316,7 +321,7 @@ int get_tables(lumen_ctx *ctx, KsTables **out) {
 }
 
 struct KsScratch {
-    u64 *coef, *ext, *u;
+    u64 *coef, *ext, *u, *acc2;
 };
 
 int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s) {
@@ -324,15 +329,16 @@ int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s) {
     s->coef = (u64 *)lm_scratch(ctx, "ks_coef", (size_t)B * L * N * 8);
     s->ext = (u64 *)lm_scratch(ctx, "ks_ext", (size_t)B * beta * LK * N * 8);
     s->u = (u64 *)lm_scratch(ctx, "ks_u", (size_t)B * 2 * LK * N * 8);
-    return (s->coef && s->ext && s->u) ? 0 : 1;
+    s->acc2 = (u64 *)lm_scratch(ctx, "ks_acc2", (size_t)B * 2 * L * N * 8);
+    return (s->coef && s->ext && s->u && s->acc2) ? 0 : 1;
 }
 
-// acc: [B][2][L][N] at top level; performs acc += Rot_galEl(acc) for every column
-int rotate_accumulate(lumen_ctx *ctx, u64 *acc, uint32_t B, const lm_galois_key &gk, KsTables *tb,
-                      const KsScratch &s) {
+// acc, acc_out: [B][2][L][N] at top level; acc_out = acc + Rot_galEl(acc) for every column
+int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, const lm_galois_key &gk,
+                      KsTables *tb, const KsScratch &s) {
     const uint32_t N = ctx->N, L = ctx->L, K = ctx->K, LK = L + K, beta = tb->beta;
-    const size_t lds = lm_ntt_lds_bytes(N);
-    const uint32_t threads = lm_ntt_threads(N);
+    const size_t lds = lm_fwd_lds(ctx->logN);
+    const uint32_t threads = lm_fwd_threads(ctx->logN);
     // 1. c1 -> coefficient domain
     if (int rc = lm_launch_ntt_strided(ctx, acc + (size_t)L * N, (size_t)2 * L * N, s.coef, (size_t)L * N, B,
                                        lm_map_q(L), true, "ks_intt_c1", &tb->yscale))
@@ -392,7 +398,8 @@ int rotate_accumulate(lumen_ctx *ctx, u64 *acc, uint32_t B, const lm_galois_key 
     case n:                                                                                                   \
         LM_LDS_ATTR(ctx, k_moddown_ntt<n>, lds);               \
         hipLaunchKernelGGL(k_moddown_ntt<n>, dim3(B * 2 * L), dim3(threads), lds, ctx->stream, s.u, acc,      \
-                           tb->d_bxp, tb->d_pinv, gk.d_inv_index, B, L, K, ctx->mods, ctx->d_tw_fwd);         \
+                           acc_out, tb->d_bxp, tb->d_pinv, gk.d_inv_index, B, L, K, ctx->mods,                \
+                           ctx->d_tw_fwd);                                                                    \
         break;
             LM_FOR_EACH_LOGN(LM_CASE)
 #undef LM_CASE
@@ -411,8 +418,13 @@ int inner_sum_batch(lumen_ctx *ctx, u64 *acc, uint32_t B, uint32_t n, KsTables *
         auto it = ctx->gkeys.find(gal[r]);
         LM_CHECK(ctx, it != ctx->gkeys.end(), "Galois key for element %llu not loaded",
                  (unsigned long long)gal[r]);
-        if (int rc = rotate_accumulate(ctx, acc, B, it->second, tb, s)) return rc;
+        // ping-pong: the automorphism reads two positions of the old accumulator per output
+        u64 *src = (r & 1) ? s.acc2 : acc, *dst = (r & 1) ? acc : s.acc2;
+        if (int rc = rotate_accumulate(ctx, src, dst, B, it->second, tb, s)) return rc;
     }
+    if (cnt & 1)
+        LM_HIP(ctx, hipMemcpyAsync(acc, s.acc2, (size_t)B * 2 * ctx->L * ctx->N * 8, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
     return 0;
 }
 

@@ -16,7 +16,7 @@
 #include "lm_ntt_dev.h"
 
 template <int LOGN, bool INV>
-__global__ __launch_bounds__(1024) void k_limb_ntt(const u64 *src, size_t src_poly_stride, u64 *dst,
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_limb_ntt(const u64 *src, size_t src_poly_stride, u64 *dst,
                                                    size_t dst_poly_stride, uint32_t npoly, lm_modmap map,
                                                    lm_mods mods, lm_ninv_t ninv,
                                                    const tw_t *__restrict__ tw_all) {
@@ -58,8 +58,9 @@ int lm_launch_ntt_strided(lumen_ctx *ctx, const u64 *src, size_t src_poly_stride
     if (!npoly || !map.period) return 0;
     const uint32_t N = ctx->N;
     const lm_ninv_t ninv = inv_scale ? *inv_scale : lm_ninv_of(ctx);
-    const size_t lds = lm_ntt_lds_bytes(N);
-    const uint32_t threads = lm_ntt_threads(N);
+    const size_t lds = inverse ? lm_inv_lds(ctx->logN) : lm_fwd_lds(ctx->logN);
+    const uint32_t threads = inverse ? lm_inv_threads(ctx->logN) : lm_fwd_threads(ctx->logN);
+    (void)N;
     const uint64_t nblocks64 = (uint64_t)npoly * map.period;
     LM_CHECK(ctx, nblocks64 < (1ull << 31), "NTT grid too large: %llu", (unsigned long long)nblocks64);
     lm_prof_scope ps(ctx, prof_name ? prof_name : (inverse ? "limb_intt" : "limb_ntt"), nblocks64);

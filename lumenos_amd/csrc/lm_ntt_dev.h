@@ -41,7 +41,7 @@ __host__ __device__ constexpr int lm_pass_r(int logN, int i) {
     return r;
 }
 // ring degrees the kernels are instantiated for
-#define LM_FOR_EACH_LOGN(X) X(8) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#define LM_FOR_EACH_LOGN(X) X(8) X(10) X(11) X(12) X(13) X(14)
 static inline bool lm_logn_supported(uint32_t logN) {
 #define LM_CASE(n) if (logN == n) return true;
     LM_FOR_EACH_LOGN(LM_CASE)
@@ -49,13 +49,34 @@ static inline bool lm_logn_supported(uint32_t logN) {
     return false;
 }
 
-static inline uint32_t lm_ntt_threads(uint32_t N) {
-    uint32_t t = N / 8;
-    if (t > 1024) t = 1024;
-    if (t < 64) t = 64;
-    return t;
+// Launch geometry.  A transform whose N coefficients fit in half a CU's LDS keeps them all there;
+// the forward transform of N = 2^14 (132 KiB padded) instead runs its first stage out of registers
+// and then its two independent halves one after the other in a half-size buffer, so that two
+// workgroups (different limbs) share a CU and cover each other's barriers and memory phases.
+// Measured on MI355X at N = 2^14 (profiles/r01_split_experiment.txt): two 512-thread workgroups per
+// CU running sequential halves reach 7.1 M limb-NTT/s against 8.2 M/s for one 1024-thread workgroup
+// with the whole limb in LDS -- the kernel is VALU-bound (~80 % VALU-busy), so the extra barriers and
+// the parked half cost more than the overlap returns.  The split path is kept but disabled.
+#define LM_SPLIT_LOGN 99 // forward transforms of this size and above run as sequential halves
+#define LM_SPLIT_NT 512
+__host__ __device__ constexpr bool lm_fwd_is_split(int logN) { return logN >= LM_SPLIT_LOGN; }
+// N <= 2^13: 512-thread workgroups so that two (or more) fit a CU by LDS and VGPRs;
+// N = 2^14: the limb fills the LDS of a CU, one 1024-thread workgroup uses all 16 waves.
+#define LM_BIG_LOGN 14
+__host__ __device__ constexpr int lm_max_threads(int logN) { return logN >= LM_BIG_LOGN ? 1024 : 512; }
+static inline uint32_t lm_fwd_threads(uint32_t logN) {
+    const uint32_t t = (1u << logN) / 8, cap = lm_fwd_is_split((int)logN) ? LM_SPLIT_NT : lm_max_threads((int)logN);
+    return t > cap ? cap : (t < 64 ? 64 : t);
 }
-static inline size_t lm_ntt_lds_bytes(uint32_t N) { return (size_t)(N + (N >> 5) + 2) * sizeof(u64); }
+static inline uint32_t lm_inv_threads(uint32_t logN) {
+    const uint32_t t = (1u << logN) / 8, cap = lm_max_threads((int)logN);
+    return t > cap ? cap : (t < 64 ? 64 : t);
+}
+static inline size_t lm_lds_for(uint32_t n) { return (size_t)(n + (n >> 5) + 2) * sizeof(u64); }
+static inline size_t lm_fwd_lds(uint32_t logN) {
+    return lm_lds_for(lm_fwd_is_split((int)logN) ? (1u << (logN - 1)) : (1u << logN));
+}
+static inline size_t lm_inv_lds(uint32_t logN) { return lm_lds_for(1u << logN); }
 static inline lm_ninv_t lm_ninv_of(const lumen_ctx *ctx) {
     lm_ninv_t n;
     for (uint32_t i = 0; i < LM_MAX_LIMBS; i++) n.t[i] = ctx->ninv[i];
@@ -140,15 +161,17 @@ __device__ __forceinline__ tw_t lm_tw_load(const tw_t *__restrict__ tw, uint32_t
 }
 
 // R forward stages on e[0 .. 2^R), first stage index s0, block index blk
+// hoff: 0 for a whole transform; 1 + h when the stages belong to half h of a transform whose
+// first stage was done separately (global twiddle index = local index + (hoff << local stage))
 template <int R, bool UW>
 __device__ __forceinline__ void lm_fwd_stages(u64 *e, uint32_t s0, uint32_t blk, const tw_t *__restrict__ tw,
-                                              const lm_qc &c) {
+                                              const lm_qc &c, uint32_t hoff = 0) {
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int span = (1 << R) >> st, half = span >> 1;
 #pragma unroll
         for (int g = 0; g < (1 << st); g++) {
-            const tw_t W = lm_tw_load<UW>(tw, ((1u << s0) << st) + (blk << st) + g);
+            const tw_t W = lm_tw_load<UW>(tw, (((1u + hoff) << s0) << st) + (blk << st) + g);
 #pragma unroll
             for (int k = 0; k < half; k++) lm_bfly_fwd<UW>(e[g * span + k], e[g * span + k + half], W, c);
         }
@@ -192,7 +215,7 @@ __device__ __forceinline__ void lm_fwd_first(u64 *s, uint32_t logN, const tw_t *
 
 template <int R, bool UW>
 __device__ __forceinline__ void lm_fwd_mid(u64 *s, uint32_t logN, uint32_t s0, const tw_t *tw, const lm_qc &c,
-                                           uint32_t tid, uint32_t nthreads) {
+                                           uint32_t tid, uint32_t nthreads, uint32_t hoff = 0) {
     const uint32_t log_tl = logN - s0 - R, items = 1u << (logN - R);
     for (uint32_t w = tid; w < items; w += nthreads) {
         const uint32_t blk = w >> log_tl, off = w & ((1u << log_tl) - 1);
@@ -200,7 +223,7 @@ __device__ __forceinline__ void lm_fwd_mid(u64 *s, uint32_t logN, uint32_t s0, c
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_tl))];
-        lm_fwd_stages<R, UW>(e, s0, blk, tw, c);
+        lm_fwd_stages<R, UW>(e, s0, blk, tw, c, hoff);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_tl))] = e[k];
     }
@@ -208,15 +231,16 @@ __device__ __forceinline__ void lm_fwd_mid(u64 *s, uint32_t logN, uint32_t s0, c
 
 template <int R, class Storer>
 __device__ __forceinline__ void lm_fwd_last(const u64 *s, uint32_t logN, const tw_t *tw, const lm_qc &c,
-                                            uint32_t tid, uint32_t nthreads, Storer &st) {
+                                            uint32_t tid, uint32_t nthreads, Storer &st, uint32_t hoff = 0,
+                                            uint32_t ioff = 0) {
     const uint32_t s0 = logN - R, items = 1u << (logN - R);
     for (uint32_t w = tid; w < items; w += nthreads) {
         const uint32_t base = w << R;
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + k)];
-        lm_fwd_stages<R, false>(e, s0, w, tw, c);
-        st(base, e, 1 << R);
+        lm_fwd_stages<R, false>(e, s0, w, tw, c, hoff);
+        st(ioff + base, e, 1 << R);
     }
 }
 
@@ -235,10 +259,60 @@ __device__ __forceinline__ void lm_fwd_rec(u64 *sm, const tw_t *tw, const lm_qc 
         lm_fwd_rec<LOGN, P + 1, S0 + R>(sm, tw, c, tid, nthreads, ld, st);
     }
 }
-template <int LOGN, class Loader, class Storer>
+struct lm_no_after {
+    __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {}
+};
+
+// passes of one half (size 2^H, all coefficients already in LDS) of a split transform
+template <int H, int P, int S0, class Storer>
+__device__ __forceinline__ void lm_half_rec(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
+                                            uint32_t nthreads, Storer &st, uint32_t hoff, uint32_t ioff) {
+    constexpr int NP = lm_npasses(H), R = lm_pass_r(H, P);
+    if constexpr (P == NP - 1)
+        lm_fwd_last<R>(sm, H, tw, c, tid, nthreads, st, hoff, ioff);
+    else
+        lm_fwd_mid<R, (H - S0 - R >= 6)>(sm, H, S0, tw, c, tid, nthreads, hoff);
+    if constexpr (P + 1 < NP) {
+        __syncthreads();
+        lm_half_rec<H, P + 1, S0 + R>(sm, tw, c, tid, nthreads, st, hoff, ioff);
+    }
+}
+
+// Forward transform.  `after(i0, n)` runs once the storer has seen coefficients [i0, i0+n)
+// (whole transform, or one half of a split one) and before LDS is reused.
+template <int LOGN, class Loader, class Storer, class After = lm_no_after>
 __device__ __forceinline__ void lm_ntt_forward(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
-                                               uint32_t nthreads, Loader &ld, Storer &st) {
-    lm_fwd_rec<LOGN, 0, 0>(sm, tw, c, tid, nthreads, ld, st);
+                                               uint32_t nthreads, Loader &ld, Storer &st,
+                                               After after = After()) {
+    if constexpr (!lm_fwd_is_split(LOGN)) {
+        lm_fwd_rec<LOGN, 0, 0>(sm, tw, c, tid, nthreads, ld, st);
+        after(0u, 1u << LOGN);
+    } else {
+        // stage 0 from registers: x + W*y feeds half 0 (to LDS now), x - W*y is parked in VGPRs
+        constexpr uint32_t NH = 1u << (LOGN - 1), NT = LM_SPLIT_NT, PER = NH / NT;
+        const tw_t W1 = lm_tw_load<true>(tw, 1);
+        u64 park[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t j = tid + k * NT;
+            u64 x = ld(j), y = ld(j + NH);
+            lm_bfly_fwd<true>(x, y, W1, c);
+            sm[LM_PAD(j)] = x;
+            park[k] = y;
+            // keep at most four coefficient pairs in flight: without this fence the scheduler hoists
+            // all 2*PER loads and the parked half no longer fits beside them in 128 VGPRs
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        lm_half_rec<LOGN - 1, 0, 0>(sm, tw, c, tid, nthreads, st, 1u, 0u);
+        after(0u, NH);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) sm[LM_PAD(tid + k * NT)] = park[k];
+        __syncthreads();
+        lm_half_rec<LOGN - 1, 0, 0>(sm, tw, c, tid, nthreads, st, 2u, NH);
+        after(NH, NH);
+    }
 }
 
 // ------------------------------------------------------------------ inverse

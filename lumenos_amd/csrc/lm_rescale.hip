@@ -25,7 +25,7 @@ struct rescale_consts {
 };
 
 template <int LOGN>
-__global__ __launch_bounds__(1024) void k_rescale_last(const u64 *__restrict__ src, size_t src_poly_stride,
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rescale_last(const u64 *__restrict__ src, size_t src_poly_stride,
                                                        uint32_t last, u64 *__restrict__ tbuf, mod_t md,
                                                        tw_t ninv, u64 half, const tw_t *__restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(1024) void k_rescale_last(const u64 *__restrict__ s
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(1024) void k_rescale_limb(const u64 *src, size_t src_poly_stride, u64 *dst,
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rescale_limb(const u64 *src, size_t src_poly_stride, u64 *dst,
                                                        size_t dst_poly_stride, const u64 *__restrict__ tbuf,
                                                        uint32_t npoly, lm_mods mods, rescale_consts rc,
                                                        const tw_t *__restrict__ tw_all) {
@@ -70,10 +70,10 @@ template <int LOGN>
 static int rescale_polys_t(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
                            uint32_t npoly, u64 *work, u64 *tbuf) {
     const uint32_t N = ctx->N;
-    const size_t lds = lm_ntt_lds_bytes(N);
-    const uint32_t threads = lm_ntt_threads(N);
-    LM_LDS_ATTR(ctx, k_rescale_last<LOGN>, lds);
-    LM_LDS_ATTR(ctx, k_rescale_limb<LOGN>, lds);
+    const size_t lds_i = lm_inv_lds(ctx->logN), lds_f = lm_fwd_lds(ctx->logN);
+    const uint32_t thr_i = lm_inv_threads(ctx->logN), thr_f = lm_fwd_threads(ctx->logN);
+    LM_LDS_ATTR(ctx, k_rescale_last<LOGN>, lds_i);
+    LM_LDS_ATTR(ctx, k_rescale_limb<LOGN>, lds_f);
     const u64 *cur = src;
     for (uint32_t cur_nl = nl; cur_nl > target; cur_nl--) {
         const uint32_t last = cur_nl - 1;
@@ -90,14 +90,14 @@ static int rescale_polys_t(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst
         }
         {
             lm_prof_scope ps(ctx, "rescale_last_intt", npoly);
-            hipLaunchKernelGGL(k_rescale_last<LOGN>, dim3(npoly), dim3(threads), lds, ctx->stream, cur,
+            hipLaunchKernelGGL(k_rescale_last<LOGN>, dim3(npoly), dim3(thr_i), lds_i, ctx->stream, cur,
                                (size_t)nl * N, last, tbuf, ctx->mods.m[last], ctx->ninv[last], (u64)rc.half,
                                ctx->d_tw_inv + (size_t)last * N);
             LM_HIP(ctx, hipGetLastError());
         }
         {
             lm_prof_scope ps(ctx, "rescale_limb_ntt", (uint64_t)npoly * last);
-            hipLaunchKernelGGL(k_rescale_limb<LOGN>, dim3(npoly * last), dim3(threads), lds, ctx->stream, cur,
+            hipLaunchKernelGGL(k_rescale_limb<LOGN>, dim3(npoly * last), dim3(thr_f), lds_f, ctx->stream, cur,
                                (size_t)nl * N, out, out_stride, tbuf, npoly, ctx->mods, rc, ctx->d_tw_fwd);
             LM_HIP(ctx, hipGetLastError());
         }

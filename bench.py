@@ -56,6 +56,25 @@ def limb_ntt_census(rows, cols, L, K, log_n):
     return commit + inner
 
 
+PMC_NAMES = {"ks_modup_ntt": "k_modup_ntt", "ks_moddown_ntt": "k_moddown_ntt", "rescale_limb_ntt": "k_rescale_limb",
+             "rescale_last_intt": "k_rescale_last", "limb_ntt": "k_limb_ntt", "limb_intt": "k_limb_ntt",
+             "ks_intt_c1": "k_limb_ntt", "ks_intt_p": "k_limb_ntt"}
+
+
+def pmc_traffic(kernel, cfg):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command
+    (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied by tools/collect_pmc.py).
+    bench.py cannot collect hardware counters itself; null when no PMC summary is committed."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{cfg}.json")
+    if not os.path.exists(path):
+        return None
+    tab = json.load(open(path))
+    for name, v in tab.items():
+        if name.startswith(PMC_NAMES.get(kernel, kernel)) and v.get("hbm_bytes_per_launch"):
+            return round(v["hbm_bytes_per_launch"])
+    return None
+
+
 class Job:
     """Device-resident inputs of one prover run + the step function."""
 
@@ -249,7 +268,8 @@ def main():
             alg_bytes_per_launch = 16.0 * job.N * units / launches  # 16*N B per limb transform
             achieved = alg_bytes_per_launch / (ms / launches * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                        "traffic": pmc_traffic(dom, args.config),
                         "avg_launch_ms": round(ms / launches, 4), "limb_ntts_per_launch": units // launches}
     if rank == 0:
         census = limb_ntt_census(job.rows, job.cols, job.L, job.K, job.log_n)

@@ -52,3 +52,19 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in os.sys.argv, verbose=True))
+
+
+HOST_LIB = os.path.join(HERE, "host", "liblumenos_host.so")
+
+
+def build_host(force=False):
+    """C++ host mirror of the reference's fhe/core API (plain g++, links the C-ABI library)."""
+    srcs = [os.path.join(HERE, "host", f) for f in ("core.cpp", "fhe.cpp")]
+    deps = srcs + glob.glob(os.path.join(HERE, "host", "*.hpp")) + [os.path.join(HERE, "..", "include", "lumenos_hip.h")]
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) < os.path.getmtime(HOST_LIB) for d in deps):
+        return HOST_LIB
+    build()
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB, *srcs,
+           "-L" + CSRC, "-llumenos_hip", "-Wl,-rpath," + CSRC]
+    subprocess.check_call(cmd)
+    return HOST_LIB

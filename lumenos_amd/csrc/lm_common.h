@@ -45,6 +45,7 @@ struct lumen_set {
     u64 *d = nullptr;
     size_t words = 0;
     bool owner = true;
+    lumen_ctx *home = nullptr; // context whose pool the storage returns to
 };
 
 struct lumen_ctx {
@@ -68,6 +69,10 @@ struct lumen_ctx {
     std::map<uint64_t, lm_galois_key> gkeys;
     // scratch
     std::map<std::string, std::pair<void *, size_t>> scratch;
+    // freed set storage kept for reuse: a prover run allocates the same set sizes every time, and
+    // mapping/unmapping tens of GB of HBM per call costs more than the kernels that fill it
+    std::multimap<size_t, void *> pool;
+    size_t pool_bytes = 0;
     // kernels whose dynamic-LDS limit has already been raised on this device
     std::set<const void *> lds_attr_done;
     // per-context derived tables owned by other translation units (key-switch constants,

@@ -183,6 +183,7 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
         hipFree(kv.second.d_inv_index);
     }
     for (auto &kv : ctx->scratch) hipFree(kv.second.first);
+    for (auto &kv : ctx->pool) hipFree(kv.second);
     ctx->ext.clear();
     lm_prof_resolve(ctx);
     for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
@@ -212,12 +213,28 @@ extern "C" int lumen_set_create(lumen_ctx *ctx, uint32_t count, uint32_t num_lim
     s->count = count;
     s->nl = num_limbs;
     s->words = (size_t)count * 2 * num_limbs * ctx->N;
+    s->home = ctx;
     if (s->words) {
-        hipError_t e = hipMalloc((void **)&s->d, s->words * sizeof(u64));
-        if (e != hipSuccess) {
-            delete s;
-            return lm_fail(ctx, "hipMalloc(%zu bytes) for a %u x %u-limb set failed: %s",
-                           s->words * sizeof(u64), count, num_limbs, hipGetErrorString(e));
+        const size_t bytes = s->words * sizeof(u64);
+        auto it = ctx->pool.find(bytes);
+        if (it != ctx->pool.end()) { // reuse a block of exactly this size
+            s->d = (u64 *)it->second;
+            ctx->pool.erase(it);
+            ctx->pool_bytes -= bytes;
+        } else {
+            hipError_t e = hipMalloc((void **)&s->d, bytes);
+            if (e != hipSuccess && !ctx->pool.empty()) { // give the pool back and retry once
+                hipStreamSynchronize(ctx->stream);
+                for (auto &kv : ctx->pool) hipFree(kv.second);
+                ctx->pool.clear();
+                ctx->pool_bytes = 0;
+                e = hipMalloc((void **)&s->d, bytes);
+            }
+            if (e != hipSuccess) {
+                delete s;
+                return lm_fail(ctx, "hipMalloc(%zu bytes) for a %u x %u-limb set failed: %s", bytes, count,
+                               num_limbs, hipGetErrorString(e));
+            }
         }
     }
     *out = s;
@@ -227,7 +244,16 @@ extern "C" int lumen_set_create(lumen_ctx *ctx, uint32_t count, uint32_t num_lim
 extern "C" void lumen_set_destroy(lumen_ctx *ctx, lumen_set *set) {
     if (!set) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
-    if (set->owner) hipFree(set->d);
+    if (set->owner && set->d) {
+        lumen_ctx *home = (ctx && ctx == set->home) ? ctx : nullptr; // never touch a context the caller did not pass
+        const size_t bytes = set->words * sizeof(u64);
+        if (home && home->pool_bytes + bytes <= ((size_t)96 << 30)) {
+            home->pool.emplace(bytes, set->d);
+            home->pool_bytes += bytes;
+        } else {
+            hipFree(set->d);
+        }
+    }
     delete set;
 }
 

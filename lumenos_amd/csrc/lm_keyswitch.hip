@@ -110,12 +110,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
     const uint32_t t = r / beta; // modulus index (Q limbs then P limbs)
     const bx_t c = bx[d * LK + t];
     u64 *o = ext + (((size_t)b * beta + d) * LK + t) * N;
-    if (c.own) { // own limb: the original NTT-domain values
-        const u64 *s = acc + ((size_t)(b * 2 + 1) * L + t) * N;
-        for (uint32_t i = 2 * tid; i < N; i += 2 * nthreads)
-            *reinterpret_cast<ulonglong2 *>(o + i) = *reinterpret_cast<const ulonglong2 *>(s + i);
-        return;
-    }
+    if (c.own) return; // own limb: the gadget product reads the original NTT-domain c1 directly
     const lm_qc qc = lm_make_qc(mods.m[t]);
     const u64 *s0 = coef + ((size_t)b * L + d * K) * N;
     const u64 *s1 = c.ns == 2 ? s0 + N : s0; // second limb of the digit
@@ -124,7 +119,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
         u64 rr[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (k < count) rr[k] = lm_reduce(v[k], qc.q, qc.qinv64);
+            if (k < count) rr[k] = lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64);
         lm_store_run(o, i0, rr, count);
     };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);
@@ -133,15 +128,17 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
 // ---- step 3: gadget product.  u[b][w][t][i] = sum_d ext[b][d][t][i] * key[d][w][t][i]
 // key in Montgomery form (k * 2^64 mod q): 128-bit accumulation, one Montgomery reduction.
 #define LM_MAC_COLS 4
-__global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, const u64 *__restrict__ key,
-                                                u64 *__restrict__ u, uint32_t B, uint32_t LK,
-                                                uint32_t beta, uint32_t logN, lm_mods mods) {
-    const uint32_t N = 1u << logN;
+__global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, const u64 *__restrict__ acc,
+                                                const u64 *__restrict__ key, u64 *__restrict__ u, uint32_t B,
+                                                uint32_t L, uint32_t K, uint32_t beta, uint32_t logN,
+                                                lm_mods mods) {
+    const uint32_t N = 1u << logN, LK = L + K;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // coefficient
     const uint32_t t = blockIdx.y;                            // modulus index
     const uint32_t b0 = blockIdx.z * LM_MAC_COLS;
     if (i >= N) return;
     const mod_t md = mods.m[t];
+    const uint32_t own = t < L ? t / K : 0xFFFFFFFFu; // digit whose limbs include t: its "extension" is c1 itself
     u128 a0[LM_MAC_COLS], a1[LM_MAC_COLS];
 #pragma unroll
     for (int c = 0; c < LM_MAC_COLS; c++) a0[c] = 0, a1[c] = 0;
@@ -151,7 +148,8 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
 #pragma unroll
         for (int c = 0; c < LM_MAC_COLS; c++) {
             if (b0 + c < B) {
-                const u64 x = ext[(((size_t)(b0 + c) * beta + d) * LK + t) * N + i];
+                const u64 x = d == own ? acc[((size_t)((b0 + c) * 2 + 1) * L + t) * N + i]
+                                       : ext[(((size_t)(b0 + c) * beta + d) * LK + t) * N + i];
                 a0[c] += (u128)x * k0;
                 a1[c] += (u128)x * k1;
             }
@@ -371,7 +369,7 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
     {
         lm_prof_scope ps(ctx, "ks_mac", (uint64_t)B);
         dim3 grid((N + 255) / 256, LK, (B + LM_MAC_COLS - 1) / LM_MAC_COLS);
-        hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, s.ext, gk.d_key, s.u, B, LK, beta,
+        hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, s.ext, acc, gk.d_key, s.u, B, L, K, beta,
                            ctx->logN, ctx->mods);
         LM_HIP(ctx, hipGetLastError());
     }

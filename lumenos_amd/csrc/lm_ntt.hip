@@ -42,7 +42,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_limb_ntt(const u64 *sr
             u64 r[8];
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                if (k < count) r[k] = lm_reduce(v[k], c.q, c.qinv64);
+                if (k < count) r[k] = lm_reduce_s(v[k], c.q, c.nq, c.qinv64);
             lm_store_run(o, i0, r, count);
         };
         lm_ntt_forward<LOGN>(sm, tw, c, tid, nthreads, ld, st);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rescale_limb(const u64
         lm_load_run(cin, i0, cv, count);
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (k < count) r[k] = lm_shoup(lm_submod(cv[k], lm_reduce(v[k], c.q, c.qinv64), c.q), qlinv, c.q);
+            if (k < count) r[k] = lm_shoup(lm_submod(cv[k], lm_reduce_s(v[k], c.q, c.nq, c.qinv64), c.q), qlinv, c.q);
         lm_store_run(o, i0, r, count);
     };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)limb * N, c, tid, nthreads, ld, st);

@@ -143,7 +143,8 @@ class DeviceSet:
 
     def free(self):
         if self.h:
-            self.ctx.lib.lumen_set_destroy(self.ctx.h, self.h)
+            # a set outliving its context (interpreter shutdown order) is released without pooling
+            self.ctx.lib.lumen_set_destroy(self.ctx.h if self.ctx.h else None, self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,414 @@
+// Host-side mirror of the reference's `fhe` package, server half (see fhe.hpp).
+#include "fhe.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace lumenos {
+namespace fhe {
+
+using core::InvMod;
+using core::MulMod;
+using core::PowMod;
+
+// ring degree per context (the C ABI does not expose it; this mirror created the context)
+static std::map<lumen_ctx *, uint32_t> g_ring_degree;
+
+// ------------------------------------------------------------------ parameters
+ParametersLiteral GenerateBGVParamsForNTT(int nttSize, int logN, uint64_t plaintextModulus) {
+    if (nttSize < 2) throw std::invalid_argument("nttSize must be >= 2");
+    if (logN <= 0) throw std::invalid_argument("logN must be positive");
+    const uint64_t modulus2N = 2ull << logN;
+    if (plaintextModulus % modulus2N != 1)
+        throw std::invalid_argument("plaintextModulus T (" + std::to_string(plaintextModulus) +
+                                    ") does not satisfy T = 1 (mod 2N) (2N=" + std::to_string(modulus2N) + ")");
+    int bits = 0;
+    while (bits < 64 && (plaintextModulus >> bits)) bits++;
+    const int bufferLevels = bits > 45 ? 0 : -2; // bfv.go:147-151
+    const int k = __builtin_ctz((unsigned)nttSize) + bufferLevels;
+    ParametersLiteral lit;
+    lit.LogN = logN;
+    for (int i = 0; i < k; i++) lit.LogQ.push_back(i == 0 ? 58 : 56); // bfv.go:163-169
+    lit.LogP = {55, 55};                                              // bfv.go:172-178
+    lit.PlaintextModulus = plaintextModulus;
+    return lit;
+}
+
+static std::vector<uint64_t> ntt_primes(int bits, uint64_t nth_root, int count, uint64_t exclude) {
+    std::vector<uint64_t> out;
+    const uint64_t base = (1ull << bits) + 1;
+    uint64_t up = base, down = base - nth_root;
+    while ((int)out.size() < count) {
+        uint64_t cand;
+        if (up - base <= base - down) cand = up, up += nth_root;
+        else cand = down, down -= nth_root;
+        if (cand != exclude && core::IsPrime(cand)) out.push_back(cand);
+    }
+    return out;
+}
+
+Parameters Parameters::FromModuli(int logN, std::vector<uint64_t> q, std::vector<uint64_t> p, uint64_t T) {
+    Parameters P;
+    P.LogN = logN;
+    P.Q = std::move(q);
+    P.P = std::move(p);
+    P.T = T;
+    const uint64_t two_n = 2ull << logN;
+    for (const auto *v : {&P.Q, &P.P})
+        for (uint64_t m : *v) {
+            if (m % two_n != 1) throw std::invalid_argument("modulus is not 1 mod 2N");
+            P.Psi.push_back(PowMod(core::PrimitiveRoot(m), (m - 1) / two_n, m));
+        }
+    return P;
+}
+
+Parameters Parameters::FromLiteral(const ParametersLiteral &lit) {
+    const uint64_t two_n = 2ull << lit.LogN;
+    std::vector<uint64_t> q, p;
+    int n58 = 0, n56 = 0;
+    for (int b : lit.LogQ) (b == 58 ? n58 : n56)++;
+    std::vector<uint64_t> q58 = ntt_primes(58, two_n, n58, lit.PlaintextModulus);
+    std::vector<uint64_t> q56 = ntt_primes(56, two_n, n56, lit.PlaintextModulus);
+    size_t i58 = 0, i56 = 0;
+    for (int b : lit.LogQ) q.push_back(b == 58 ? q58[i58++] : q56[i56++]);
+    p = ntt_primes(55, two_n, (int)lit.LogP.size(), lit.PlaintextModulus);
+    return FromModuli(lit.LogN, q, p, lit.PlaintextModulus);
+}
+
+std::vector<uint64_t> Parameters::GaloisElementsForInnerSum(int batch, int n) const {
+    std::vector<uint64_t> out;
+    const uint64_t two_n = 2ull << LogN;
+    const int span = (n * batch == N()) ? n / 2 : n;
+    uint64_t g = PowMod(5, (uint64_t)batch, two_n);
+    for (int r = 1; r < span; r <<= 1) {
+        out.push_back(g);
+        g = (g * g) & (two_n - 1);
+    }
+    if (n * batch == N()) out.push_back(two_n - 1);
+    return out;
+}
+
+// ------------------------------------------------------------------ Ciphertexts
+Ciphertexts &Ciphertexts::operator=(Ciphertexts &&o) noexcept {
+    if (this != &o) {
+        if (set_) lumen_set_destroy(ctx_, set_);
+        ctx_ = o.ctx_, set_ = o.set_;
+        o.ctx_ = nullptr, o.set_ = nullptr;
+    }
+    return *this;
+}
+Ciphertexts::~Ciphertexts() {
+    if (set_) lumen_set_destroy(ctx_, set_);
+}
+int Ciphertexts::Len() const { return set_ ? (int)lumen_set_count(set_) : 0; }
+int Ciphertexts::Level() const { return set_ ? (int)lumen_set_limbs(set_) - 1 : -1; }
+
+Ciphertexts Ciphertexts::Upload(ServerBFV &backend, const std::vector<uint64_t> &host, int count, int level) {
+    lumen_set *s = nullptr;
+    backend.check(lumen_set_create(backend.Context(), (uint32_t)count, (uint32_t)level + 1, &s), "lumen_set_create");
+    Ciphertexts c(backend.Context(), s);
+    const size_t want = (size_t)count * 2 * (level + 1) * backend.GetParameters().N();
+    if (host.size() != want) throw std::invalid_argument("Upload: host buffer has the wrong size");
+    if (count) backend.check(lumen_set_upload(backend.Context(), s, 0, (uint32_t)count, host.data()), "lumen_set_upload");
+    return c;
+}
+
+std::vector<uint64_t> Ciphertexts::Download() const {
+    if (!set_) return {};
+    const uint32_t count = lumen_set_count(set_), nl = lumen_set_limbs(set_);
+    const uint32_t N = g_ring_degree.at(ctx_);
+    std::vector<uint64_t> out((size_t)count * 2 * nl * N);
+    if (count && lumen_set_download(ctx_, set_, 0, count, out.data()))
+        throw std::runtime_error(std::string("lumen_set_download: ") + lumen_last_error(ctx_));
+    return out;
+}
+
+// ------------------------------------------------------------------ host ring helpers
+static void host_ntt(std::vector<uint64_t> &a, uint64_t q, uint64_t psi, int logN, bool inverse) {
+    // [LATTIGO-RECALL] SubRing.NTT / INTT (negacyclic, bit-reversed output); host-side use only for
+    // the single plaintexts / the one zero column the host creates per call
+    const uint32_t N = 1u << logN;
+    std::vector<uint64_t> tw(N);
+    const uint64_t root = inverse ? InvMod(psi, q) : psi;
+    uint64_t cur = 1;
+    for (uint32_t j = 0; j < N; j++) {
+        tw[core::BitReverse64(j, logN)] = cur;
+        cur = MulMod(cur, root, q);
+    }
+    if (!inverse) {
+        uint32_t t = N >> 1;
+        for (uint32_t m = 1; m < N; m <<= 1, t >>= 1)
+            for (uint32_t i = 0; i < m; i++)
+                for (uint32_t j = 2 * i * t; j < 2 * i * t + t; j++) {
+                    const uint64_t u = a[j], v = MulMod(a[j + t], tw[m + i], q);
+                    a[j] = u + v >= q ? u + v - q : u + v;
+                    a[j + t] = u >= v ? u - v : u + q - v;
+                }
+    } else {
+        uint32_t t = 1;
+        for (uint32_t m = N >> 1; m >= 1; m >>= 1, t <<= 1)
+            for (uint32_t i = 0; i < m; i++)
+                for (uint32_t j = 2 * i * t; j < 2 * i * t + t; j++) {
+                    const uint64_t u = a[j], v = a[j + t];
+                    a[j] = u + v >= q ? u + v - q : u + v;
+                    a[j + t] = MulMod(u >= v ? u - v : u + q - v, tw[m + i], q);
+                }
+        const uint64_t ninv = InvMod(N % q, q);
+        for (uint64_t &x : a) x = MulMod(x, ninv, q);
+    }
+}
+
+// ------------------------------------------------------------------ ServerBFV
+void ServerBFV::check(int rc, const char *what) const {
+    if (rc) throw std::runtime_error(std::string(what) + ": " + lumen_last_error(ctx_));
+}
+
+ServerBFV::ServerBFV(core::PrimeField *plaintextField, const Parameters &params, std::vector<uint64_t> pk,
+                     const std::map<uint64_t, std::vector<uint64_t>> &evk, int device)
+    : ptField_(plaintextField), params_(params), pk_(std::move(pk)), rng_(std::random_device{}()) {
+    lumen_params_desc d;
+    memset(&d, 0, sizeof(d));
+    d.abi_version = LUMEN_ABI_VERSION;
+    d.log_n = (uint32_t)params.LogN;
+    d.num_q = (uint32_t)params.Q.size();
+    d.num_p = (uint32_t)params.P.size();
+    d.plaintext_modulus = params.T;
+    d.device = device;
+    size_t i = 0;
+    for (uint64_t m : params.Q) d.moduli[i++] = m;
+    for (uint64_t m : params.P) d.moduli[i++] = m;
+    for (size_t k = 0; k < params.Psi.size(); k++) d.psi[k] = params.Psi[k];
+    if (lumen_ctx_create(&d, &ctx_)) throw std::runtime_error(std::string("lumen_ctx_create: ") + lumen_last_error(nullptr));
+    g_ring_degree[ctx_] = (uint32_t)params.N();
+    check(lumen_field_set(ctx_, plaintextField->RootsForward().data(), (uint32_t)plaintextField->N()), "lumen_field_set");
+    for (const auto &kv : evk) check(lumen_load_galois_key(ctx_, kv.first, kv.second.data()), "lumen_load_galois_key");
+    // encoder tables ([LATTIGO-RECALL] bgv.Encoder: slot i of row 0 sits at 5^i, row 1 at -5^i)
+    const uint64_t T = params.T, two_n = 2ull << params.LogN;
+    psiT_ = PowMod(core::PrimitiveRoot(T), (T - 1) / two_n, T);
+    const int N = params.N(), row = N >> 1;
+    slot_index_.resize(N);
+    uint64_t pos = 1;
+    for (int s = 0; s < row; s++) {
+        slot_index_[s] = (uint32_t)core::BitReverse64((pos - 1) >> 1, params.LogN);
+        slot_index_[s | row] = (uint32_t)core::BitReverse64((two_n - pos - 1) >> 1, params.LogN);
+        pos = (pos * 5) & (two_n - 1);
+    }
+}
+
+ServerBFV::~ServerBFV() {
+    if (ctx_) {
+        g_ring_degree.erase(ctx_);
+        lumen_ctx_destroy(ctx_);
+    }
+}
+
+int ServerBFV::MulCounter() const { return (int)lumen_mul_counter(ctx_); }
+
+Plaintext ServerBFV::Encode(const std::vector<uint64_t> &values) const {
+    const int N = params_.N(), nl = (int)params_.Q.size();
+    if ((int)values.size() > N) throw std::invalid_argument("cannot Encode: too many values for the ring degree");
+    std::vector<uint64_t> m(N, 0);
+    for (size_t i = 0; i < values.size(); i++) m[slot_index_[i]] = values[i] % params_.T; // raw u64 reduce implicitly
+    host_ntt(m, params_.T, psiT_, params_.LogN, true);
+    Plaintext pt;
+    pt.Level = nl - 1;
+    pt.Value.resize((size_t)nl * N);
+    for (int l = 0; l < nl; l++) {
+        const uint64_t q = params_.Q[l], tinv = InvMod(params_.T % q, q);
+        std::vector<uint64_t> limb(N);
+        for (int k = 0; k < N; k++) limb[k] = MulMod(m[k] % q, tinv, q);
+        host_ntt(limb, q, params_.Psi[l], params_.LogN, false);
+        memcpy(&pt.Value[(size_t)l * N], limb.data(), (size_t)N * 8);
+    }
+    return pt;
+}
+
+std::vector<uint64_t> ServerBFV::EncryptNew(const Plaintext &pt) {
+    // rlwe.Encryptor with a public key: (u*pk0 + e0 + pt, u*pk1 + e1), ternary u, Gaussian e (sigma 3.2)
+    const int N = params_.N(), L = (int)params_.Q.size(), nl = pt.Level + 1;
+    std::normal_distribution<double> gauss(0.0, 3.2);
+    std::vector<int64_t> u(N), e0(N), e1(N);
+    for (int k = 0; k < N; k++) {
+        u[k] = (int64_t)(rng_() % 3) - 1;
+        do e0[k] = (int64_t)std::llround(gauss(rng_)); while (std::llabs(e0[k]) > 19);
+        do e1[k] = (int64_t)std::llround(gauss(rng_)); while (std::llabs(e1[k]) > 19);
+    }
+    std::vector<uint64_t> ct((size_t)2 * nl * N);
+    auto lift = [&](const std::vector<int64_t> &c, int l) {
+        const uint64_t q = params_.Q[l];
+        std::vector<uint64_t> v(N);
+        for (int k = 0; k < N; k++) v[k] = c[k] >= 0 ? (uint64_t)c[k] : q - (uint64_t)(-c[k]);
+        host_ntt(v, q, params_.Psi[l], params_.LogN, false);
+        return v;
+    };
+    for (int l = 0; l < nl; l++) {
+        const uint64_t q = params_.Q[l];
+        const std::vector<uint64_t> un = lift(u, l), a = lift(e0, l), b = lift(e1, l);
+        for (int k = 0; k < N; k++) {
+            uint64_t c0 = (MulMod(un[k], pk_[(size_t)l * N + k], q) + a[k]) % q;
+            c0 = (c0 + pt.Value[(size_t)l * N + k]) % q;
+            ct[(size_t)l * N + k] = c0;
+            ct[(size_t)(nl + l) * N + k] = (MulMod(un[k], pk_[(size_t)(L + l) * N + k], q) + b[k]) % q;
+        }
+    }
+    return ct;
+}
+
+// ------------------------------------------------------------------ Encode / NTT
+Ciphertexts Encode(const Ciphertexts &matrix, int rows, int rhoInv, ServerBFV &backend) {
+    // code.go:15-22: one fresh encryption of the zero vector, copied into every padding column
+    Plaintext zeroColPt = backend.Encode(std::vector<uint64_t>((size_t)rows, 0));
+    const std::vector<uint64_t> zeroCol = backend.EncryptNew(zeroColPt);
+    lumen_set *enc = nullptr;
+    backend.check(lumen_encode(backend.Context(), matrix.Handle(), zeroCol.data(), (uint32_t)rhoInv, &enc), "lumen_encode");
+    return Ciphertexts(backend.Context(), enc);
+}
+
+void NTT(Ciphertexts &values, int size, ServerBFV &backend) {
+    backend.check(lumen_ct_ntt(backend.Context(), values.Handle(), (uint32_t)size), "lumen_ct_ntt");
+}
+
+// ------------------------------------------------------------------ Ligero
+int calculateQueries(double securityBits, int rhoInv) {
+    const double t = std::log2(1.0 + 1.0 / (double)rhoInv);
+    if (1.0 - t <= 0) return 0;
+    return (int)std::ceil(securityBits / (1.0 - t));
+}
+
+LigeroCommitter LigeroCommitter::NewLigeroCommitter(double securityBits, int rows, int cols, int rhoInv) {
+    if ((long long)rows * cols <= 0) throw std::invalid_argument("size must be positive");
+    if (securityBits <= 0) throw std::invalid_argument("securityBits must be positive");
+    LigeroCommitter c;
+    c.Metadata = {rows, cols, rhoInv, calculateQueries(securityBits, rhoInv)};
+    return c;
+}
+
+void LigeroMetadata::WriteTo(std::vector<uint8_t> &buf) const {
+    auto le = [&](uint64_t v, int n) {
+        for (int i = 0; i < n; i++) buf.push_back((uint8_t)(v >> (8 * i)));
+    };
+    le((uint32_t)Rows, 4), le((uint32_t)Cols, 4), le((uint8_t)RhoInv, 1), le((uint16_t)Queries, 2);
+}
+
+std::pair<LigeroProver, std::vector<uint8_t>> LigeroCommitter::Commit(const Ciphertexts &matrix, ServerBFV &backend,
+                                                                       core::Span *ctx) const {
+    lumen_ctx *h = backend.Context();
+    core::Span *span = core::Span::StartSpan("Encode", ctx);
+    Ciphertexts encoded = Encode(matrix, Metadata.Rows, Metadata.RhoInv, backend);
+    backend.check(lumen_sync(h), "lumen_sync");
+    span->End();
+    delete span;
+
+    span = core::Span::StartSpan("Merkle tree built", ctx);
+    // processLeafParallel (ligero.go:126-183): mod-switch every column to level 1, serialise, hash
+    lumen_set *lvl1 = nullptr;
+    backend.check(lumen_rescale(h, encoded.Handle(), 2, &lvl1), "lumen_rescale");
+    Ciphertexts level1(h, lvl1);
+    std::vector<core::Digest> leaves((size_t)level1.Len());
+    if (!leaves.empty()) backend.check(lumen_leaf_digests(h, lvl1, leaves[0].data()), "lumen_leaf_digests");
+    core::MerkleTree tree = core::MerkleTree::FromLeafDigests(std::move(leaves)); // core.NewTree
+    span->End();
+    delete span;
+
+    LigeroProver prover;
+    prover.Committer = this;
+    prover.Matrix = &matrix;
+    prover.EncodedMatrix = std::move(level1);
+    prover.Tree = std::move(tree);
+    std::vector<uint8_t> root = prover.Tree.MerkleRoot();
+    return {std::move(prover), std::move(root)};
+}
+
+Ciphertexts matrixInnerSumEval(const Ciphertexts &matrix, const Plaintext &plaintext, int rows, ServerBFV &backend) {
+    lumen_set *out = nullptr;
+    backend.check(lumen_matrix_inner_sum(backend.Context(), matrix.Handle(), plaintext.Value.data(), (uint32_t)rows, &out),
+                  "lumen_matrix_inner_sum");
+    return Ciphertexts(backend.Context(), out);
+}
+
+std::vector<int> sampleQueryIndices(core::Transcript &transcript, int queries, int extCols) {
+    std::vector<int> idx((size_t)queries);
+    for (int &q : idx) q = (int)(transcript.SampleUint64("query") % (uint64_t)extCols);
+    return idx;
+}
+
+EncryptedProof LigeroProver::Prove(core::Element point, ServerBFV &backend, core::Transcript &transcript, core::Span *ctx) {
+    const int cols = Committer->Metadata.Cols, rows = Committer->Metadata.Rows;
+    // don't write root to transcript for compatibility with LigeroProveReference (ligero.go:198-199)
+    std::vector<uint64_t> r((size_t)rows);
+    transcript.SampleUints("r", r); // raw u64, not reduced (ligero.go:202-203)
+    Plaintext rPt = backend.Encode(r);
+    std::vector<uint64_t> b((size_t)rows);
+    const core::Element zPow = backend.Field()->Pow((uint64_t)cols, point);
+    core::Element powB = 1;
+    for (uint64_t &bi : b) {
+        bi = powB;
+        powB = backend.Field()->Mul(powB, zPow);
+    }
+    Plaintext bPt = backend.Encode(b);
+
+    // the reference runs R and Z concurrently on two evaluator copies (ligero.go:231-242); one
+    // device context serialises them on its stream
+    core::Span *spanR = core::Span::StartSpan("InnerProduct(Matrix, r)", ctx);
+    Ciphertexts matR = matrixInnerSumEval(*Matrix, rPt, rows, backend);
+    backend.check(lumen_sync(backend.Context()), "lumen_sync");
+    spanR->End();
+    delete spanR;
+    core::Span *spanZ = core::Span::StartSpan("InnerProduct(Matrix, b)", ctx);
+    Ciphertexts matZ = matrixInnerSumEval(*Matrix, bPt, rows, backend);
+    backend.check(lumen_sync(backend.Context()), "lumen_sync");
+    spanZ->End();
+    delete spanZ;
+
+    transcript.AppendField("point", point);
+
+    core::Span *querySpan = core::Span::StartSpan("Query columns", ctx);
+    const int extCols = cols * Committer->Metadata.RhoInv;
+    EncryptedProof proof;
+    proof.QueryIndices = sampleQueryIndices(transcript, Committer->Metadata.Queries, extCols);
+    std::vector<uint32_t> idx(proof.QueryIndices.begin(), proof.QueryIndices.end());
+    lumen_set *q = nullptr;
+    backend.check(lumen_gather(backend.Context(), EncodedMatrix.Handle(), idx.data(), (uint32_t)idx.size(), &q), "lumen_gather");
+    proof.QueriedCols = Ciphertexts(backend.Context(), q);
+    for (int i : proof.QueryIndices) proof.MerklePaths.push_back(Tree.GetMerklePath((unsigned)i));
+    querySpan->End();
+    delete querySpan;
+
+    proof.Metadata = Committer->Metadata;
+    proof.Root = Tree.MerkleRoot();
+    proof.MatR = std::move(matR);
+    proof.MatZ = std::move(matZ);
+    return proof;
+}
+
+static void write_cts(std::vector<uint8_t> &buf, const Ciphertexts &c) {
+    const std::vector<uint64_t> host = c.Download();
+    const int count = c.Len();
+    if (!count) return;
+    const uint32_t nl = (uint32_t)c.Level() + 1;
+    const size_t ctw = host.size() / (size_t)count;
+    const uint32_t N = (uint32_t)(ctw / (2 * nl));
+    for (int i = 0; i < count; i++) {
+        const uint32_t hdr[4] = {0x54434d4cu, 2u, nl, N}; // stand-in for rlwe.Ciphertext.WriteTo
+        const uint8_t *h = reinterpret_cast<const uint8_t *>(hdr);
+        buf.insert(buf.end(), h, h + 16);
+        const uint8_t *d = reinterpret_cast<const uint8_t *>(host.data() + (size_t)i * ctw);
+        buf.insert(buf.end(), d, d + ctw * 8);
+    }
+}
+
+std::vector<uint8_t> EncryptedProof::MarshalBinary() const {
+    std::vector<uint8_t> buf;
+    Metadata.WriteTo(buf);      // ligero.go:660
+    write_cts(buf, MatR);       // ligero.go:664-671
+    write_cts(buf, MatZ);       // ligero.go:674-681
+    write_cts(buf, QueriedCols); // ligero.go:684-691
+    for (const auto &path : MerklePaths)
+        for (const core::Digest &d : path) buf.insert(buf.end(), d.begin(), d.end()); // ligero.go:694-698
+    buf.insert(buf.end(), Root.begin(), Root.end());                                   // ligero.go:700
+    return buf;
+}
+
+} // namespace fhe
+} // namespace lumenos

@@ -1,0 +1,150 @@
+// Host-side mirror of the reference's `fhe` package, server half (fhe/bfv.go, fhe/code.go,
+// fhe/ntt.go, fhe/ligero.go:19-370,638-705,755-797), written above the C ABI of
+// include/lumenos_hip.h.  Names, argument meaning and error behaviour follow the Go code so that a
+// test written against it reads like fhe/ligero_test.go; where the Go code hands []*rlwe.Ciphertext
+// around, this mirror hands `Ciphertexts` (an HBM-resident lumen_set) around.
+#pragma once
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/lumenos_hip.h"
+#include "core.hpp"
+
+namespace lumenos {
+namespace fhe {
+
+// bgv.ParametersLiteral as produced by GenerateBGVParamsForNTT
+struct ParametersLiteral {
+    int LogN = 0;
+    std::vector<int> LogQ, LogP;
+    uint64_t PlaintextModulus = 0;
+};
+
+// fhe.GenerateBGVParamsForNTT (fhe/bfv.go:121-188); errors become std::invalid_argument with the
+// reference's messages
+ParametersLiteral GenerateBGVParamsForNTT(int nttSize, int logN, uint64_t plaintextModulus);
+
+// the part of bgv.Parameters the path needs
+struct Parameters {
+    int LogN = 0;
+    std::vector<uint64_t> Q, P;
+    std::vector<uint64_t> Psi; // primitive 2N-th root per modulus (Q then P)
+    uint64_t T = 0;
+    int N() const { return 1 << LogN; }
+    int MaxLevel() const { return (int)Q.size() - 1; }
+    uint64_t PlaintextModulus() const { return T; }
+    // bgv.NewParametersFromLiteral: [LATTIGO-RECALL] NTT-friendly primes nearest 2^bits, upstream first
+    static Parameters FromLiteral(const ParametersLiteral &lit);
+    // explicit moduli (what a Go host passes: Lattigo's own)
+    static Parameters FromModuli(int logN, std::vector<uint64_t> q, std::vector<uint64_t> p, uint64_t T);
+    // params.GaloisElementsForInnerSum(1, n) in the order InnerSum uses them
+    std::vector<uint64_t> GaloisElementsForInnerSum(int batch, int n) const;
+};
+
+struct Plaintext { // *rlwe.Plaintext: one polynomial, NTT domain, [level+1][N]
+    std::vector<uint64_t> Value;
+    int Level = 0;
+};
+
+class ServerBFV;
+
+// []*rlwe.Ciphertext resident in HBM
+class Ciphertexts {
+  public:
+    Ciphertexts() = default;
+    Ciphertexts(lumen_ctx *ctx, lumen_set *set) : ctx_(ctx), set_(set) {}
+    Ciphertexts(Ciphertexts &&o) noexcept { *this = std::move(o); }
+    Ciphertexts &operator=(Ciphertexts &&o) noexcept;
+    Ciphertexts(const Ciphertexts &) = delete;
+    ~Ciphertexts();
+    static Ciphertexts Upload(ServerBFV &backend, const std::vector<uint64_t> &host, int count, int level);
+    std::vector<uint64_t> Download() const; // [count][2][level+1][N]
+    int Len() const;
+    int Level() const;
+    lumen_set *Handle() const { return set_; }
+    lumen_ctx *Context() const { return ctx_; }
+
+  private:
+    lumen_ctx *ctx_ = nullptr;
+    lumen_set *set_ = nullptr;
+};
+
+// fhe.ServerBFV (fhe/bfv.go:13-58): plaintext field + parameters + evaluator/encoder/encryptor
+class ServerBFV {
+  public:
+    // NewBackendBFV(plaintextField, params, pk, evk).  pk: [2][L][N] NTT domain; evk: Galois keys in
+    // the layout of lumen_load_galois_key.
+    ServerBFV(core::PrimeField *plaintextField, const Parameters &params, std::vector<uint64_t> pk,
+              const std::map<uint64_t, std::vector<uint64_t>> &evk, int device = 0);
+    ~ServerBFV();
+    core::PrimeField *Field() { return ptField_; }
+    const Parameters &GetParameters() const { return params_; }
+    int MulCounter() const; // bfv.go:44-46
+    lumen_ctx *Context() const { return ctx_; }
+    // Encoder.Encode(values, pt) at MaxLevel ([LATTIGO-RECALL] m * T^-1 form, slot index matrix)
+    Plaintext Encode(const std::vector<uint64_t> &values) const;
+    // Encryptor.EncryptNew(pt) under pk, host layout [2][L][N]
+    std::vector<uint64_t> EncryptNew(const Plaintext &pt);
+    void check(int rc, const char *what) const; // throws std::runtime_error with lumen_last_error
+
+  private:
+    core::PrimeField *ptField_;
+    Parameters params_;
+    std::vector<uint64_t> pk_;
+    lumen_ctx *ctx_ = nullptr;
+    std::mt19937_64 rng_;
+    uint64_t psiT_ = 0;
+    std::vector<uint32_t> slot_index_;
+};
+
+// fhe.Encode (fhe/code.go:8-34)
+Ciphertexts Encode(const Ciphertexts &matrix, int rows, int rhoInv, ServerBFV &backend);
+// fhe.NTT (fhe/ntt.go:12-18): in place on `values`
+void NTT(Ciphertexts &values, int size, ServerBFV &backend);
+
+struct LigeroMetadata { // fhe/ligero.go:19-24
+    int Rows = 0, Cols = 0, RhoInv = 0, Queries = 0;
+    void WriteTo(std::vector<uint8_t> &buf) const; // ligero.go:755-761
+};
+
+int calculateQueries(double securityBits, int rhoInv); // ligero.go:65-71
+
+struct EncryptedProof { // fhe/ligero.go:185-192
+    LigeroMetadata Metadata;
+    Ciphertexts MatR, MatZ, QueriedCols;
+    std::vector<std::vector<core::Digest>> MerklePaths;
+    std::vector<uint8_t> Root;
+    std::vector<int> QueryIndices; // not part of the wire format; kept for tests
+    // ligero.go:646-705; ciphertext bytes are the documented stand-in for Lattigo's WriteTo
+    std::vector<uint8_t> MarshalBinary() const;
+};
+
+class LigeroCommitter;
+
+struct LigeroProver { // fhe/ligero.go:32-37
+    const LigeroCommitter *Committer = nullptr;
+    const Ciphertexts *Matrix = nullptr;
+    Ciphertexts EncodedMatrix; // kept at level 1: the reference re-rescales queried columns to it
+    core::MerkleTree Tree;
+    // ligero.go:194-291
+    EncryptedProof Prove(core::Element point, ServerBFV &backend, core::Transcript &transcript, core::Span *ctx);
+};
+
+class LigeroCommitter { // fhe/ligero.go:27-29, 40-63
+  public:
+    LigeroMetadata Metadata;
+    static LigeroCommitter NewLigeroCommitter(double securityBits, int rows, int cols, int rhoInv);
+    // ligero.go:95-124: returns the prover state and the Merkle root
+    std::pair<LigeroProver, std::vector<uint8_t>> Commit(const Ciphertexts &matrix, ServerBFV &backend,
+                                                         core::Span *ctx) const;
+};
+
+// matrixInnerSumEval (ligero.go:299-370), without the ring switch
+Ciphertexts matrixInnerSumEval(const Ciphertexts &matrix, const Plaintext &plaintext, int rows, ServerBFV &backend);
+std::vector<int> sampleQueryIndices(core::Transcript &transcript, int queries, int extCols); // ligero.go:638-644
+
+} // namespace fhe
+} // namespace lumenos

@@ -1,0 +1,162 @@
+// C++ twin of TestLigeroE2E (fhe/ligero_test.go:70-176) against the host mirror in
+// lumenos_amd/host: the server side runs on the GPU through the C ABI, the client side
+// (keys, decryption) and the plain verifier arithmetic come from the CPU oracle (test infra).
+//   usage: test_ligero_host <logN> <rows> <cols> <numQ>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "../../lumenos_amd/host/fhe.hpp"
+#include "../../oracle/lo_common.h"
+
+extern "C" {
+void lo_decrypt_phase(const lo_params *p, const uint64_t *sk, const uint64_t *ct, uint32_t nl, uint64_t *phase);
+}
+
+using namespace lumenos;
+
+#define REQUIRE(cond, ...)                          \
+    do {                                            \
+        if (!(cond)) {                              \
+            fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+            fprintf(stderr, __VA_ARGS__);           \
+            fprintf(stderr, "\n");                  \
+            return 1;                               \
+        }                                           \
+    } while (0)
+
+static const uint64_t Modulus = 144115188075593729ull; // fhe/ligero_test.go:16
+static const int rhoInv = 2;
+
+int main(int argc, char **argv) {
+    const int LogN = argc > 1 ? atoi(argv[1]) : 10;
+    const int rows = argc > 2 ? atoi(argv[2]) : 512;
+    const int cols = argc > 3 ? atoi(argv[3]) : 16;
+    const int numQ = argc > 4 ? atoi(argv[4]) : 6;
+    core::Span::quiet = false;
+
+    // run(): parameters, keys (ligero_test.go:36-68)
+    fhe::ParametersLiteral lit = fhe::GenerateBGVParamsForNTT(cols, LogN, Modulus);
+    while ((int)lit.LogQ.size() < numQ) lit.LogQ.push_back(56); // small shapes need more room than the heuristic gives
+    fhe::Parameters params = fhe::Parameters::FromLiteral(lit);
+    const int N = params.N(), L = (int)params.Q.size(), K = (int)params.P.size();
+    std::vector<uint64_t> moduli(params.Q);
+    moduli.insert(moduli.end(), params.P.begin(), params.P.end());
+    lo_params *op = lo_params_new(LogN, L, K, moduli.data(), Modulus);
+    REQUIRE(op, "oracle params");
+    for (int i = 0; i < L + K; i++) REQUIRE(lo_params_psi(op, i) == params.Psi[i], "psi mismatch at %d", i);
+    lo_rng rng;
+    lo_rng_seed(&rng, 42);
+    std::vector<uint64_t> sk((size_t)(L + K) * N), pk((size_t)2 * L * N);
+    lo_keygen_secret(op, &rng, sk.data());
+    lo_keygen_public(op, &rng, sk.data(), pk.data());
+    std::map<uint64_t, std::vector<uint64_t>> evk;
+    for (uint64_t g : params.GaloisElementsForInnerSum(1, rows)) {
+        evk[g].resize(lo_evk_words(op));
+        lo_keygen_galois(op, &rng, sk.data(), g, evk[g].data());
+    }
+    core::PrimeField ptField(params.PlaintextModulus(), cols * 2);
+    fhe::ServerBFV server(&ptField, params, pk, evk);
+
+    // testLigeroE2E: witness, encryption of the batched columns by the server's own encoder/encryptor
+    std::vector<uint64_t> matrix = core::RandomMatrixRowMajor(rows, cols, Modulus);
+    const core::Element z = 1;
+    fhe::LigeroCommitter ligero = fhe::LigeroCommitter::NewLigeroCommitter(128, rows, cols, rhoInv);
+    printf("Number of queried columns: %d\n", ligero.Metadata.Queries);
+    REQUIRE(ligero.Metadata.Queries == 309, "queries");
+    core::Span *span = core::Span::StartSpan("Encrypt matrix", nullptr);
+    std::vector<uint64_t> host_cts((size_t)cols * 2 * L * N);
+    for (int j = 0; j < cols; j++) {
+        std::vector<uint64_t> column(rows);
+        for (int i = 0; i < rows; i++) column[i] = matrix[(size_t)i * cols + j];
+        std::vector<uint64_t> ct = server.EncryptNew(server.Encode(column));
+        memcpy(&host_cts[(size_t)j * 2 * L * N], ct.data(), ct.size() * 8);
+    }
+    fhe::Ciphertexts ciphertexts = fhe::Ciphertexts::Upload(server, host_cts, cols, L - 1);
+    span->End();
+
+    span = core::Span::StartSpan("Commit FHE evaluation", nullptr, "Commit FHE evaluation...");
+    auto commit = ligero.Commit(ciphertexts, server, span);
+    span->End();
+    fhe::LigeroProver &comm = commit.first;
+
+    core::Transcript transcript("test");
+    span = core::Span::StartSpan("Prove FHE evaluation", nullptr, "Prove FHE evaluation...");
+    fhe::EncryptedProof proof = comm.Prove(z, server, transcript, span);
+    span->End();
+    printf("Number of multiplications: %d\n", server.MulCounter());
+
+    std::vector<uint8_t> marshaled = proof.MarshalBinary();
+    const size_t ct1 = 16 + (size_t)4 * N * 8;
+    const int S = cols * rhoInv;
+    int depth = 0;
+    while ((1 << depth) < S) depth++;
+    REQUIRE(marshaled.size() == 11 + (size_t)(2 * cols + 309) * ct1 + (size_t)309 * depth * 32 + 32,
+            "marshaled size %zu", marshaled.size());
+
+    // ---- client: decrypt (EncryptedProof.Decrypt, ligero.go:381-502) with the oracle
+    const uint64_t scale = lo_rescale_scale(op, L, 2);
+    auto decrypt = [&](const std::vector<uint64_t> &host, int idx, int nvals) {
+        std::vector<uint64_t> v(nvals);
+        lo_decrypt_decode(op, sk.data(), host.data() + (size_t)idx * 4 * N, 2, scale, v.data(), nvals);
+        return v;
+    };
+    std::vector<uint64_t> hR = proof.MatR.Download(), hZ = proof.MatZ.Download(), hQ = proof.QueriedCols.Download();
+    std::vector<uint64_t> MatR(cols), MatZ(cols);
+    for (int j = 0; j < cols; j++) MatR[j] = decrypt(hR, j, 1)[0], MatZ[j] = decrypt(hZ, j, 1)[0];
+
+    // ---- LigeroProveReference equality (ligero_test.go:164-174)
+    core::Transcript refT("test");
+    std::vector<uint64_t> r(rows);
+    refT.SampleUints("r", r);
+    std::vector<uint64_t> b(rows);
+    {
+        const uint64_t zPow = ptField.Pow(cols, z);
+        uint64_t pw = 1;
+        for (auto &x : b) x = pw, pw = ptField.Mul(pw, zPow);
+    }
+    for (int j = 0; j < cols; j++) {
+        uint64_t sr = 0, sz = 0;
+        for (int i = 0; i < rows; i++) {
+            const uint64_t m = matrix[(size_t)i * cols + j];
+            sr = ptField.Add(sr, ptField.Mul(m, r[i] % Modulus));
+            sz = ptField.Add(sz, ptField.Mul(m, b[i]));
+        }
+        REQUIRE(MatR[j] == sr, "MatR differs at [%d]", j);
+        REQUIRE(MatZ[j] == sz, "MatZ differs at [%d]", j);
+    }
+
+    // ---- Proof.Verify (ligero.go:517-574)
+    std::vector<uint64_t> encR(S), encZ(S);
+    lo_plain_encode(MatR.data(), cols, rhoInv, Modulus, ptField.RootsForward().data(), S, encR.data());
+    lo_plain_encode(MatZ.data(), cols, rhoInv, Modulus, ptField.RootsForward().data(), S, encZ.data());
+    refT.AppendField("point", z);
+    std::vector<int> qidx = fhe::sampleQueryIndices(refT, 309, S);
+    REQUIRE(qidx == proof.QueryIndices, "query indices differ from the verifier's transcript");
+    std::vector<uint8_t> leaf(ct1);
+    for (size_t qi = 0; qi < qidx.size(); qi++) {
+        lo_ct_serialize(hQ.data() + qi * 4 * N, 2, N, leaf.data());
+        core::Digest d = core::Sha256(leaf.data(), leaf.size());
+        REQUIRE(core::VerifyMerklePath(d, proof.MerklePaths[qi], proof.Root, (unsigned)qidx[qi]),
+                "failed to verify merkle path for column %d", qidx[qi]);
+        std::vector<uint64_t> col = decrypt(hQ, (int)qi, rows);
+        uint64_t ir = 0, ib = 0;
+        for (int i = 0; i < rows; i++) {
+            ir = ptField.Add(ir, ptField.Mul(col[i], r[i] % Modulus));
+            ib = ptField.Add(ib, ptField.Mul(col[i], b[i]));
+        }
+        REQUIRE(ir == encR[qidx[qi]], "well-formedness R check failed for column %d", qidx[qi]);
+        REQUIRE(ib == encZ[qidx[qi]], "well-formedness B check failed for column %d", qidx[qi]);
+    }
+    uint64_t value = 0; // poly.Evaluate at z = 1
+    for (uint64_t m : matrix) value = ptField.Add(value, m);
+    uint64_t claim = 0;
+    for (int j = 0; j < cols; j++) claim = ptField.Add(claim, MatZ[j]); // a_j = z^j = 1
+    REQUIRE(claim == value, "claimed value does not match the evaluation of the committed polynomial");
+    printf("PASS TestLigeroE2E (host mirror): rows=%d cols=%d LogN=%d L=%d proof=%zu bytes\n", rows, cols, LogN, L,
+           marshaled.size());
+    lo_params_free(op);
+    return 0;
+}

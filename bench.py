@@ -10,10 +10,11 @@ limbs, rhoInv = 2, 309 queries).  It fits one GPU (about 75 GB of the 288 GB).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (strong scaling, fixed job): the transform along the ciphertext axis is
-replicated, the per-column work (rescale + leaf hashing; ct x pt + InnerSum +
-rescale; query gather) is sharded by column over the ranks, and the one data
-exchange is an RCCL all-gather of the 32-byte leaf digests for the Merkle tree.
+N > 1 (strong scaling, fixed job): every rank holds the input matrix; the passes of
+the ciphertext-axis transform that mix all ciphertexts are replicated, its final
+pass and all per-column work (rescale + leaf hashing; ct x pt + InnerSum + rescale;
+query gather) are sharded by column over the ranks, and the one data exchange is an
+RCCL all-gather of the 32-byte leaf digests for the Merkle tree.
 
 Rank 0 prints ONE JSON line (see the keys at the bottom of main()).
 """
@@ -108,27 +109,24 @@ class Job:
                 rand_limbs(P.q + P.p, (beta, 2, self.N)).transpose(1, 2, 0, 3))  # [beta][2][L+K][N]
             ctx.load_galois_key(g, evk)
         self.query_idx = rng.integers(0, self.S, size=self.queries).astype(np.uint32)
-        # column shards
-        self.enc_lo, self.enc_hi = self.S * rank // world, self.S * (rank + 1) // world
+        # column shards (input columns; encoded columns are sharded by the transform itself)
         self.col_lo, self.col_hi = self.cols * rank // world, self.cols * (rank + 1) // world
         ctx.sync()
 
     def step(self, dist=None):
         ctx = self.ctx
-        # ---- Commit: Encode (fhe/code.go:8-34)
-        enc = ctx.encode(self.matrix, self.zero_ct, RHO_INV)
+        # ---- Commit: Encode (fhe/code.go:8-34); with several ranks each keeps the encoded columns
+        # its share of the transform's final pass produces
+        if self.world > 1:
+            mine, my_cols = ctx.encode_shard(self.matrix, self.zero_ct, RHO_INV, self.rank, self.world)
+        else:
+            mine, my_cols = ctx.encode(self.matrix, self.zero_ct, RHO_INV), np.arange(self.S, dtype=np.uint32)
         # ---- Commit: leaves (fhe/ligero.go:126-183) on this rank's columns
-        mine = enc.slice(self.enc_lo, self.enc_hi - self.enc_lo)
         lvl1 = ctx.rescale(mine, 2)
         mine.free()
-        enc.free()
         dig = ctx.leaf_digests(lvl1)
         if dist is not None and self.world > 1:
-            import torch
-            t = torch.from_numpy(dig).cuda()
-            parts = [torch.empty_like(t) for _ in range(self.world)]
-            dist.all_gather(parts, t)  # the one exchange: S x 32 B of leaf digests over RCCL
-            dig = torch.cat(parts).cpu().numpy()
+            dig = all_gather_digests(dist, dig, my_cols, self.S, self.world)
         nodes, root = ctx.merkle_build(dig)  # core/tree.go:113-163
         # ---- Prove: <r, M> and <b, M> (fhe/ligero.go:231-242, 299-370) on this rank's columns
         cols = self.matrix.slice(self.col_lo, self.col_hi - self.col_lo)
@@ -136,12 +134,47 @@ class Job:
         mat_z = ctx.matrix_inner_sum(cols, self.b_pt, self.rows)
         cols.free()
         # ---- Prove: query columns (fhe/ligero.go:261-280): already at level 1 from Commit
-        own = self.query_idx[(self.query_idx >= self.enc_lo) & (self.query_idx < self.enc_hi)] - self.enc_lo
-        q = ctx.gather(lvl1, own.astype(np.uint32))
+        q = ctx.gather(lvl1, owned_queries(self.query_idx, my_cols))
         ctx.sync()
         for s in (q, mat_r, mat_z, lvl1):
             s.free()
         return root
+
+
+def owned_queries(query_idx, my_cols):
+    """Local positions (in this rank's ascending column list) of the queried columns it owns."""
+    pos = np.searchsorted(my_cols, query_idx)
+    pos = np.clip(pos, 0, len(my_cols) - 1)
+    own = my_cols[pos] == query_idx
+    return pos[own].astype(np.uint32)
+
+
+def all_gather_digests(dist, dig, my_cols, S, world):
+    """The one exchange of the multi-GPU path: S x 32 B of leaf digests (plus their column indices)
+    over RCCL; returns the digests of all S leaves in column order."""
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    cap = (S + world - 1) // world + 128  # shards differ by at most one group of <= 128 columns
+    buf = torch.zeros((cap, 36), dtype=torch.uint8)
+    n = len(my_cols)
+    buf[:n, :32] = torch.from_numpy(np.ascontiguousarray(dig))
+    buf[:n, 32:] = torch.from_numpy(np.ascontiguousarray(my_cols.astype("<u4")).view(np.uint8).reshape(n, 4))
+    cnt = torch.tensor([n], dtype=torch.int64)
+    buf, cnt = buf.to(dev), cnt.to(dev)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    cnts = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    dist.all_gather(cnts, cnt)
+    full = np.zeros((S, 32), dtype=np.uint8)
+    seen = 0
+    for p, c in zip(parts, cnts):
+        k = int(c.item())
+        a = p[:k].cpu().numpy()
+        idx = np.ascontiguousarray(a[:, 32:]).view("<u4").reshape(k)
+        full[idx] = a[:, :32]
+        seen += k
+    assert seen == S, f"digest shards cover {seen} of {S} leaves"
+    return full
 
 
 def cpu_baseline(cfg, budget_s=20.0):
@@ -210,6 +243,9 @@ def main():
     ap.add_argument("--config", default="16384x4096", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu rehearses the N>1 path on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -221,12 +257,14 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the lumenos HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group(args.dist_backend)  # "nccl" is RCCL on ROCm
 
     job = Job(args.config, rank, world, local_rank)
 
@@ -245,7 +283,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sec_per_step = elapsed / args.steps
@@ -288,7 +326,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"Encode+Commit+InnerProduct(r,b)+QueryCols {args.config} LogN={job.log_n} "
                                    f"L={job.L} K={job.K} rhoInv={RHO_INV} queries={job.queries}",
-                       "parallelism": f"columns sharded over {world} GPU(s); encode replicated",
+                       "parallelism": f"columns sharded over {world} GPU(s); digest all-gather",
                        "baseline_ref": "BASELINE.md: reference Go/Lattigo CPU, m7i.8xlarge 32 vCPU"},
             "limb_ntts_per_s": round(census / sec_per_step, 1),
             "ct_ntts_per_s": round(census / sec_per_step / (2 * job.L), 1),

@@ -98,6 +98,14 @@ int lumen_ct_ntt(lumen_ctx *ctx, lumen_set *values, uint32_t size);
 int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *zero_ct,
                  uint32_t rho_inv, lumen_set **encoded);
 
+/* ---- multi-GPU Commit: the same transform, of which rank `rank` of `world` keeps only the encoded
+ * columns its share of the final pass produces (every rank holds the whole input matrix; no exchange
+ * is needed before the leaf digests are all-gathered).  col_index: room for cols*rho_inv entries;
+ * receives the global indices (ascending) of the *n_cols columns returned in `encoded`. */
+int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *zero_ct,
+                       uint32_t rho_inv, uint32_t rank, uint32_t world, lumen_set **encoded,
+                       uint32_t *col_index, uint32_t *n_cols);
+
 /* ---- Evaluator.Rescale looped `for ct.Level() > target` (fhe/ligero.go:149-155,
  * 271-273, 331-333).  out is a new set with target_limbs limbs. */
 int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t target_limbs, lumen_set **out);

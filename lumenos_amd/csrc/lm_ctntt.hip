@@ -136,6 +136,7 @@ struct Plan {
     };
     std::vector<Dev> dev;
     uint32_t *d_out_pos = nullptr;
+    std::vector<std::vector<uint32_t>> final_groups; // slots of every group of the final pass
     ~Plan() {
         for (Dev &d : dev) {
             hipFree(d.d_slots);
@@ -313,6 +314,8 @@ int upload_plan(lumen_ctx *ctx, Plan *plan, uint32_t count) {
         if (!layer.empty()) LM_HIP(ctx, hipMemcpy(d.d_layer, layer.data(), layer.size() * 4, hipMemcpyHostToDevice));
         plan->dev.push_back(d);
     }
+    if (!plan->passes.empty())
+        for (Group &g : plan->passes.back().groups) plan->final_groups.push_back(g.slots);
     LM_HIP(ctx, hipMalloc((void **)&plan->d_out_pos, std::max<size_t>(count, 1) * 4));
     LM_HIP(ctx, hipMemcpy(plan->d_out_pos, plan->out_pos.data(), (size_t)count * 4, hipMemcpyHostToDevice));
     return 0;
@@ -346,6 +349,7 @@ struct ct_pass_args {
     const uint32_t *out_pos; // slot -> destination index, or NULL for identity
     const tw_t *scal;        // [nl_table][fieldN+1]
     uint32_t splitA, gsize, total, nlayers, fieldN1, logN, nl;
+    uint32_t group0; // first group of this launch (multi-GPU: a rank runs only its groups of the final pass)
     size_t ctw;
 };
 
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mo
     extern __shared__ __attribute__((aligned(16))) u64 buf[]; // [gsize][W]
     const uint32_t tid = threadIdx.x, l = tid % LM_CT_W, r = tid / LM_CT_W;
     constexpr uint32_t R = LM_CT_THREADS / LM_CT_W;
-    const uint32_t group = blockIdx.y;
+    const uint32_t group = blockIdx.y + a.group0;
     const size_t lane = (size_t)blockIdx.x * LM_CT_W + l;
     const uint32_t limb = (uint32_t)((lane >> a.logN) % a.nl);
     const u64 q = mods.m[limb].q;
@@ -394,8 +398,11 @@ __global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mo
     }
 }
 
+// final_g0/final_ng: groups of the final pass to run (all when final_ng == 0); final_pos: device
+// table slot -> output position for that pass (the plan's own permutation when NULL)
 static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, const u64 *srcA,
-                    uint32_t splitA, const u64 *srcB, u64 *tmp, u64 *out) {
+                    uint32_t splitA, const u64 *srcB, u64 *tmp, u64 *out, uint32_t final_g0 = 0,
+                    uint32_t final_ng = 0, const uint32_t *final_pos = nullptr) {
     const size_t ctw = (size_t)2 * nl * ctx->N;
     const uint32_t P = (uint32_t)plan->dev.size();
     LM_CHECK(ctx, ctw % LM_CT_W == 0, "ciphertext width not a multiple of the lane tile");
@@ -410,13 +417,15 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
         a.srcA = cur, a.srcB = curB, a.splitA = split;
         a.dst = final_pass ? out : tmp;
         a.slots = d.d_slots, a.ops = d.d_ops, a.layer = d.d_layer;
-        a.out_pos = final_pass ? plan->d_out_pos : nullptr;
+        a.out_pos = final_pass ? (final_pos ? final_pos : plan->d_out_pos) : nullptr;
+        a.group0 = final_pass && final_ng ? final_g0 : 0;
         a.scal = ctx->d_scal;
         a.gsize = d.gsize, a.total = d.total, a.nlayers = d.nlayers;
         a.fieldN1 = ctx->fieldN + 1, a.logN = ctx->logN, a.nl = nl, a.ctw = ctw;
-        dim3 grid((uint32_t)(ctw / LM_CT_W), d.ngroups);
+        const uint32_t ng = final_pass && final_ng ? final_ng : d.ngroups;
+        dim3 grid((uint32_t)(ctw / LM_CT_W), ng);
         size_t lds = (size_t)d.gsize * LM_CT_W * sizeof(u64);
-        lm_prof_scope ps(ctx, "ct_axis_pass", (uint64_t)d.ngroups * d.gsize);
+        lm_prof_scope ps(ctx, "ct_axis_pass", (uint64_t)ng * d.gsize);
         hipLaunchKernelGGL(k_ct_pass, grid, dim3(LM_CT_THREADS), lds, ctx->stream, a, ctx->mods);
         LM_HIP(ctx, hipGetLastError());
         cur = tmp, split = count, curB = nullptr;
@@ -524,6 +533,59 @@ extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint6
         }
         if (!rc) rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d);
     }
+    if (rc) {
+        lumen_set_destroy(ctx, out);
+        return rc;
+    }
+    *encoded = out;
+    return 0;
+}
+
+// Multi-GPU Commit: every rank runs the passes that mix all ciphertexts, but only its own
+// groups of the final pass -- each of which yields a fixed subset of the encoded columns.  The rank's
+// columns come back compacted, in ascending order of their global index (col_index).
+extern "C" int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *zero_ct,
+                                  uint32_t rho_inv, uint32_t rank, uint32_t world, lumen_set **encoded,
+                                  uint32_t *col_index, uint32_t *n_cols) {
+    LM_CHECK(nullptr, ctx && matrix && zero_ct && encoded && col_index && n_cols, "lumen_encode_shard: NULL argument");
+    LM_CHECK(ctx, world >= 1 && rank < world, "rank %u out of range for world %u", rank, world);
+    LM_CHECK(ctx, rho_inv >= 1, "rho_inv must be >= 1");
+    const uint32_t cols = matrix->count, S = cols * rho_inv, nl = matrix->nl;
+    LM_CHECK(ctx, cols > 0, "matrix is empty");
+    if (int rc = check_field(ctx, S)) return rc;
+    Plan *plan = nullptr;
+    if (int rc = get_plan(ctx, S, S, &plan)) return rc;
+    const uint32_t P = (uint32_t)plan->dev.size();
+    LM_CHECK(ctx, P >= 1, "sharded encode needs a transform of at least two ciphertexts");
+    const uint32_t G = (uint32_t)plan->final_groups.size();
+    const uint32_t g0 = (uint32_t)((uint64_t)G * rank / world), g1 = (uint32_t)((uint64_t)G * (rank + 1) / world);
+    // this rank's columns, ascending; slot -> local position
+    std::vector<std::pair<uint32_t, uint32_t>> own; // (global column, slot)
+    for (uint32_t g = g0; g < g1; g++)
+        for (uint32_t slot : plan->final_groups[g]) own.emplace_back(plan->out_pos[slot], slot);
+    std::sort(own.begin(), own.end());
+    std::vector<uint32_t> pos(S, LM_NOSLOT);
+    for (uint32_t i = 0; i < own.size(); i++) {
+        col_index[i] = own[i].first;
+        pos[own[i].second] = i;
+    }
+    *n_cols = (uint32_t)own.size();
+    const size_t ctw = (size_t)2 * nl * ctx->N;
+    u64 *dzero = (u64 *)lm_scratch(ctx, "zero_ct", ctw * sizeof(u64));
+    uint32_t *dpos = (uint32_t *)lm_scratch(ctx, "shard_pos", (size_t)S * 4);
+    if (!dzero || !dpos) return 1;
+    LM_HIP(ctx, hipMemcpyAsync(dzero, zero_ct, ctw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(ctx, hipMemcpyAsync(dpos, pos.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lumen_set *out = nullptr;
+    if (int rc = lumen_set_create(ctx, (uint32_t)own.size(), nl, &out)) return rc;
+    int rc = 0;
+    u64 *tmp = nullptr;
+    if (P >= 2) {
+        tmp = (u64 *)lm_scratch(ctx, "ct_tmp", (size_t)S * ctw * sizeof(u64));
+        if (!tmp) rc = 1;
+    }
+    if (!rc && g1 > g0) rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d, g0, g1 - g0, dpos);
     if (rc) {
         lumen_set_destroy(ctx, out);
         return rc;

@@ -57,6 +57,7 @@ SYMBOLS = {
     "lumen_field_set": (C.c_int, [_vp, _u64p, C.c_uint32]),
     "lumen_ct_ntt": (C.c_int, [_vp, _vp, C.c_uint32]),
     "lumen_encode": (C.c_int, [_vp, _vp, _u64p, C.c_uint32, _vpp]),
+    "lumen_encode_shard": (C.c_int, [_vp, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, _vpp, _u32p, _u32p]),
     "lumen_rescale": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
     "lumen_leaf_digests": (C.c_int, [_vp, _vp, _u8p]),
     "lumen_merkle_build": (C.c_int, [_vp, _u8p, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t), _u8p]),
@@ -216,6 +217,16 @@ class Context:
         h = C.c_void_p()
         self._ck(self.lib.lumen_encode(self.h, matrix.h, _p64(zero_ct), rho_inv, C.byref(h)))
         return DeviceSet(self, h)
+
+    def encode_shard(self, matrix, zero_ct, rho_inv, rank, world):
+        """-> (DeviceSet of this rank's encoded columns, their global indices, ascending)"""
+        zero_ct = np.ascontiguousarray(zero_ct, dtype=np.uint64)
+        idx = np.zeros(matrix.count * rho_inv, dtype=np.uint32)
+        n = C.c_uint32()
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_encode_shard(self.h, matrix.h, _p64(zero_ct), rho_inv, rank, world, C.byref(h),
+                                             idx.ctypes.data_as(_u32p), C.byref(n)))
+        return DeviceSet(self, h), idx[:n.value].copy()
 
     def rescale(self, s, target_limbs=2):
         h = C.c_void_p()

@@ -26,15 +26,14 @@ def _worker(rank, world, port, S, digests, queries, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = _shard(S, rank, world)
-    mine = torch.from_numpy(digests[lo:hi].copy())
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
-    full = torch.cat(parts).numpy()
+    import bench
+    # interleaved, uneven ownership like the transform's final-pass groups give
+    my_cols = np.array([c for c in range(S) if (c // 3) % world == rank], dtype=np.uint32)
+    full = bench.all_gather_digests(dist, digests[my_cols].copy(), my_cols, S, world)
     from oracle.loader import Oracle
     o = Oracle()
     _, root = o.merkle(full)
-    own = [int(q) for q in queries if lo <= q < hi]
+    own = [int(my_cols[p]) for p in bench.owned_queries(queries.astype(np.uint32), my_cols)]
     cnt = torch.tensor([len(own)])
     dist.all_reduce(cnt)
     out.put((rank, root, own, int(cnt.item())))

@@ -270,3 +270,26 @@ def test_full_size_matrix_inner_sum(oracle, full_d):
     assert np.array_equal(got, P.matrix_inner_sum(cts, pt, rows, evks))
     want = int(np.sum(col.astype(object) * (r.astype(object) % T_REF)) % T_REF)
     assert int(P.decrypt(sk, got[0], 1, P.rescale_scale(P.L, 2))[0]) == want
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_encode_shards_cover_full_encode(oracle, small, world):
+    """Multi-GPU Commit: the union of the per-rank shards (run one after the other on this one GPU)
+    is exactly fhe.Encode's output, each column owned once."""
+    P, ctx = small
+    cols, rho = 128, 2
+    S = cols * rho
+    roots = oracle.field_roots(T_REF, S)
+    ctx.field_set(roots)
+    m = random_cts(P, cols, 2, seed=77)
+    zero = random_cts(P, 1, 2, seed=78)[0]
+    dm = ctx.upload(m)
+    full = ctx.encode(dm, zero, rho).download()
+    assert np.array_equal(full, P.ct_encode(m, rho, zero, roots))
+    seen = np.zeros(S, dtype=int)
+    for rank in range(world):
+        shard, idx = ctx.encode_shard(dm, zero, rho, rank, world)
+        assert np.all(np.diff(idx.astype(np.int64)) > 0)
+        assert np.array_equal(shard.download(), full[idx])
+        seen[idx] += 1
+    assert np.all(seen == 1)

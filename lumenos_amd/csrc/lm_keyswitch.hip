@@ -20,11 +20,20 @@
 // k_moddown_ntt: the extended limb never exists in HBM in coefficient form);
 // the gadget product keeps key material in Montgomery form and accumulates
 // the beta products of a coefficient in 128 bits, one reduction per output.
+#include <cstdlib>
 #include <cstring>
 
 #include "lm_ntt_dev.h"
 
 #define LM_KS_BATCH 64 // columns processed together (scratch ~ 172 limbs per column)
+static uint32_t ks_batch() { // LUMEN_KS_BATCH overrides the default (tuning knob)
+    static const uint32_t v = [] {
+        const char *e = getenv("LUMEN_KS_BATCH");
+        const long x = e ? atol(e) : 0;
+        return (uint32_t)(x >= 1 && x <= 4096 ? x : LM_KS_BATCH);
+    }();
+    return v;
+}
 
 // constants of one basis extension (sources m_0..m_{ns-1} -> target t).
 // The source-side factors y_a = x_a * (M/m_a)^-1 mod m_a do not depend on the target: they are
@@ -168,15 +177,14 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
 // ---- steps 4+5: ModDown, add c0, automorphism, accumulate.  One workgroup per (column b,
 // poly w, Q limb t): the lift of the (coefficient-domain) P limbs into q_t is fused into the load,
 // the NTT runs in LDS, d = (u_t - lift) * P^-1 (+ c0 for w == 0) is formed in the last pass and
-// parked in LDS; after a barrier (every c0 has been read) the limb is added into acc through the
-// inverse automorphism table: acc[inv[p]] += d[p].  In the bit-reversed NTT domain the
-// automorphism maps aligned blocks of 2^k consecutive indices onto aligned blocks, so this
-// scatter touches exactly the cache lines a linear pass would.
+// parked in LDS; after a barrier the new accumulator limb is written linearly,
+// acc_out[j] = acc_in[j] + d[index[j]], the automorphism being a gather out of LDS.  (acc is
+// ping-ponged: an output needs the old accumulator at two positions, j and index[j].)
 template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 *__restrict__ u, const u64 *__restrict__ acc_in,
                                                      u64 *__restrict__ acc_out, const bx_t *__restrict__ bxp,
                                                      const tw_t *__restrict__ pinv,
-                                                     const uint32_t *__restrict__ inv_index, uint32_t B,
+                                                     const uint32_t *__restrict__ index, uint32_t B,
                                                      uint32_t L, uint32_t K, lm_mods mods,
                                                      const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
@@ -194,7 +202,6 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
     const u64 *ain = acc_in + ((size_t)pw * L + t) * N; // c0 (w == 0) / c1 (w == 1) limb of the accumulator
     u64 *aout = acc_out + ((size_t)pw * L + t) * N;
     const tw_t pi = pinv[t];
-    uint32_t part0 = 0; // first coefficient of the part of the transform currently parked in LDS
     auto ld = [&](uint32_t i) { return bx_apply(c, up0[i], up1[i], qc); };
     auto st = [&](uint32_t i0, const u64 *v, int count) {
         u64 uv[8], cv[8];
@@ -205,24 +212,22 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
             if (k < count) {
                 u64 x = lm_shoup_cs(lm_submod(uv[k], lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64), qc.q), pi, qc.q, qc.nq);
                 if (w == 0) x = lm_addmod(x, cv[k], qc.q);
-                sm[LM_PAD(i0 - part0 + k)] = x; // the slots this work item just consumed
+                sm[LM_PAD(i0 + k)] = x; // the slots this work item just consumed
             }
     };
-    // acc_out[inv[p]] = acc_in[inv[p]] + d[p] for the coefficients [i0, i0 + n) now parked in LDS
-    auto after = [&](uint32_t i0, uint32_t n) {
+    // acc_out[j] = acc_in[j] + d[index[j]]: the automorphism is applied as a gather out of LDS, so the
+    // accumulator itself streams through HBM linearly in 16-byte vectors
+    static_assert(!lm_fwd_is_split(LOGN), "the LDS gather needs the whole limb resident");
+    auto after = [&](uint32_t, uint32_t) {
         __syncthreads();
-        for (uint32_t p0 = tid; p0 < n; p0 += 8 * nthreads) {
-            uint32_t j[8];
-            u64 x[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) j[k] = p0 + k * nthreads < n ? inv_index[i0 + p0 + k * nthreads] : 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) x[k] = ain[j[k]];
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (p0 + k * nthreads < n) aout[j[k]] = lm_addmod(x[k], sm[LM_PAD(p0 + k * nthreads)], qc.q);
+        for (uint32_t j = 2 * tid; j < N; j += 2 * nthreads) {
+            const uint2 p = *reinterpret_cast<const uint2 *>(index + j);
+            const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(ain + j);
+            ulonglong2 y;
+            y.x = lm_addmod(x.x, sm[LM_PAD(p.x)], qc.q);
+            y.y = lm_addmod(x.y, sm[LM_PAD(p.y)], qc.q);
+            *reinterpret_cast<ulonglong2 *>(aout + j) = y;
         }
-        part0 = i0 + n; // the next part (if any) starts here
     };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st, after);
 }
@@ -396,7 +401,7 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
     case n:                                                                                                   \
         LM_LDS_ATTR(ctx, k_moddown_ntt<n>, lds);               \
         hipLaunchKernelGGL(k_moddown_ntt<n>, dim3(B * 2 * L), dim3(threads), lds, ctx->stream, s.u, acc,      \
-                           acc_out, tb->d_bxp, tb->d_pinv, gk.d_inv_index, B, L, K, ctx->mods,                \
+                           acc_out, tb->d_bxp, tb->d_pinv, gk.d_index, B, L, K, ctx->mods,                \
                            ctx->d_tw_fwd);                                                                    \
         break;
             LM_FOR_EACH_LOGN(LM_CASE)
@@ -543,7 +548,7 @@ extern "C" int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, 
     if (int rc = lumen_set_create(ctx, in->count, in->nl, &o)) return rc;
     if (in->words)
         LM_HIP(ctx, hipMemcpyAsync(o->d, in->d, in->words * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    const uint32_t Bmax = std::min<uint32_t>(LM_KS_BATCH, std::max(in->count, 1u));
+    const uint32_t Bmax = std::min<uint32_t>(ks_batch(), std::max(in->count, 1u));
     KsScratch s;
     if (get_scratch(ctx, Bmax, tb->beta, &s)) {
         lumen_set_destroy(ctx, o);
@@ -574,7 +579,7 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
     const uint32_t target = std::min<uint32_t>(2, L);
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, matrix->count, target, &o)) return rc;
-    const uint32_t Bmax = std::min<uint32_t>(LM_KS_BATCH, std::max(matrix->count, 1u));
+    const uint32_t Bmax = std::min<uint32_t>(ks_batch(), std::max(matrix->count, 1u));
     KsScratch s;
     const size_t ctw = (size_t)2 * L * N, octw = (size_t)2 * target * N;
     u64 *acc = (u64 *)lm_scratch(ctx, "ks_acc", (size_t)Bmax * ctw * 8);

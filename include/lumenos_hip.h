@@ -137,6 +137,17 @@ int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, const uint64
 int lumen_mul_plain(lumen_ctx *ctx, const lumen_set *in, const uint64_t *pt, lumen_set **out);
 int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, lumen_set **out);
 
+/* ---- fhe.RingSwitchServer (fhe/ring_switch.go:93-113): Evaluator.ApplyEvaluationKey of every
+ * ciphertext of `in` into the ring of degree 2^log_n_small with the single modulus q_0.
+ * key: rlwe.EvaluationKey of NewRingSwitchClient (ring_switch.go:43-56), only the entries level 0
+ * uses: host layout [digit(lumen_ringswitch_digits)][b|a][limb {q_0, p_0..p_{K-1}}][N], NTT domain,
+ * standard form; base_two_w = BaseTwoDecomposition (13).  out: host, [count][2][2^log_n_small]
+ * residues mod q_0 in the small ring's NTT domain. */
+uint32_t lumen_ringswitch_digits(const lumen_ctx *ctx, uint32_t base_two_w);
+int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, uint32_t base_two_w,
+                              const uint64_t *key);
+int lumen_ring_switch(lumen_ctx *ctx, const lumen_set *in, uint64_t *out);
+
 /* ---- query loop of Prove (fhe/ligero.go:268-279): gather ciphertexts idx[i]
  * of a set into a new set (duplicates allowed). */
 int lumen_gather(lumen_ctx *ctx, const lumen_set *src, const uint32_t *idx, uint32_t n,

@@ -169,6 +169,9 @@ struct lm_ninv_t;
 int lm_launch_ntt_strided(lumen_ctx *ctx, const u64 *src, size_t src_poly_stride, u64 *dst,
                           size_t dst_poly_stride, uint32_t npoly, const lm_modmap &map, bool inverse,
                           const char *prof_name, const lm_ninv_t *inv_scale = nullptr);
+int lm_launch_ntt_subring(lumen_ctx *ctx, uint32_t logn, const tw_t *tw, tw_t ninv_scale, const u64 *src,
+                          size_t src_poly_stride, u64 *dst, size_t dst_poly_stride, uint32_t npoly,
+                          uint32_t mod_idx, bool inverse);
 int lm_rescale_polys(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
                      uint32_t npoly, u64 *work, u64 *tbuf);
 lm_modmap lm_map_q(uint32_t nl);

@@ -23,7 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "lm_ntt_dev.h"
+#include "lm_ks_dev.h"
 
 #define LM_KS_BATCH 64 // columns processed together (scratch ~ 172 limbs per column)
 static uint32_t ks_batch() { // LUMEN_KS_BATCH overrides the default (tuning knob)
@@ -33,28 +33,6 @@ static uint32_t ks_batch() { // LUMEN_KS_BATCH overrides the default (tuning kno
         return (uint32_t)(x >= 1 && x <= 4096 ? x : LM_KS_BATCH);
     }();
     return v;
-}
-
-// constants of one basis extension (sources m_0..m_{ns-1} -> target t).
-// The source-side factors y_a = x_a * (M/m_a)^-1 mod m_a do not depend on the target: they are
-// produced once, fused into the N^-1 scaling of the INTT that brings the sources to the
-// coefficient domain, and the correction term v is packed into bit 63 of y_0 (k_pack_v).
-struct bx_t {
-    tw_t hat_mod_t[2]; // (M/m_a) mod t
-    u64 t_minus_m;     // t - (M mod t)
-    uint32_t ns;       // 1: plain reduction, 2: float-corrected reconstruction
-    uint32_t own;      // target limb belongs to the digit: no extension
-};
-#define LM_V_BIT 63
-
-// lazy value (< 7t) congruent to the extension of the digit to modulus t
-__device__ __forceinline__ u64 bx_apply(const bx_t &c, u64 y0v, u64 y1, const lm_qc &qc) {
-    if (c.ns == 1) return lm_shoup3<true>(y0v, 1ull, qc.qinv64, qc.nq); // x mod t, lazily
-    const u64 y0 = y0v & ~(1ull << LM_V_BIT);
-    u64 r = lm_shoup3<true>(y0, c.hat_mod_t[0].w, c.hat_mod_t[0].wp, qc.nq) +
-            lm_shoup3<true>(y1, c.hat_mod_t[1].w, c.hat_mod_t[1].wp, qc.nq); // < 6t
-    if (y0v >> LM_V_BIT) r += c.t_minus_m;                                     // - v*M (mod t)
-    return r;
 }
 
 // v = uint64(float64(y0)/float64(m0) + float64(y1)/float64(m1))  ([LATTIGO-RECALL] reconstructRNS).
@@ -322,6 +300,27 @@ int get_tables(lumen_ctx *ctx, KsTables **out) {
     *out = sp.get();
     return 0;
 }
+
+} // namespace
+
+int lm_ks_tables_view(lumen_ctx *ctx, lm_ks_view *out) {
+    KsTables *tb = nullptr;
+    if (int rc = get_tables(ctx, &tb)) return rc;
+    out->d_bxp = tb->d_bxp;
+    out->d_pinv = tb->d_pinv;
+    out->yscale = &tb->yscale;
+    return 0;
+}
+
+int lm_launch_pack_v(lumen_ctx *ctx, u64 *y, size_t poly_stride, uint32_t npoly, uint32_t ngroups,
+                     uint32_t group_limbs, uint32_t first_mod, uint32_t nlimbs_total) {
+    hipLaunchKernelGGL(k_pack_v, dim3(2048), dim3(256), 0, ctx->stream, y, poly_stride, npoly, ngroups, group_limbs,
+                       first_mod, nlimbs_total, ctx->logN, ctx->mods);
+    LM_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+namespace {
 
 struct KsScratch {
     u64 *coef, *ext, *u, *acc2;

@@ -49,6 +49,43 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_limb_ntt(const u64 *sr
     }
 }
 
+// Transform over a different ring degree (sub-ring of the ring switch): one modulus (mods index
+// map.idx[0]) with its own twiddle table `tw` of 2^logn entries.
+int lm_launch_ntt_subring(lumen_ctx *ctx, uint32_t logn, const tw_t *tw, tw_t ninv_scale, const u64 *src,
+                          size_t src_poly_stride, u64 *dst, size_t dst_poly_stride, uint32_t npoly,
+                          uint32_t mod_idx, bool inverse) {
+    if (!npoly) return 0;
+    lm_modmap map = lm_map_q(1);
+    map.idx[0] = 0; // the kernel adds mi * N to the table pointer: keep mi = 0 and pass the modulus in slot 0
+    lm_mods mods = ctx->mods;
+    mods.m[0] = ctx->mods.m[mod_idx];
+    lm_ninv_t ninv = lm_ninv_of(ctx);
+    ninv.t[0] = ninv_scale;
+    const size_t lds = inverse ? lm_inv_lds(logn) : lm_fwd_lds(logn);
+    const uint32_t threads = inverse ? lm_inv_threads(logn) : lm_fwd_threads(logn);
+    const dim3 grid(npoly), block(threads);
+#define LM_LAUNCH(n)                                                                                          \
+    case n:                                                                                                   \
+        if (inverse) {                                                                                        \
+            LM_LDS_ATTR(ctx, (k_limb_ntt<n, true>), lds);                                                     \
+            hipLaunchKernelGGL((k_limb_ntt<n, true>), grid, block, lds, ctx->stream, src, src_poly_stride,    \
+                               dst, dst_poly_stride, npoly, map, mods, ninv, tw);                             \
+        } else {                                                                                              \
+            LM_LDS_ATTR(ctx, (k_limb_ntt<n, false>), lds);                                                    \
+            hipLaunchKernelGGL((k_limb_ntt<n, false>), grid, block, lds, ctx->stream, src, src_poly_stride,   \
+                               dst, dst_poly_stride, npoly, map, mods, ninv, tw);                             \
+        }                                                                                                     \
+        break;
+    switch (logn) {
+        LM_FOR_EACH_LOGN(LM_LAUNCH)
+    default:
+        return lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", logn);
+    }
+#undef LM_LAUNCH
+    LM_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 // Transforms limbs [0, map.period) of `npoly` polynomials; polynomial p's limb
 // j is read at src + p*src_poly_stride + j*N and written at dst + p*dst_poly_stride + j*N
 // (src == dst allowed) with modulus map.idx[j].

@@ -1,0 +1,271 @@
+// fhe.RingSwitchServer.RingSwitchNew (fhe/ring_switch.go:93-113): Evaluator.ApplyEvaluationKey of a
+// level-1 ciphertext into a ring of smaller degree n = 2^logn with the single modulus q_0
+// [LATTIGO-RECALL]:
+//   1. work at min(level) = 0: only the q_0 residues of the input take part
+//   2. c1 -> coefficient domain; unsigned base-2^w digits (w = 13), each a small polynomial that is
+//      the same integer modulo q_0 and the special primes; NTT every digit on {q_0, p_0..}
+//   3. (u0,u1) = sum_j digit_j (.) evk_j on {q_0, P}; ModDown by P; add c0
+//   4. SwitchCiphertextRingDegreeNTT: coefficient domain, keep the coefficients of X^(i*N/n),
+//      NTT in the small ring (psi_small = psi_{q_0}^(N/n)).
+// Built from the same pieces as the Galois key switch (LDS-resident limb transform with fused
+// load/store stages, Montgomery-form keys with 128-bit accumulation, float-corrected P -> q lift).
+#include <cstring>
+
+#include "lm_ks_dev.h"
+
+namespace {
+
+struct RsKey {
+    u64 *d_key = nullptr; // [nd][2][1+K][N], Montgomery form
+    tw_t *d_tw_small = nullptr, *d_tw_small_inv = nullptr;
+    uint32_t nd = 0, w = 0, logn = 0;
+    tw_t ninv_small;
+    ~RsKey() {
+        hipFree(d_key);
+        hipFree(d_tw_small);
+        hipFree(d_tw_small_inv);
+    }
+};
+
+} // namespace
+
+// digit j of c (coefficient domain, mod q_0) -> NTT on modulus t (0 = q_0, 1.. = P limbs)
+template <int LOGN>
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rs_digit_ntt(const u64 *__restrict__ coef,
+                                                                       u64 *__restrict__ ext, uint32_t B,
+                                                                       uint32_t nd, uint32_t nt, uint32_t L,
+                                                                       uint32_t w, lm_mods mods,
+                                                                       const tw_t *__restrict__ tw_all) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm[];
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t r = blockIdx.x;
+    const uint32_t b = r % B;
+    r /= B;
+    const uint32_t j = r % nd, t = r / nd;
+    const uint32_t mi = t == 0 ? 0 : L + (t - 1);
+    const lm_qc qc = lm_make_qc(mods.m[mi]);
+    const u64 *c = coef + (size_t)b * N;
+    u64 *o = ext + (((size_t)b * nd + j) * nt + t) * N;
+    const u64 mask = (1ull << w) - 1;
+    const uint32_t sh = w * j;
+    auto ld = [&](uint32_t i) { return (c[i] >> sh) & mask; };
+    auto st = [&](uint32_t i0, const u64 *v, int count) {
+        u64 rr[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < count) rr[k] = lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64);
+        lm_store_run(o, i0, rr, count);
+    };
+    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)mi * N, qc, tid, nthreads, ld, st);
+}
+
+// u[b][pw][t][i] = sum_j ext[b][j][t][i] * key[j][pw][t][i]
+__global__ __launch_bounds__(256) void k_rs_mac(const u64 *__restrict__ ext, const u64 *__restrict__ key,
+                                                u64 *__restrict__ u, uint32_t B, uint32_t nd, uint32_t nt,
+                                                uint32_t L, uint32_t logN, lm_mods mods) {
+    const uint32_t N = 1u << logN;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y, b = blockIdx.z;
+    if (i >= N || b >= B) return;
+    const mod_t md = mods.m[t == 0 ? 0 : L + (t - 1)];
+    u128 a0 = 0, a1 = 0;
+    for (uint32_t j = 0; j < nd; j++) {
+        const u64 x = ext[(((size_t)b * nd + j) * nt + t) * N + i];
+        a0 += (u128)x * key[(((size_t)j * 2 + 0) * nt + t) * N + i];
+        a1 += (u128)x * key[(((size_t)j * 2 + 1) * nt + t) * N + i];
+    }
+    u64 *o = u + ((size_t)b * 2 * nt + t) * N + i;
+    o[0] = lm_mont_reduce((u64)a0, (u64)(a0 >> 64), md.q, md.qneg);
+    o[(size_t)nt * N] = lm_mont_reduce((u64)a1, (u64)(a1 >> 64), md.q, md.qneg);
+}
+
+// ModDown on q_0 only: lift of the P limbs fused into the load, NTT, (u - lift) * P^-1 (+ c0)
+template <int LOGN>
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rs_moddown(const u64 *__restrict__ u,
+                                                                     const u64 *__restrict__ in, size_t in_ctw,
+                                                                     u64 *__restrict__ big,
+                                                                     const bx_t *__restrict__ bxp,
+                                                                     const tw_t *__restrict__ pinv, uint32_t nt,
+                                                                     uint32_t K, lm_mods mods,
+                                                                     const tw_t *__restrict__ tw_all) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm[];
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    const uint32_t pw = blockIdx.x, w = pw & 1, b = pw >> 1;
+    const bx_t c = bxp[0];
+    const lm_qc qc = lm_make_qc(mods.m[0]);
+    const u64 *uq = u + (size_t)pw * nt * N;
+    const u64 *up0 = uq + N, *up1 = K == 2 ? up0 + N : up0;
+    const u64 *c0 = in + (size_t)b * in_ctw; // poly 0, limb 0 of the input ciphertext
+    u64 *o = big + (size_t)pw * N;
+    const tw_t pi = pinv[0];
+    auto ld = [&](uint32_t i) { return bx_apply(c, up0[i], up1[i], qc); };
+    auto st = [&](uint32_t i0, const u64 *v, int count) {
+        u64 uv[8], cv[8], rr[8];
+        lm_load_run(uq, i0, uv, count);
+        if (w == 0) lm_load_run(c0, i0, cv, count);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < count) {
+                u64 x = lm_shoup_cs(lm_submod(uv[k], lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64), qc.q), pi, qc.q, qc.nq);
+                if (w == 0) x = lm_addmod(x, cv[k], qc.q);
+                rr[k] = x;
+            }
+        lm_store_run(o, i0, rr, count);
+    };
+    lm_ntt_forward<LOGN>(sm, tw_all, qc, tid, nthreads, ld, st);
+}
+
+// small[p][i] = big[p][i * gap]
+__global__ void k_rs_project(const u64 *__restrict__ big, u64 *__restrict__ small, uint32_t npoly, uint32_t logN,
+                             uint32_t logn) {
+    const uint32_t n = 1u << logn, gap = 1u << (logN - logn);
+    const size_t total = (size_t)npoly << logn, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t p = g >> logn;
+        const uint32_t i = (uint32_t)(g & (n - 1));
+        small[g] = big[(p << logN) + (size_t)i * gap];
+    }
+}
+
+extern "C" uint32_t lumen_ringswitch_digits(const lumen_ctx *ctx, uint32_t base_two_w) {
+    if (!ctx || !base_two_w) return 0;
+    uint32_t bits = 0;
+    while (bits < 64 && (ctx->mod[0] >> bits)) bits++;
+    return (bits + base_two_w - 1) / base_two_w;
+}
+
+extern "C" int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, uint32_t base_two_w,
+                                         const uint64_t *key) {
+    LM_CHECK(nullptr, ctx && key, "lumen_load_ringswitch_key: NULL argument");
+    LM_CHECK(ctx, ctx->K >= 1 && ctx->K <= 2, "ring switch needs 1 or 2 special primes");
+    LM_CHECK(ctx, log_n_small <= ctx->logN && lm_logn_supported(log_n_small),
+             "target ring degree 2^%u is not supported (need <= 2^%u and one of the instantiated sizes)",
+             log_n_small, ctx->logN);
+    LM_CHECK(ctx, base_two_w >= 1 && base_two_w <= 32, "BaseTwoDecomposition %u out of range", base_two_w);
+    const uint32_t N = ctx->N, K = ctx->K, nt = 1 + K, L = ctx->L;
+    const uint32_t nd = lumen_ringswitch_digits(ctx, base_two_w);
+    auto sp = std::make_shared<RsKey>();
+    sp->nd = nd, sp->w = base_two_w, sp->logn = log_n_small;
+    const size_t words = (size_t)nd * 2 * nt * N;
+    std::vector<u64> mont(words);
+    for (uint32_t j = 0; j < nd; j++)
+        for (uint32_t pw = 0; pw < 2; pw++)
+            for (uint32_t t = 0; t < nt; t++) {
+                const uint64_t q = ctx->mod[t == 0 ? 0 : L + (t - 1)];
+                const uint64_t r = (uint64_t)((((u128)1) << 64) % q);
+                const size_t off = (((size_t)j * 2 + pw) * nt + t) * N;
+                for (uint32_t k = 0; k < N; k++) {
+                    if (key[off + k] >= q) return lm_fail(ctx, "ring-switch key residue out of range (digit %u limb %u)", j, t);
+                    mont[off + k] = h_mulmod(key[off + k], r, q);
+                }
+            }
+    LM_HIP(ctx, hipMalloc((void **)&sp->d_key, words * 8));
+    LM_HIP(ctx, hipMemcpy(sp->d_key, mont.data(), words * 8, hipMemcpyHostToDevice));
+    // small ring tables on q_0: psi_small = psi^(N/n)
+    const uint32_t n = 1u << log_n_small;
+    const uint64_t q0 = ctx->mod[0], psi = h_powmod(ctx->psi[0], N / n, q0), psi_inv = h_invmod(psi, q0);
+    std::vector<tw_t> f(n), b(n);
+    uint64_t cf = 1, cb = 1;
+    for (uint32_t jdx = 0; jdx < n; jdx++) {
+        const uint32_t rr = h_bitrev(jdx, (int)log_n_small);
+        f[rr] = h_tw(cf, q0), b[rr] = h_tw(cb, q0);
+        cf = h_mulmod(cf, psi, q0), cb = h_mulmod(cb, psi_inv, q0);
+    }
+    LM_HIP(ctx, hipMalloc((void **)&sp->d_tw_small, n * sizeof(tw_t)));
+    LM_HIP(ctx, hipMalloc((void **)&sp->d_tw_small_inv, n * sizeof(tw_t)));
+    LM_HIP(ctx, hipMemcpy(sp->d_tw_small, f.data(), n * sizeof(tw_t), hipMemcpyHostToDevice));
+    LM_HIP(ctx, hipMemcpy(sp->d_tw_small_inv, b.data(), n * sizeof(tw_t), hipMemcpyHostToDevice));
+    sp->ninv_small = h_tw(h_invmod(n % q0, q0), q0);
+    ctx->ext["ringswitch_key"] = sp;
+    return 0;
+}
+
+template <int LOGN>
+static int ring_switch_batch(lumen_ctx *ctx, RsKey *rk, const lm_ks_view &kv, const u64 *in, size_t in_ctw,
+                             uint32_t nl, uint32_t B, u64 *coef, u64 *ext, u64 *u, u64 *big, u64 *small) {
+    const uint32_t N = ctx->N, K = ctx->K, nt = 1 + K, L = ctx->L, nd = rk->nd;
+    const size_t lds = lm_fwd_lds(ctx->logN);
+    const uint32_t threads = lm_fwd_threads(ctx->logN);
+    // 1. c1 (limb 0) -> coefficient domain
+    if (int rc = lm_launch_ntt_strided(ctx, in + (size_t)nl * N, in_ctw, coef, N, B, lm_map_q(1), true, "rs_intt_c1"))
+        return rc;
+    // 2. digits + NTT
+    {
+        lm_prof_scope ps(ctx, "rs_digit_ntt", (uint64_t)B * nd * nt);
+        LM_LDS_ATTR(ctx, k_rs_digit_ntt<LOGN>, lds);
+        hipLaunchKernelGGL(k_rs_digit_ntt<LOGN>, dim3(B * nd * nt), dim3(threads), lds, ctx->stream, coef, ext, B, nd,
+                           nt, L, rk->w, ctx->mods, ctx->d_tw_fwd);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    // 3. gadget product
+    {
+        lm_prof_scope ps(ctx, "rs_mac", (uint64_t)B);
+        hipLaunchKernelGGL(k_rs_mac, dim3((N + 255) / 256, nt, B), dim3(256), 0, ctx->stream, ext, rk->d_key, u, B, nd,
+                           nt, L, ctx->logN, ctx->mods);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    // 4. P limbs -> coefficient domain with the source-side lift factors, correction bit
+    {
+        lm_modmap mp;
+        mp.period = K;
+        for (uint32_t i = 0; i < LM_MAX_LIMBS; i++) mp.idx[i] = (uint8_t)(L + (i < K ? i : 0));
+        if (int rc = lm_launch_ntt_strided(ctx, u + N, (size_t)nt * N, u + N, (size_t)nt * N, B * 2, mp, true,
+                                           "rs_intt_p", kv.yscale))
+            return rc;
+        if (K == 2)
+            if (int rc = lm_launch_pack_v(ctx, u + N, (size_t)nt * N, B * 2, 1u, K, L, K)) return rc;
+    }
+    // 5. ModDown, add c0 -> level-0 ciphertext of the big ring under the embedded small key
+    {
+        lm_prof_scope ps(ctx, "rs_moddown", (uint64_t)B * 2);
+        LM_LDS_ATTR(ctx, k_rs_moddown<LOGN>, lds);
+        hipLaunchKernelGGL(k_rs_moddown<LOGN>, dim3(B * 2), dim3(threads), lds, ctx->stream, u, in, in_ctw, big,
+                           kv.d_bxp, kv.d_pinv, nt, K, ctx->mods, ctx->d_tw_fwd);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    // 6. SwitchCiphertextRingDegreeNTT
+    if (int rc = lm_launch_ntt_strided(ctx, big, N, big, N, B * 2, lm_map_q(1), true, "rs_intt_big")) return rc;
+    hipLaunchKernelGGL(k_rs_project, dim3(1024), dim3(256), 0, ctx->stream, big, small, B * 2, ctx->logN, rk->logn);
+    LM_HIP(ctx, hipGetLastError());
+    const size_t n = (size_t)1 << rk->logn;
+    return lm_launch_ntt_subring(ctx, rk->logn, rk->d_tw_small, rk->ninv_small, small, n, small, n, B * 2, 0, false);
+}
+
+extern "C" int lumen_ring_switch(lumen_ctx *ctx, const lumen_set *in, uint64_t *out) {
+    LM_CHECK(nullptr, ctx && in && out, "lumen_ring_switch: NULL argument");
+    auto it = ctx->ext.find("ringswitch_key");
+    LM_CHECK(ctx, it != ctx->ext.end(), "no ring-switch key loaded (lumen_load_ringswitch_key)");
+    RsKey *rk = static_cast<RsKey *>(it->second.get());
+    lm_ks_view kv;
+    if (int rc = lm_ks_tables_view(ctx, &kv)) return rc;
+    const uint32_t N = ctx->N, K = ctx->K, nt = 1 + K, nd = rk->nd, nl = in->nl;
+    const size_t n = (size_t)1 << rk->logn, in_ctw = (size_t)2 * nl * N;
+    const uint32_t Bmax = std::min<uint32_t>(256, std::max(in->count, 1u));
+    u64 *coef = (u64 *)lm_scratch(ctx, "rs_coef", (size_t)Bmax * N * 8);
+    u64 *ext = (u64 *)lm_scratch(ctx, "rs_ext", (size_t)Bmax * nd * nt * N * 8);
+    u64 *u = (u64 *)lm_scratch(ctx, "rs_u", (size_t)Bmax * 2 * nt * N * 8);
+    u64 *big = (u64 *)lm_scratch(ctx, "rs_big", (size_t)Bmax * 2 * N * 8);
+    u64 *small = (u64 *)lm_scratch(ctx, "rs_small", (size_t)Bmax * 2 * n * 8);
+    if (!coef || !ext || !u || !big || !small) return 1;
+    for (uint32_t first = 0; first < in->count; first += Bmax) {
+        const uint32_t B = std::min(Bmax, in->count - first);
+        int rc = 1;
+        switch (ctx->logN) {
+#define LM_CASE(nn)                                                                                          \
+    case nn:                                                                                                 \
+        rc = ring_switch_batch<nn>(ctx, rk, kv, in->d + (size_t)first * in_ctw, in_ctw, nl, B, coef, ext, u, big, \
+                                   small);                                                                   \
+        break;
+            LM_FOR_EACH_LOGN(LM_CASE)
+#undef LM_CASE
+        default:
+            return lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
+        }
+        if (rc) return rc;
+        LM_HIP(ctx, hipMemcpyAsync(out + (size_t)first * 2 * n, small, (size_t)B * 2 * n * 8, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}

@@ -67,6 +67,9 @@ SYMBOLS = {
     "lumen_mul_plain": (C.c_int, [_vp, _vp, _u64p, _vpp]),
     "lumen_inner_sum": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
     "lumen_gather": (C.c_int, [_vp, _vp, _u32p, C.c_uint32, _vpp]),
+    "lumen_ringswitch_digits": (C.c_uint32, [_vp, C.c_uint32]),
+    "lumen_load_ringswitch_key": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _u64p]),
+    "lumen_ring_switch": (C.c_int, [_vp, _vp, _u64p]),
     "lumen_timer_start": (C.c_int, [_vp]),
     "lumen_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "lumen_prof_enable": (C.c_int, [_vp, C.c_int]),
@@ -280,6 +283,16 @@ class Context:
         h = C.c_void_p()
         self._ck(self.lib.lumen_gather(self.h, s.h, idx.ctypes.data_as(_u32p), len(idx), C.byref(h)))
         return DeviceSet(self, h)
+
+    def load_ringswitch_key(self, log_n_small, key, w=13):
+        key = np.ascontiguousarray(key, dtype=np.uint64)
+        self._ck(self.lib.lumen_load_ringswitch_key(self.h, log_n_small, w, _p64(key)))
+        self._rs_logn = log_n_small
+
+    def ring_switch(self, s):
+        out = np.zeros((s.count, 2, 1 << self._rs_logn), dtype=np.uint64)
+        self._ck(self.lib.lumen_ring_switch(self.h, s.h, _p64(out)))
+        return out
 
     def mul_counter(self):
         return int(self.lib.lumen_mul_counter(self.h))

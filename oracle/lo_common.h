@@ -217,6 +217,27 @@ int lo_decrypt_decode(const lo_params *p, const uint64_t *sk, const uint64_t *ct
  * prod q_dropped^-1 mod T */
 uint64_t lo_rescale_scale(const lo_params *p, uint32_t nl_from, uint32_t nl_to);
 
+/* --------------------------------------------------------------- ring switch */
+/* fhe/ring_switch.go:16-57,93-113 [LATTIGO-RECALL]: key-switch sk -> skNew (a secret of the ring of
+ * degree n = 2^logn_small, embedded as skNew(X^(N/n))) with a base-2^w gadget (w = 13), at level 0
+ * (only q_0), then projection onto the sub-ring: keep the coefficients of X^(i*N/n).
+ * Key layout: [npw2][b|a][limb {q_0, p_0..p_{K-1}}][N], NTT domain, standard form,
+ * npw2 = ceil(bits(q_0)/w).  Output: [2][n] residues mod q_0, NTT domain of the small ring
+ * (psi_small = psi_{q_0}^(N/n)). */
+uint32_t lo_rs_num_digits(const lo_params *p, uint32_t w);
+size_t lo_rs_key_words(const lo_params *p, uint32_t w);
+void lo_keygen_secret_small(const lo_params *p, lo_rng *r, uint32_t logn_small, int64_t *sk_small_coeffs);
+void lo_keygen_ringswitch(const lo_params *p, lo_rng *r, const uint64_t *sk, const int64_t *sk_small_coeffs,
+                          uint32_t logn_small, uint32_t w, uint64_t *key);
+/* ct: [2][nl][N] (nl >= 1; only limb 0 is used, as ApplyEvaluationKey works at min(level) = 0) */
+void lo_ring_switch(const lo_params *p, const uint64_t *ct, uint32_t nl, const uint64_t *key, uint32_t w,
+                    uint32_t logn_small, uint64_t *out);
+/* coefficient-domain plaintext (mod T, after the *T of decryption) of a small-ring ciphertext and of a
+ * big-ring one (limb 0 only), for the sub-ring property test */
+void lo_decrypt_small_coeffs(const lo_params *p, const int64_t *sk_small_coeffs, uint32_t logn_small,
+                             const uint64_t *ct_small, uint64_t *m);
+void lo_decrypt_big_coeffs_l0(const lo_params *p, const uint64_t *sk, const uint64_t *ct, uint32_t nl, uint64_t *m);
+
 /* ---------------------------------------------------------------- ligero glue */
 /* calculateQueries (fhe/ligero.go:65-71) */
 int lo_calculate_queries(double security_bits, int rho_inv);

@@ -105,6 +105,13 @@ class Oracle:
             "lo_decrypt_phase": (None, [vp, u64p, u64p, C.c_uint32, u64p]),
             "lo_decode_coeffs": (None, [vp, u64p, C.c_uint64, u64p, C.c_uint32]),
             "lo_decrypt_decode": (C.c_int, [vp, u64p, u64p, C.c_uint32, C.c_uint64, u64p, C.c_uint32]),
+            "lo_rs_num_digits": (C.c_uint32, [vp, C.c_uint32]),
+            "lo_rs_key_words": (C.c_size_t, [vp, C.c_uint32]),
+            "lo_keygen_secret_small": (None, [vp, vp, C.c_uint32, C.POINTER(C.c_int64)]),
+            "lo_keygen_ringswitch": (None, [vp, vp, u64p, C.POINTER(C.c_int64), C.c_uint32, C.c_uint32, u64p]),
+            "lo_ring_switch": (None, [vp, u64p, C.c_uint32, u64p, C.c_uint32, C.c_uint32, u64p]),
+            "lo_decrypt_small_coeffs": (None, [vp, C.POINTER(C.c_int64), C.c_uint32, u64p, u64p]),
+            "lo_decrypt_big_coeffs_l0": (None, [vp, u64p, u64p, C.c_uint32, u64p]),
             "lo_calculate_queries": (C.c_int, [C.c_double, C.c_int]),
             "lo_ct_serialized_size": (C.c_size_t, [C.c_uint32, C.c_uint32]),
             "lo_ct_serialize": (None, [u64p, C.c_uint32, C.c_uint32, u8p]),
@@ -387,6 +394,40 @@ class Params:
         half = Q // 2
         m = np.array([int(((y - Q) if y > half else y) % self.T) for y in acc], dtype=np.uint64)
         return self.decode_coeffs(m, scale, nvalues)
+
+    # ring switch (fhe/ring_switch.go)
+    def rs_num_digits(self, w=13):
+        return int(self.o.lib.lo_rs_num_digits(self.h, w))
+
+    def keygen_secret_small(self, logn_small):
+        c = np.zeros(1 << logn_small, dtype=np.int64)
+        self.o.lib.lo_keygen_secret_small(self.h, self._r(), logn_small, c.ctypes.data_as(C.POINTER(C.c_int64)))
+        return c
+
+    def keygen_ringswitch(self, sk, sk_small, logn_small, w=13):
+        key = np.zeros((self.rs_num_digits(w), 2, 1 + self.K, self.N), dtype=np.uint64)
+        self.o.lib.lo_keygen_ringswitch(self.h, self._r(), _p64(sk), sk_small.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        logn_small, w, _p64(key))
+        return key
+
+    def ring_switch(self, ct, key, logn_small, w=13):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        out = np.zeros((2, 1 << logn_small), dtype=np.uint64)
+        self.o.lib.lo_ring_switch(self.h, _p64(ct), ct.shape[1], _p64(key), w, logn_small, _p64(out))
+        return out
+
+    def decrypt_small_coeffs(self, sk_small, logn_small, ct_small):
+        ct_small = np.ascontiguousarray(ct_small, dtype=np.uint64)
+        m = np.zeros(1 << logn_small, dtype=np.uint64)
+        self.o.lib.lo_decrypt_small_coeffs(self.h, sk_small.ctypes.data_as(C.POINTER(C.c_int64)), logn_small,
+                                           _p64(ct_small), _p64(m))
+        return m
+
+    def decrypt_big_coeffs_l0(self, sk, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        m = np.zeros(self.N, dtype=np.uint64)
+        self.o.lib.lo_decrypt_big_coeffs_l0(self.h, _p64(sk), _p64(ct), ct.shape[1], _p64(m))
+        return m
 
     def commit_leaves(self, encoded):
         encoded = np.ascontiguousarray(encoded, dtype=np.uint64)

@@ -293,3 +293,30 @@ def test_encode_shards_cover_full_encode(oracle, small, world):
         assert np.array_equal(shard.download(), full[idx])
         seen[idx] += 1
     assert np.all(seen == 1)
+
+
+@pytest.mark.parametrize("log_n,logn_small", [(10, 10), (12, 10), (12, 8), (14, 10)])
+def test_ring_switch_matches_oracle(oracle, log_n, logn_small):
+    """RingSwitchNew (fhe/ring_switch.go:106-113): bit-exact vs the oracle, and the sub-ring contract:
+    the small-ring ciphertext decrypts (under skNew) to the coefficients X^(i*N/n) of the input's
+    plaintext.  T as in TestRingSwitch (ring_switch_test.go:17): with T ~ 2^57 a single 58-bit limb
+    leaves no room for noise."""
+    T = 0x3EE0001
+    P = make_params(oracle, log_n, 3, T=T)
+    P.seed(log_n * 100 + logn_small)
+    sk, ctx = P.keygen_secret(), make_context(P)
+    pk = P.keygen_public(sk)
+    rng = np.random.default_rng(9)
+    cts = np.stack([P.rescale_to_level1(P.encrypt(pk, P.encode(rng.integers(0, T, size=P.N, dtype=np.uint64))))
+                    for _ in range(3)])
+    sk_small = P.keygen_secret_small(logn_small)
+    key = P.keygen_ringswitch(sk, sk_small, logn_small)
+    assert ctx.lib.lumen_ringswitch_digits(ctx.h, 13) == P.rs_num_digits() == 5
+    ctx.load_ringswitch_key(logn_small, key)
+    got = ctx.ring_switch(ctx.upload(cts))
+    gap = P.N >> logn_small
+    for c in range(3):
+        assert np.array_equal(got[c], P.ring_switch(cts[c], key, logn_small)), c
+        assert np.array_equal(P.decrypt_small_coeffs(sk_small, logn_small, got[c]),
+                              P.decrypt_big_coeffs_l0(sk, cts[c])[::gap])
+    ctx.close()

@@ -144,3 +144,24 @@ def test_golden_evaluator(oracle):
     assert [int(x) for x in g["gal_els"]] == P.inner_sum_galois_elements(int(g["rows"]))
     got = P.matrix_inner_sum(g["cts"], g["pt"], int(g["rows"]), list(g["evks"]))
     assert np.array_equal(got, g["matrix_inner_sum"])
+
+
+@pytest.mark.parametrize("logn_small", [10, 8])
+def test_ring_switch_on_oracle(oracle, logn_small):
+    """TestRingSwitch (fhe/ring_switch_test.go:13-77): same-degree switch decrypts to the same slots;
+    smaller degree keeps the coefficients of X^(i*N/n) (SwitchCiphertextRingDegreeNTT)."""
+    T = 0x3EE0001  # ring_switch_test.go:17
+    P = make_params(oracle, 10, 3, T=T)
+    P.seed(77)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    vals = np.zeros(P.N, dtype=np.uint64)
+    vals[:2] = 1  # m := []uint64{1, 1}
+    ct = P.rescale_to_level1(P.encrypt(pk, P.encode(vals)))
+    sk_small = P.keygen_secret_small(logn_small)
+    key = P.keygen_ringswitch(sk, sk_small, logn_small)
+    small = P.ring_switch(ct, key, logn_small)
+    m = P.decrypt_small_coeffs(sk_small, logn_small, small)
+    assert np.array_equal(m, P.decrypt_big_coeffs_l0(sk, ct)[::P.N >> logn_small])
+    if logn_small == 10:
+        assert np.array_equal(P.decode_coeffs(m, P.rescale_scale(P.L, 2), 2), vals[:2])

@@ -79,7 +79,7 @@ def pmc_traffic(kernel, cfg):
 class Job:
     """Device-resident inputs of one prover run + the step function."""
 
-    def __init__(self, cfg, rank, world, device):
+    def __init__(self, cfg, rank, world, device, ring_switch_logn=0):
         from lumenos_amd.hip import Context
         self.rows, self.cols, self.log_n = CONFIGS[cfg]
         self.rank, self.world = rank, world
@@ -109,6 +109,11 @@ class Job:
                 rand_limbs(P.q + P.p, (beta, 2, self.N)).transpose(1, 2, 0, 3))  # [beta][2][L+K][N]
             ctx.load_galois_key(g, evk)
         self.query_idx = rng.integers(0, self.S, size=self.queries).astype(np.uint32)
+        self.ring_switch_logn = ring_switch_logn
+        if ring_switch_logn:
+            nd = ctx.lib.lumen_ringswitch_digits(ctx.h, 13)
+            key = np.ascontiguousarray(rand_limbs(P.q[:1] + P.p, (nd, 2, self.N)).transpose(1, 2, 0, 3))
+            ctx.load_ringswitch_key(ring_switch_logn, key)
         # column shards (input columns; encoded columns are sharded by the transform itself)
         self.col_lo, self.col_hi = self.cols * rank // world, self.cols * (rank + 1) // world
         ctx.sync()
@@ -133,6 +138,9 @@ class Job:
         mat_r = ctx.matrix_inner_sum(cols, self.r_pt, self.rows)
         mat_z = ctx.matrix_inner_sum(cols, self.b_pt, self.rows)
         cols.free()
+        if self.ring_switch_logn:  # ligero.go:336-342: RingSwitchNew on every inner-product output
+            ctx.ring_switch(mat_r)
+            ctx.ring_switch(mat_z)
         # ---- Prove: query columns (fhe/ligero.go:261-280): already at level 1 from Commit
         q = ctx.gather(lvl1, owned_queries(self.query_idx, my_cols))
         ctx.sync()
@@ -246,6 +254,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal only)")
+    ap.add_argument("--ring-switch-logn", type=int, default=0,
+                    help="BASELINE config 5: ring-switch MatR/MatZ to this ring degree (fhe/ring_switch.go)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -266,7 +276,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.dist_backend)  # "nccl" is RCCL on ROCm
 
-    job = Job(args.config, rank, world, local_rank)
+    job = Job(args.config, rank, world, local_rank, args.ring_switch_logn)
 
     def barrier():
         if dist is not None:
@@ -325,7 +335,8 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"Encode+Commit+InnerProduct(r,b)+QueryCols {args.config} LogN={job.log_n} "
-                                   f"L={job.L} K={job.K} rhoInv={RHO_INV} queries={job.queries}",
+                                   f"L={job.L} K={job.K} rhoInv={RHO_INV} queries={job.queries}"
+                                   + (f" +ring-switch->LogN={args.ring_switch_logn}" if args.ring_switch_logn else ""),
                        "parallelism": f"columns sharded over {world} GPU(s); digest all-gather",
                        "baseline_ref": "BASELINE.md: reference Go/Lattigo CPU, m7i.8xlarge 32 vCPU"},
             "limb_ntts_per_s": round(census / sec_per_step, 1),

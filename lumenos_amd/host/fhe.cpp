@@ -255,6 +255,21 @@ std::vector<uint64_t> ServerBFV::EncryptNew(const Plaintext &pt) {
     return ct;
 }
 
+// ------------------------------------------------------------------ ring switch
+RingSwitchServer::RingSwitchServer(ServerBFV &backend, const std::vector<uint64_t> &ringSwitchEvk, int logN,
+                                   int baseTwoDecomposition)
+    : logN_(logN) {
+    backend.check(lumen_load_ringswitch_key(backend.Context(), (uint32_t)logN, (uint32_t)baseTwoDecomposition,
+                                            ringSwitchEvk.data()),
+                  "lumen_load_ringswitch_key");
+}
+
+std::vector<uint64_t> RingSwitchServer::RingSwitchNew(const Ciphertexts &cts, ServerBFV &backend) const {
+    std::vector<uint64_t> out((size_t)cts.Len() * 2 * ((size_t)1 << logN_));
+    if (cts.Len()) backend.check(lumen_ring_switch(backend.Context(), cts.Handle(), out.data()), "lumen_ring_switch");
+    return out;
+}
+
 // ------------------------------------------------------------------ Encode / NTT
 Ciphertexts Encode(const Ciphertexts &matrix, int rows, int rhoInv, ServerBFV &backend) {
     // code.go:15-22: one fresh encryption of the zero vector, copied into every padding column

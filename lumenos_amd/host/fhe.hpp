@@ -50,6 +50,7 @@ struct Plaintext { // *rlwe.Plaintext: one polynomial, NTT domain, [level+1][N]
 };
 
 class ServerBFV;
+class RingSwitchServer;
 
 // []*rlwe.Ciphertext resident in HBM
 class Ciphertexts {
@@ -89,6 +90,8 @@ class ServerBFV {
     // Encryptor.EncryptNew(pt) under pk, host layout [2][L][N]
     std::vector<uint64_t> EncryptNew(const Plaintext &pt);
     void check(int rc, const char *what) const; // throws std::runtime_error with lumen_last_error
+    void SetRingSwitchServer(RingSwitchServer *rs) { rs_ = rs; } // bfv.go:48-50
+    RingSwitchServer *RingSwitch() const { return rs_; }          // bfv.go:52-54
 
   private:
     core::PrimeField *ptField_;
@@ -98,6 +101,22 @@ class ServerBFV {
     std::mt19937_64 rng_;
     uint64_t psiT_ = 0;
     std::vector<uint32_t> slot_index_;
+    RingSwitchServer *rs_ = nullptr;
+};
+
+// fhe.RingSwitchServer (fhe/ring_switch.go:93-113)
+class RingSwitchServer {
+  public:
+    // NewRingSwitchServer(ringSwitchEvk, paramsLit): paramsLit.LogN is the target degree, its single
+    // modulus is q_0 (ring_switch.go:30-38); the key arrives in the layout of lumen_load_ringswitch_key
+    RingSwitchServer(ServerBFV &backend, const std::vector<uint64_t> &ringSwitchEvk, int logN,
+                     int baseTwoDecomposition = 13);
+    // RingSwitchNew for every ciphertext of the slice: host result [len][2][2^logN] (level 0, small ring)
+    std::vector<uint64_t> RingSwitchNew(const Ciphertexts &cts, ServerBFV &backend) const;
+    int LogN() const { return logN_; }
+
+  private:
+    int logN_;
 };
 
 // fhe.Encode (fhe/code.go:8-34)

@@ -102,11 +102,13 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
     const u64 *s0 = coef + ((size_t)b * L + d * K) * N;
     const u64 *s1 = c.ns == 2 ? s0 + N : s0; // second limb of the digit
     auto ld = [&](uint32_t i) { return bx_apply(c, s0[i], s1[i], qc); };
+    // the extended digit is left in [0, 3q): beta * 3q * q < q * 2^64, so the gadget product's
+    // 128-bit accumulation and its single Montgomery reduction still hold
     auto st = [&](uint32_t i0, const u64 *v, int count) {
         u64 rr[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (k < count) rr[k] = lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64);
+            if (k < count) rr[k] = lm_shoup3<true>(v[k], 1ull, qc.qinv64, qc.nq);
         lm_store_run(o, i0, rr, count);
     };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_limb_ntt(const u64 *sr
     if (INV) {
         const tw_t ni = ninv.t[mi];
         auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
-        auto st = [&](uint32_t i, u64 v) { o[i] = lm_shoup(v, ni, c.q); };
+        auto st = [&](uint32_t i, u64 v) { o[i] = lm_shoup_cs(v, ni, c.q, c.nq); };
         lm_ntt_inverse<LOGN>(sm, tw, c, tid, nthreads, ld, st);
     } else {
         auto ld = [&](uint32_t i) { return p[i]; };

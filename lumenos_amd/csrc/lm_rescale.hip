@@ -35,7 +35,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rescale_last(const u64
     const u64 *p = src + (size_t)blockIdx.x * src_poly_stride + (size_t)last * N;
     u64 *o = tbuf + (size_t)blockIdx.x * N;
     auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
-    auto st = [&](uint32_t i, u64 v) { o[i] = lm_addmod(lm_shoup(v, ninv, c.q), half, c.q); };
+    auto st = [&](uint32_t i, u64 v) { o[i] = lm_addmod(lm_shoup_cs(v, ninv, c.q, c.nq), half, c.q); };
     lm_ntt_inverse<LOGN>(sm, tw, c, tid, nthreads, ld, st);
 }
 
@@ -54,13 +54,13 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rescale_limb(const u64
     const u64 *t = tbuf + (size_t)poly * N;
     const u64 *cin = src + (size_t)poly * src_poly_stride + (size_t)limb * N;
     u64 *o = dst + (size_t)poly * dst_poly_stride + (size_t)limb * N;
-    auto ld = [&](uint32_t i) { return lm_submod(lm_reduce(t[i], c.q, c.qinv64), hm, c.q); };
+    auto ld = [&](uint32_t i) { return lm_submod(lm_reduce_s(t[i], c.q, c.nq, c.qinv64), hm, c.q); };
     auto st = [&](uint32_t i0, const u64 *v, int count) {
         u64 cv[8], r[8];
         lm_load_run(cin, i0, cv, count);
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (k < count) r[k] = lm_shoup(lm_submod(cv[k], lm_reduce_s(v[k], c.q, c.nq, c.qinv64), c.q), qlinv, c.q);
+            if (k < count) r[k] = lm_shoup_cs(lm_submod(cv[k], lm_reduce_s(v[k], c.q, c.nq, c.qinv64), c.q), qlinv, c.q, c.nq);
         lm_store_run(o, i0, r, count);
     };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)limb * N, c, tid, nthreads, ld, st);

@@ -581,25 +581,32 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, matrix->count, target, &o)) return rc;
     const uint32_t Bmax = std::min<uint32_t>(ks_batch(), std::max(matrix->count, 1u));
+    // the rescale to level 1 runs on groups of batches: one batch alone (2*B polynomials) does not
+    // fill the 256 CUs in the kernels that take one workgroup per polynomial
+    const uint32_t group = std::min<uint32_t>(8 * Bmax, std::max(matrix->count, 1u));
     KsScratch s;
     const size_t ctw = (size_t)2 * L * N, octw = (size_t)2 * target * N;
-    u64 *acc = (u64 *)lm_scratch(ctx, "ks_acc", (size_t)Bmax * ctw * 8);
-    u64 *work = (u64 *)lm_scratch(ctx, "rescale_work", (size_t)Bmax * ctw * 8);
-    u64 *tbuf = (u64 *)lm_scratch(ctx, "rescale_t", (size_t)Bmax * 2 * N * 8);
+    u64 *acc = (u64 *)lm_scratch(ctx, "ks_acc", (size_t)group * ctw * 8);
+    u64 *work = (u64 *)lm_scratch(ctx, "rescale_work", (size_t)group * ctw * 8);
+    u64 *tbuf = (u64 *)lm_scratch(ctx, "rescale_t", (size_t)group * 2 * N * 8);
     if (get_scratch(ctx, Bmax, tb->beta, &s) || !acc || !work || !tbuf) {
         lumen_set_destroy(ctx, o);
         return 1;
     }
     int rc = 0;
-    for (uint32_t first = 0; first < matrix->count && !rc; first += Bmax) {
-        const uint32_t B = std::min(Bmax, matrix->count - first);
-        rc = launch_mul_plain(ctx, matrix->d + (size_t)first * ctw, acc, ptT, (size_t)B * ctw, L, B); // ligero.go:319
-        if (!rc) rc = inner_sum_batch(ctx, acc, B, rows, tb, s);                                       // ligero.go:325
-        if (!rc) {                                                                                     // ligero.go:331-333
+    for (uint32_t g0 = 0; g0 < matrix->count && !rc; g0 += group) {
+        const uint32_t gn = std::min(group, matrix->count - g0);
+        for (uint32_t first = 0; first < gn && !rc; first += Bmax) {
+            const uint32_t B = std::min(Bmax, gn - first);
+            u64 *a = acc + (size_t)first * ctw;
+            rc = launch_mul_plain(ctx, matrix->d + (size_t)(g0 + first) * ctw, a, ptT, (size_t)B * ctw, L, B); // ligero.go:319
+            if (!rc) rc = inner_sum_batch(ctx, a, B, rows, tb, s);                                              // ligero.go:325
+        }
+        if (!rc) { // ligero.go:331-333
             if (L > target)
-                rc = lm_rescale_polys(ctx, acc, L, o->d + (size_t)first * octw, target, B * 2, work, tbuf);
+                rc = lm_rescale_polys(ctx, acc, L, o->d + (size_t)g0 * octw, target, gn * 2, work, tbuf);
             else
-                rc = hipMemcpyAsync(o->d + (size_t)first * octw, acc, (size_t)B * ctw * 8, hipMemcpyDeviceToDevice,
+                rc = hipMemcpyAsync(o->d + (size_t)g0 * octw, acc, (size_t)gn * ctw * 8, hipMemcpyDeviceToDevice,
                                     ctx->stream) != hipSuccess;
         }
     }

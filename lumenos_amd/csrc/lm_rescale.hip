@@ -138,6 +138,7 @@ extern "C" int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t targe
     }
     // chunk so that the full-stride work buffer stays <= ~2 GiB
     uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)2 << 30) / (in_ctw * sizeof(u64)));
+    if (chunk >= 128) chunk -= chunk % 128; // 2*chunk polynomials = whole rounds of 256 workgroups
     chunk = std::min(chunk, std::max(in->count, 1u));
     u64 *work = nullptr;
     if (nl - target_limbs > 1) {

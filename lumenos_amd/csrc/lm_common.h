@@ -50,7 +50,9 @@ struct lumen_set {
 
 struct lumen_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // where every entry point enqueues (may be swapped to stream2 internally)
+    hipStream_t stream2 = nullptr; // second lane for independent column batches (key-switch pipeline)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t logN = 0, N = 0, L = 0, K = 0;
     uint64_t T = 0;
     uint64_t mod[LM_MAX_LIMBS] = {0};

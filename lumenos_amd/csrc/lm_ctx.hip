@@ -120,6 +120,9 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
     ctx->device = desc->device;
     LM_HIP(ctx, hipSetDevice(ctx->device));
     LM_HIP(ctx, hipStreamCreate(&ctx->stream));
+    LM_HIP(ctx, hipStreamCreate(&ctx->stream2));
+    LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     ctx->logN = desc->log_n;
     ctx->N = 1u << desc->log_n;
     ctx->L = desc->num_q;
@@ -189,6 +192,9 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
     hipEventDestroy(ctx->tm0);
     hipEventDestroy(ctx->tm1);
+    hipEventDestroy(ctx->ev_fork);
+    hipEventDestroy(ctx->ev_join);
+    hipStreamDestroy(ctx->stream2);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -197,7 +197,6 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
     };
     // acc_out[j] = acc_in[j] + d[index[j]]: the automorphism is applied as a gather out of LDS, so the
     // accumulator itself streams through HBM linearly in 16-byte vectors
-    static_assert(!lm_fwd_is_split(LOGN), "the LDS gather needs the whole limb resident");
     auto after = [&](uint32_t, uint32_t) {
         __syncthreads();
         for (uint32_t j = 2 * tid; j < N; j += 2 * nthreads) {
@@ -328,14 +327,34 @@ struct KsScratch {
     u64 *coef, *ext, *u, *acc2;
 };
 
-int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s) {
+int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s, int lane = 0) {
     const size_t N = ctx->N, L = ctx->L, LK = ctx->L + ctx->K;
-    s->coef = (u64 *)lm_scratch(ctx, "ks_coef", (size_t)B * L * N * 8);
-    s->ext = (u64 *)lm_scratch(ctx, "ks_ext", (size_t)B * beta * LK * N * 8);
-    s->u = (u64 *)lm_scratch(ctx, "ks_u", (size_t)B * 2 * LK * N * 8);
-    s->acc2 = (u64 *)lm_scratch(ctx, "ks_acc2", (size_t)B * 2 * L * N * 8);
+    const char *names[2][4] = {{"ks_coef", "ks_ext", "ks_u", "ks_acc2"}, {"ks_coef_b", "ks_ext_b", "ks_u_b", "ks_acc2_b"}};
+    s->coef = (u64 *)lm_scratch(ctx, names[lane][0], (size_t)B * L * N * 8);
+    s->ext = (u64 *)lm_scratch(ctx, names[lane][1], (size_t)B * beta * LK * N * 8);
+    s->u = (u64 *)lm_scratch(ctx, names[lane][2], (size_t)B * 2 * LK * N * 8);
+    s->acc2 = (u64 *)lm_scratch(ctx, names[lane][3], (size_t)B * 2 * L * N * 8);
     return (s->coef && s->ext && s->u && s->acc2) ? 0 : 1;
 }
+
+// Enqueue on the context's second stream for the lifetime of the guard.  Independent column
+// batches alternate between the two streams so that the HBM-bound steps of one batch (gadget
+// product, correction-bit pass) overlap the VALU-bound transforms of the other.
+static uint32_t ks_lanes() {
+    static const uint32_t n = [] {
+        const char *e = getenv("LUMEN_KS_LANES");
+        return (e && atoi(e) == 1) ? 1u : 2u;
+    }();
+    return n;
+}
+struct LaneGuard {
+    lumen_ctx *ctx;
+    hipStream_t saved;
+    LaneGuard(lumen_ctx *c, int lane) : ctx(c), saved(c->stream) {
+        if (lane) ctx->stream = ctx->stream2;
+    }
+    ~LaneGuard() { ctx->stream = saved; }
+};
 
 // acc, acc_out: [B][2][L][N] at top level; acc_out = acc + Rot_galEl(acc) for every column
 int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, const lm_galois_key &gk,
@@ -584,24 +603,33 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
     // the rescale to level 1 runs on groups of batches: one batch alone (2*B polynomials) does not
     // fill the 256 CUs in the kernels that take one workgroup per polynomial
     const uint32_t group = std::min<uint32_t>(8 * Bmax, std::max(matrix->count, 1u));
-    KsScratch s;
+    KsScratch s[2];
     const size_t ctw = (size_t)2 * L * N, octw = (size_t)2 * target * N;
     u64 *acc = (u64 *)lm_scratch(ctx, "ks_acc", (size_t)group * ctw * 8);
     u64 *work = (u64 *)lm_scratch(ctx, "rescale_work", (size_t)group * ctw * 8);
     u64 *tbuf = (u64 *)lm_scratch(ctx, "rescale_t", (size_t)group * 2 * N * 8);
-    if (get_scratch(ctx, Bmax, tb->beta, &s) || !acc || !work || !tbuf) {
+    if (get_scratch(ctx, Bmax, tb->beta, &s[0], 0) || get_scratch(ctx, Bmax, tb->beta, &s[1], 1) || !acc || !work ||
+        !tbuf) {
         lumen_set_destroy(ctx, o);
         return 1;
     }
     int rc = 0;
     for (uint32_t g0 = 0; g0 < matrix->count && !rc; g0 += group) {
         const uint32_t gn = std::min(group, matrix->count - g0);
-        for (uint32_t first = 0; first < gn && !rc; first += Bmax) {
+        // fork: the second lane starts after everything already enqueued on the main stream
+        LM_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        LM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        uint32_t lane = 0;
+        for (uint32_t first = 0; first < gn && !rc; first += Bmax, lane = (lane + 1) % ks_lanes()) {
             const uint32_t B = std::min(Bmax, gn - first);
             u64 *a = acc + (size_t)first * ctw;
+            LaneGuard guard(ctx, (int)lane);
             rc = launch_mul_plain(ctx, matrix->d + (size_t)(g0 + first) * ctw, a, ptT, (size_t)B * ctw, L, B); // ligero.go:319
-            if (!rc) rc = inner_sum_batch(ctx, a, B, rows, tb, s);                                              // ligero.go:325
+            if (!rc) rc = inner_sum_batch(ctx, a, B, rows, tb, s[lane]);                                        // ligero.go:325
         }
+        // join: the rescale of the group needs both lanes
+        LM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        LM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         if (!rc) { // ligero.go:331-333
             if (L > target)
                 rc = lm_rescale_polys(ctx, acc, L, o->d + (size_t)g0 * octw, target, gn * 2, work, tbuf);

@@ -1,41 +1,62 @@
 // LDS-resident limb NTT building blocks for gfx950 (design notes: lm_ntt.hip).
 //
-// v2 structure: a transform is a list of passes of R <= 3 butterfly stages.
-// A work item keeps 2^R coefficients in VGPRs for the R stages of a pass.
-//   * the FIRST pass reads its coefficients straight from global memory
-//     through a caller-supplied loader (which fuses e.g. an RNS basis extension
-//     or a modular reduction into the load) and leaves them in LDS;
-//   * middle passes go LDS -> LDS;
-//   * the LAST pass hands runs of finished coefficients to a caller-supplied
-//     storer (which fuses the final reduction and e.g. the rescale combine)
-//     that writes global memory.  So coefficients cross LDS P-1 times, not P+1.
-// Multiplications by twiddles are Shoup multiplications written as explicit
-// v_mad_u64_u32 chains (4.9 cycles per wave-op on MI355X against 8-10 for
-// v_mul_lo/hi_u32, profiles/r01_ubench_int_valu.txt), with the quotient
-// estimate truncated to three partial products: the result is in [0, 3q).
-// Twiddles of stages whose block index is wave-uniform are fetched with scalar
-// loads.
+// v3 structure.  A transform of N = 2^logN coefficients runs in one workgroup of NT = N/16 threads
+// (64 <= NT <= 1024), i.e. NW = NT/64 waves, 16 coefficients per lane, as a list of passes of
+// R <= 4 butterfly stages; a work item keeps 2^R coefficients in VGPRs for the R stages of a pass.
+//   * The CROSS-WAVE pass does log2(NW) stages (the ones whose butterflies span more than N/NW
+//     coefficients): it is the first pass of the forward transform, which reads its coefficients
+//     straight from global memory through a caller-supplied loader (fusing e.g. an RNS basis
+//     extension into the load), and the last pass of the inverse.
+//   * Every other stage only touches one block of N/NW = 1024 consecutive coefficients, and each
+//     block is owned by ONE wave for the rest of the transform: work items are dealt so that wave j
+//     handles block j in every pass.  Those passes exchange coefficients through LDS without
+//     workgroup barriers (a wave's LDS operations execute in order), so a transform has ONE
+//     s_barrier instead of one per pass and the waves of a CU drift apart -- which is what keeps
+//     the VALU fed: a single wave can issue a VALU instruction only every ~8 cycles
+//     (profiles/r01_ubench_mad_latency.txt), so each SIMD needs two of its four waves runnable.
+//   * The forward transform's last pass hands runs of 8 finished coefficients to a
+//     caller-supplied storer (final reduction, rescale combine, ... fused) that writes global memory.
+// Multiplications by twiddles are Shoup multiplications written as explicit v_mad_u64_u32 chains
+// with the quotient estimate truncated to three partial products: the result is in [0, 3q).
+// Twiddles of stages whose block index is wave-uniform are fetched with scalar loads.
 #pragma once
 #include <cstring>
 
 #include "lm_common.h"
 
-#define LM_PAD(i) ((i) + ((i) >> 5))
+// LDS layout: one pad slot per 8 coefficients.  Conflict-free for the three access shapes of the
+// passes (64 consecutive coefficients; 8 runs of 8 coefficients 64 apart; one run of 8 per lane).
+#define LM_PAD(i) ((i) + ((i) >> 3))
 #define LM_MAX_PASSES 8
 
 struct lm_ninv_t {
     tw_t t[LM_MAX_LIMBS];
 };
 
-// Pass plan of a 2^logN transform, known at compile time (kernels are instantiated per ring
-// degree): as many radix-8 passes as possible, the remainder spread as radix-4 passes, big first.
-__host__ __device__ constexpr int lm_npasses(int logN) { return (logN + 2) / 3; }
+__host__ __device__ constexpr int lm_ilog2(int x) { return x <= 1 ? 0 : 1 + lm_ilog2(x >> 1); }
+// launch geometry: 16 coefficients per lane, at least one wave, at most 1024 threads
+__host__ __device__ constexpr int lm_nthreads(int logN) {
+    return (1 << logN) / 16 < 64 ? 64 : ((1 << logN) / 16 > 1024 ? 1024 : (1 << logN) / 16);
+}
+__host__ __device__ constexpr int lm_max_threads(int logN) { return lm_nthreads(logN); }
+__host__ __device__ constexpr int lm_log_epl(int logN) { return logN - lm_ilog2(lm_nthreads(logN)); } // log2 coefficients per lane
+__host__ __device__ constexpr int lm_cross_r(int logN) { return lm_ilog2(lm_nthreads(logN) / 64); }   // stages of the cross-wave pass
+// Pass plan in forward order: [cross-wave pass,] then the wave-local stages in as few passes of
+// at most log2(coefficients per lane) stages as possible, bigger passes first (14 -> 4 | 4 3 3).
+__host__ __device__ constexpr int lm_local_passes(int logN) {
+    return (logN - lm_cross_r(logN) + lm_log_epl(logN) - 1) / lm_log_epl(logN);
+}
+__host__ __device__ constexpr int lm_npasses(int logN) { return (lm_cross_r(logN) > 0 ? 1 : 0) + lm_local_passes(logN); }
 __host__ __device__ constexpr int lm_pass_r(int logN, int i) {
-    int n = lm_npasses(logN), rem = logN, r = 0;
+    const int ra = lm_cross_r(logN);
+    if (ra > 0) {
+        if (i == 0) return ra;
+        i--;
+    }
+    int n = lm_local_passes(logN), rem = logN - ra, r = 0;
     for (int k = 0; k <= i; k++) {
         const int left = n - k;
         r = (rem + left - 1) / left;
-        if (r > 3) r = 3;
         rem -= r;
     }
     return r;
@@ -49,33 +70,10 @@ static inline bool lm_logn_supported(uint32_t logN) {
     return false;
 }
 
-// Launch geometry.  A transform whose N coefficients fit in half a CU's LDS keeps them all there;
-// the forward transform of N = 2^14 (132 KiB padded) instead runs its first stage out of registers
-// and then its two independent halves one after the other in a half-size buffer, so that two
-// workgroups (different limbs) share a CU and cover each other's barriers and memory phases.
-// Measured on MI355X at N = 2^14 (profiles/r01_split_experiment.txt): two 512-thread workgroups per
-// CU running sequential halves reach 7.1 M limb-NTT/s against 8.2 M/s for one 1024-thread workgroup
-// with the whole limb in LDS -- the kernel is VALU-bound (~80 % VALU-busy), so the extra barriers and
-// the parked half cost more than the overlap returns.  The split path is kept but disabled.
-#define LM_SPLIT_LOGN 99 // forward transforms of this size and above run as sequential halves
-#define LM_SPLIT_NT 512
-__host__ __device__ constexpr bool lm_fwd_is_split(int logN) { return logN >= LM_SPLIT_LOGN; }
-// N <= 2^13: 512-thread workgroups so that two (or more) fit a CU by LDS and VGPRs;
-// N = 2^14: the limb fills the LDS of a CU, one 1024-thread workgroup uses all 16 waves.
-#define LM_BIG_LOGN 14
-__host__ __device__ constexpr int lm_max_threads(int logN) { return logN >= LM_BIG_LOGN ? 1024 : 512; }
-static inline uint32_t lm_fwd_threads(uint32_t logN) {
-    const uint32_t t = (1u << logN) / 8, cap = lm_fwd_is_split((int)logN) ? LM_SPLIT_NT : lm_max_threads((int)logN);
-    return t > cap ? cap : (t < 64 ? 64 : t);
-}
-static inline uint32_t lm_inv_threads(uint32_t logN) {
-    const uint32_t t = (1u << logN) / 8, cap = lm_max_threads((int)logN);
-    return t > cap ? cap : (t < 64 ? 64 : t);
-}
-static inline size_t lm_lds_for(uint32_t n) { return (size_t)(n + (n >> 5) + 2) * sizeof(u64); }
-static inline size_t lm_fwd_lds(uint32_t logN) {
-    return lm_lds_for(lm_fwd_is_split((int)logN) ? (1u << (logN - 1)) : (1u << logN));
-}
+static inline uint32_t lm_fwd_threads(uint32_t logN) { return (uint32_t)lm_nthreads((int)logN); }
+static inline uint32_t lm_inv_threads(uint32_t logN) { return (uint32_t)lm_nthreads((int)logN); }
+static inline size_t lm_lds_for(uint32_t n) { return (size_t)(n + (n >> 3) + 2) * sizeof(u64); }
+static inline size_t lm_fwd_lds(uint32_t logN) { return lm_lds_for(1u << logN); }
 static inline size_t lm_inv_lds(uint32_t logN) { return lm_lds_for(1u << logN); }
 static inline lm_ninv_t lm_ninv_of(const lumen_ctx *ctx) {
     lm_ninv_t n;
@@ -98,21 +96,95 @@ __device__ __forceinline__ u64 lm_keep(u64 x) {
 // t ~ floor(a*wp / 2^64) from three partial products (the a0*wp0 term and its
 // carry are dropped: t is exact or one short), then r = a*w + t*nq mod 2^64.
 // UW documents that the twiddle (w, wp) is wave-uniform (it then lives in SGPRs).
+// x is an optional addend: the result is x + a*w (lazily reduced a*w) mod 2^64, for free, because
+// the first multiply-add of the low chain has an empty addend slot.
+//
+// The compiler's rendering of this chain costs ~19 instructions: every time the HIGH word of one
+// product feeds the next multiply-add it copies that word into a zero-extended, 64-bit-aligned
+// register pair (gfx950 only takes even-aligned VGPR tuples) and then adds pairs.  LM_ASM_SHOUP
+// writes the chain by hand on fixed temporaries v[80:89]: 10 multiply-adds and 2 adds.
+//   * "x += zext(hi word)" is itself a multiply-add by the inline constant 1 (the word is read as a
+//     32-bit source, so its alignment does not matter);
+//   * S = a1*p0 + m1 is a 65-bit sum: its carry-out (an SGPR pair) is added to the upper word of t;
+//   * the upper result word only matters mod 2^32, so it is accumulated apart (4 multiply-adds),
+//     added into the upper word of lo' = a0*w0 + x, and the last multiply-add t0*n0 + {lo', upper}
+//     writes the result.
+// gfx950 needs two wait states between a VALU write of an SGPR (the carry) and a VALU read of it:
+// three independent instructions sit in between.
+#ifndef LM_ASM_SHOUP
+#define LM_ASM_SHOUP 1
+#endif
+#define LM_SHOUP_CLOBBERS "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "s96", "s97", "s98", "s99"
+#define LM_SHOUP_BODY(ADDEND)                                                                                   \
+    "v_mad_u64_u32 v[80:81], s[96:97], %[a0], %[p1], 0\n\t"          /* m1 = a0*p1               */           \
+    "v_mad_u64_u32 v[82:83], s[98:99], %[a1], %[p0], v[80:81]\n\t"   /* S, carry -> s[98:99]     */           \
+    "v_mad_u64_u32 v[84:85], s[96:97], %[a1], %[p1], 0\n\t"          /* t = a1*p1                */           \
+    "v_mad_u64_u32 v[86:87], s[96:97], %[a0], %[w0], " ADDEND "\n\t"  /* lo' = a0*w0 + x          */           \
+    "v_mad_u64_u32 v[84:85], s[96:97], v83, 1, v[84:85]\n\t"         /* t += hi(S)               */           \
+    "v_mad_u64_u32 v[88:89], s[96:97], %[a0], %[w1], 0\n\t"          /* up = a0*w1               */           \
+    "v_addc_co_u32_e64 v85, s[96:97], v85, 0, s[98:99]\n\t"          /* t += carry << 32         */           \
+    "v_mad_u64_u32 v[88:89], s[96:97], %[a1], %[w0], v[88:89]\n\t"   /* up += a1*w0              */           \
+    "v_mad_u64_u32 v[88:89], s[96:97], v84, %[n1], v[88:89]\n\t"     /* up += t0*n1              */           \
+    "v_mad_u64_u32 v[88:89], s[96:97], v85, %[n0], v[88:89]\n\t"     /* up += t1*n0              */           \
+    "v_add_u32 v87, v87, v88\n\t"                                    /* hi(lo') += up            */           \
+    "v_mad_u64_u32 %[o], s[96:97], v84, %[n0], v[86:87]"              /* {lo', upper} + t0*n0     */
+
 template <bool UW>
-__device__ __forceinline__ u64 lm_shoup3(u64 a, u64 w, u64 wp, u64 nq) {
+__device__ __forceinline__ u64 lm_shoup3(u64 a, u64 w, u64 wp, u64 nq, u64 x) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
     const u32 w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+#if LM_ASM_SHOUP
+    u64 o;
+    if (UW)
+        asm(LM_SHOUP_BODY("%[x]")
+            : [o] "=v"(o)
+            : [a0] "v"(a0), [a1] "v"(a1), [p0] "s"(p0), [p1] "s"(p1), [w0] "s"(w0), [w1] "s"(w1), [n0] "s"(n0),
+              [n1] "s"(n1), [x] "v"(x)
+            : LM_SHOUP_CLOBBERS);
+    else
+        asm(LM_SHOUP_BODY("%[x]")
+            : [o] "=v"(o)
+            : [a0] "v"(a0), [a1] "v"(a1), [p0] "v"(p0), [p1] "v"(p1), [w0] "v"(w0), [w1] "v"(w1), [n0] "s"(n0),
+              [n1] "s"(n1), [x] "v"(x)
+            : LM_SHOUP_CLOBBERS);
+    return o;
+#else
     const u64 m1 = (u64)a0 * p1;
     const u64 m2 = lm_keep((u64)a1 * p0 + (u32)m1);
     const u64 t = (u64)a1 * p1 + (m1 >> 32) + (m2 >> 32);
     const u32 t0 = (u32)t, t1 = (u32)(t >> 32);
-    const u64 lo = (u64)a0 * w0 + (u64)t0 * n0;
+    // everything below is arithmetic mod 2^64: partial sums may wrap
+    const u64 lo = lm_keep((u64)a0 * w0 + x) + (u64)t0 * n0;
     u64 acc = (u64)a0 * w1 + (lo >> 32);
     acc += (u64)a1 * w0;
     acc += (u64)t0 * n1;
     acc += (u64)t1 * n0;
     acc = lm_keep(acc);
     return (acc << 32) | (u32)lo;
+#endif
+}
+template <bool UW>
+__device__ __forceinline__ u64 lm_shoup3(u64 a, u64 w, u64 wp, u64 nq) {
+#if LM_ASM_SHOUP
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
+    const u32 w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    u64 o;
+    if (UW)
+        asm(LM_SHOUP_BODY("0")
+            : [o] "=v"(o)
+            : [a0] "v"(a0), [a1] "v"(a1), [p0] "s"(p0), [p1] "s"(p1), [w0] "s"(w0), [w1] "s"(w1), [n0] "s"(n0),
+              [n1] "s"(n1)
+            : LM_SHOUP_CLOBBERS);
+    else
+        asm(LM_SHOUP_BODY("0")
+            : [o] "=v"(o)
+            : [a0] "v"(a0), [a1] "v"(a1), [p0] "v"(p0), [p1] "v"(p1), [w0] "v"(w0), [w1] "v"(w1), [n0] "s"(n0),
+              [n1] "s"(n1)
+            : LM_SHOUP_CLOBBERS);
+    return o;
+#else
+    return lm_shoup3<UW>(a, w, wp, nq, 0);
+#endif
 }
 // canonical a*w mod q for a constant multiplier held in SGPRs
 __device__ __forceinline__ u64 lm_shoup_cs(u64 a, tw_t W, u64 q, u64 nq) {
@@ -142,9 +214,9 @@ __device__ __forceinline__ lm_qc lm_make_qc(const mod_t &m) {
 // forward (Cooley-Tukey) butterfly, fully lazy: both outputs grow by < 3q
 template <bool UW>
 __device__ __forceinline__ void lm_bfly_fwd(u64 &x, u64 &y, const tw_t W, const lm_qc &c) {
-    const u64 v = lm_shoup3<UW>(y, W.w, W.wp, c.nq);
-    y = x + c.q3 - v;
-    x = x + v;
+    const u64 s = lm_shoup3<UW>(y, W.w, W.wp, c.nq, x); // x + v
+    y = ((x << 1) + c.q3) - s;                          // x + 3q - v as one shift-add and one subtract
+    x = s;
 }
 // inverse (Gentleman-Sande) butterfly on values in [0, 3q), outputs in [0, 3q)
 template <bool UW>
@@ -161,17 +233,15 @@ __device__ __forceinline__ tw_t lm_tw_load(const tw_t *__restrict__ tw, uint32_t
 }
 
 // R forward stages on e[0 .. 2^R), first stage index s0, block index blk
-// hoff: 0 for a whole transform; 1 + h when the stages belong to half h of a transform whose
-// first stage was done separately (global twiddle index = local index + (hoff << local stage))
 template <int R, bool UW>
 __device__ __forceinline__ void lm_fwd_stages(u64 *e, uint32_t s0, uint32_t blk, const tw_t *__restrict__ tw,
-                                              const lm_qc &c, uint32_t hoff = 0) {
+                                              const lm_qc &c) {
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int span = (1 << R) >> st, half = span >> 1;
 #pragma unroll
         for (int g = 0; g < (1 << st); g++) {
-            const tw_t W = lm_tw_load<UW>(tw, (((1u + hoff) << s0) << st) + (blk << st) + g);
+            const tw_t W = lm_tw_load<UW>(tw, ((1u << s0) << st) + (blk << st) + g);
 #pragma unroll
             for (int k = 0; k < half; k++) lm_bfly_fwd<UW>(e[g * span + k], e[g * span + k + half], W, c);
         }
@@ -195,15 +265,38 @@ __device__ __forceinline__ void lm_inv_stages(u64 *e, uint32_t logN, uint32_t lo
     }
 }
 
+// Work-item dealing.  Cross-wave pass: item = tid + m*nthreads.  Wave-local passes: the items of
+// a pass are split evenly over the waves in order, so that wave j always covers coefficients
+// [j*N/NW, (j+1)*N/NW); within its share lane l takes items l, l+64, ...
+template <int LOGN, int R>
+struct lm_deal {
+    static constexpr uint32_t items = 1u << (LOGN - R);
+    static constexpr uint32_t per_wave = items / (lm_nthreads(LOGN) / 64);
+    static constexpr uint32_t reps = per_wave / 64 ? per_wave / 64 : 1;
+    static __device__ __forceinline__ uint32_t local(uint32_t tid, uint32_t m) {
+        return (tid >> 6) * per_wave + (tid & 63) + 64 * m;
+    }
+    static __device__ __forceinline__ bool valid(uint32_t tid) { return per_wave >= 64 || (tid & 63) < per_wave; }
+};
+// orders a wave's LDS writes before its later LDS reads of other lanes' slots: the hardware keeps
+// one wave's LDS operations in order, this only pins the compiler
+__device__ __forceinline__ void lm_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------ forward
-// Loader: u64 operator()(uint32_t i) -> coefficient i in [0, q)
+// Loader: u64 operator()(uint32_t i) -> coefficient i in [0, 7q)
 // Storer: void operator()(uint32_t i0, const u64 *v, int count) -> `count` consecutive lazy
-//         results (values < (3*logN+1)*q) starting at coefficient i0
-template <int R, class Loader>
-__device__ __forceinline__ void lm_fwd_first(u64 *s, uint32_t logN, const tw_t *tw, const lm_qc &c,
-                                             uint32_t tid, uint32_t nthreads, Loader &ld) {
-    const uint32_t log_tl = logN - R, items = 1u << log_tl;
-    for (uint32_t w = tid; w < items; w += nthreads) {
+//         results (values < (3*logN+7)*q) starting at coefficient i0
+template <int LOGN, int R, bool CROSS, class Loader>
+__device__ __forceinline__ void lm_fwd_first(u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Loader &ld) {
+    constexpr uint32_t log_tl = LOGN - R, items = 1u << log_tl, NT = lm_nthreads(LOGN);
+    constexpr uint32_t reps = items / NT ? items / NT : 1;
+#pragma unroll 1
+    for (uint32_t m = 0; m < reps; m++) {
+        const uint32_t w = tid + m * NT;
+        if (items < NT && w >= items) break;
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = ld(w + ((uint32_t)k << log_tl));
@@ -213,175 +306,154 @@ __device__ __forceinline__ void lm_fwd_first(u64 *s, uint32_t logN, const tw_t *
     }
 }
 
-template <int R, bool UW>
-__device__ __forceinline__ void lm_fwd_mid(u64 *s, uint32_t logN, uint32_t s0, const tw_t *tw, const lm_qc &c,
-                                           uint32_t tid, uint32_t nthreads, uint32_t hoff = 0) {
-    const uint32_t log_tl = logN - s0 - R, items = 1u << (logN - R);
-    for (uint32_t w = tid; w < items; w += nthreads) {
+template <int LOGN, int R, int S0>
+__device__ __forceinline__ void lm_fwd_mid(u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid) {
+    constexpr uint32_t log_tl = LOGN - S0 - R;
+    using D = lm_deal<LOGN, R>;
+    if (!D::valid(tid)) return;
+#pragma unroll 1
+    for (uint32_t m = 0; m < D::reps; m++) {
+        const uint32_t w = D::local(tid, m);
         const uint32_t blk = w >> log_tl, off = w & ((1u << log_tl) - 1);
         const uint32_t base = (blk << (log_tl + R)) + off;
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_tl))];
-        lm_fwd_stages<R, UW>(e, s0, blk, tw, c, hoff);
+        lm_fwd_stages<R, (log_tl >= 6)>(e, S0, blk, tw, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_tl))] = e[k];
     }
 }
 
-template <int R, class Storer>
-__device__ __forceinline__ void lm_fwd_last(const u64 *s, uint32_t logN, const tw_t *tw, const lm_qc &c,
-                                            uint32_t tid, uint32_t nthreads, Storer &st, uint32_t hoff = 0,
-                                            uint32_t ioff = 0) {
-    const uint32_t s0 = logN - R, items = 1u << (logN - R);
-    for (uint32_t w = tid; w < items; w += nthreads) {
+template <int LOGN, int R, class Storer>
+__device__ __forceinline__ void lm_fwd_last(const u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Storer &st) {
+    constexpr uint32_t s0 = LOGN - R;
+    using D = lm_deal<LOGN, R>;
+    if (!D::valid(tid)) return;
+#pragma unroll 1
+    for (uint32_t m = 0; m < D::reps; m++) {
+        const uint32_t w = D::local(tid, m);
         const uint32_t base = w << R;
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + k)];
-        lm_fwd_stages<R, false>(e, s0, w, tw, c, hoff);
-        st(ioff + base, e, 1 << R);
+        lm_fwd_stages<R, false>(e, s0, w, tw, c);
+        st(base, e, 1 << R);
     }
 }
 
 template <int LOGN, int P, int S0, class Loader, class Storer>
-__device__ __forceinline__ void lm_fwd_rec(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
-                                           uint32_t nthreads, Loader &ld, Storer &st) {
+__device__ __forceinline__ void lm_fwd_rec(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid, Loader &ld,
+                                           Storer &st) {
     constexpr int NP = lm_npasses(LOGN), R = lm_pass_r(LOGN, P);
+    constexpr bool cross = lm_cross_r(LOGN) > 0;
     if constexpr (P == 0)
-        lm_fwd_first<R>(sm, LOGN, tw, c, tid, nthreads, ld);
+        lm_fwd_first<LOGN, R, cross>(sm, tw, c, tid, ld);
     else if constexpr (P == NP - 1)
-        lm_fwd_last<R>(sm, LOGN, tw, c, tid, nthreads, st);
+        lm_fwd_last<LOGN, R>(sm, tw, c, tid, st);
     else
-        lm_fwd_mid<R, (LOGN - S0 - R >= 6)>(sm, LOGN, S0, tw, c, tid, nthreads);
+        lm_fwd_mid<LOGN, R, S0>(sm, tw, c, tid);
     if constexpr (P + 1 < NP) {
-        __syncthreads();
-        lm_fwd_rec<LOGN, P + 1, S0 + R>(sm, tw, c, tid, nthreads, ld, st);
+        if constexpr (P == 0 && cross)
+            __syncthreads();
+        else
+            lm_wave_sync();
+        lm_fwd_rec<LOGN, P + 1, S0 + R>(sm, tw, c, tid, ld, st);
     }
 }
 struct lm_no_after {
     __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {}
 };
 
-// passes of one half (size 2^H, all coefficients already in LDS) of a split transform
-template <int H, int P, int S0, class Storer>
-__device__ __forceinline__ void lm_half_rec(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
-                                            uint32_t nthreads, Storer &st, uint32_t hoff, uint32_t ioff) {
-    constexpr int NP = lm_npasses(H), R = lm_pass_r(H, P);
-    if constexpr (P == NP - 1)
-        lm_fwd_last<R>(sm, H, tw, c, tid, nthreads, st, hoff, ioff);
-    else
-        lm_fwd_mid<R, (H - S0 - R >= 6)>(sm, H, S0, tw, c, tid, nthreads, hoff);
-    if constexpr (P + 1 < NP) {
-        __syncthreads();
-        lm_half_rec<H, P + 1, S0 + R>(sm, tw, c, tid, nthreads, st, hoff, ioff);
-    }
-}
-
-// Forward transform.  `after(i0, n)` runs once the storer has seen coefficients [i0, i0+n)
-// (whole transform, or one half of a split one) and before LDS is reused.
+// Forward transform.  `after(i0, n)` runs once the storer has seen coefficients [i0, i0+n) (the
+// whole transform) -- NOT behind a barrier: other waves may still be in their last pass.
 template <int LOGN, class Loader, class Storer, class After = lm_no_after>
-__device__ __forceinline__ void lm_ntt_forward(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
-                                               uint32_t nthreads, Loader &ld, Storer &st,
-                                               After after = After()) {
-    if constexpr (!lm_fwd_is_split(LOGN)) {
-        lm_fwd_rec<LOGN, 0, 0>(sm, tw, c, tid, nthreads, ld, st);
-        after(0u, 1u << LOGN);
-    } else {
-        // stage 0 from registers: x + W*y feeds half 0 (to LDS now), x - W*y is parked in VGPRs
-        constexpr uint32_t NH = 1u << (LOGN - 1), NT = LM_SPLIT_NT, PER = NH / NT;
-        const tw_t W1 = lm_tw_load<true>(tw, 1);
-        u64 park[PER];
-#pragma unroll
-        for (uint32_t k = 0; k < PER; k++) {
-            const uint32_t j = tid + k * NT;
-            u64 x = ld(j), y = ld(j + NH);
-            lm_bfly_fwd<true>(x, y, W1, c);
-            sm[LM_PAD(j)] = x;
-            park[k] = y;
-            // keep at most four coefficient pairs in flight: without this fence the scheduler hoists
-            // all 2*PER loads and the parked half no longer fits beside them in 128 VGPRs
-            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        lm_half_rec<LOGN - 1, 0, 0>(sm, tw, c, tid, nthreads, st, 1u, 0u);
-        after(0u, NH);
-        __syncthreads();
-#pragma unroll
-        for (uint32_t k = 0; k < PER; k++) sm[LM_PAD(tid + k * NT)] = park[k];
-        __syncthreads();
-        lm_half_rec<LOGN - 1, 0, 0>(sm, tw, c, tid, nthreads, st, 2u, NH);
-        after(NH, NH);
-    }
+__device__ __forceinline__ void lm_ntt_forward(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid, uint32_t,
+                                               Loader &ld, Storer &st, After after = After()) {
+    static_assert(lm_npasses(LOGN) >= 2, "a transform needs a loading and a storing pass");
+    lm_fwd_rec<LOGN, 0, 0>(sm, tw, c, tid, ld, st);
+    after(0u, 1u << LOGN);
 }
 
 // ------------------------------------------------------------------ inverse
 // Loader: void operator()(uint32_t i0, u64 *v, int count) -> `count` consecutive coefficients in [0, q)
 // Storer: void operator()(uint32_t i, u64 v) -> lazy result (< 3q, before the N^-1 scaling)
-template <int R, class Loader>
-__device__ __forceinline__ void lm_inv_first(u64 *s, uint32_t logN, const tw_t *tw, const lm_qc &c,
-                                             uint32_t tid, uint32_t nthreads, Loader &ld) {
-    const uint32_t items = 1u << (logN - R);
-    for (uint32_t w = tid; w < items; w += nthreads) {
+template <int LOGN, int R, class Loader>
+__device__ __forceinline__ void lm_inv_first(u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Loader &ld) {
+    using D = lm_deal<LOGN, R>;
+    if (!D::valid(tid)) return;
+#pragma unroll 1
+    for (uint32_t m = 0; m < D::reps; m++) {
+        const uint32_t w = D::local(tid, m);
         const uint32_t base = w << R;
         u64 e[1 << R];
         ld(base, e, 1 << R);
-        lm_inv_stages<R, false>(e, logN, 0, w, tw, c);
+        lm_inv_stages<R, false>(e, LOGN, 0, w, tw, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + k)] = e[k];
     }
 }
 
-template <int R, bool UW>
-__device__ __forceinline__ void lm_inv_mid(u64 *s, uint32_t logN, uint32_t log_t0, const tw_t *tw,
-                                           const lm_qc &c, uint32_t tid, uint32_t nthreads) {
-    const uint32_t items = 1u << (logN - R);
-    for (uint32_t w = tid; w < items; w += nthreads) {
-        const uint32_t blk = w >> log_t0, off = w & ((1u << log_t0) - 1);
-        const uint32_t base = (blk << (log_t0 + R)) + off;
+template <int LOGN, int R, int LT>
+__device__ __forceinline__ void lm_inv_mid(u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid) {
+    using D = lm_deal<LOGN, R>;
+    if (!D::valid(tid)) return;
+#pragma unroll 1
+    for (uint32_t m = 0; m < D::reps; m++) {
+        const uint32_t w = D::local(tid, m);
+        const uint32_t blk = w >> LT, off = w & ((1u << LT) - 1);
+        const uint32_t base = (blk << (LT + R)) + off;
         u64 e[1 << R];
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_t0))];
-        lm_inv_stages<R, UW>(e, logN, log_t0, blk, tw, c);
+        for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << LT))];
+        lm_inv_stages<R, (LT >= 6)>(e, LOGN, LT, blk, tw, c);
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_t0))] = e[k];
+        for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << LT))] = e[k];
     }
 }
 
-template <int R, class Storer>
-__device__ __forceinline__ void lm_inv_last(const u64 *s, uint32_t logN, const tw_t *tw, const lm_qc &c,
-                                            uint32_t tid, uint32_t nthreads, Storer &st) {
-    const uint32_t log_t0 = logN - R, items = 1u << log_t0;
-    for (uint32_t w = tid; w < items; w += nthreads) {
+template <int LOGN, int R, class Storer>
+__device__ __forceinline__ void lm_inv_last(const u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Storer &st) {
+    constexpr uint32_t log_t0 = LOGN - R, items = 1u << log_t0, NT = lm_nthreads(LOGN);
+    constexpr uint32_t reps = items / NT ? items / NT : 1;
+#pragma unroll 1
+    for (uint32_t m = 0; m < reps; m++) {
+        const uint32_t w = tid + m * NT;
+        if (items < NT && w >= items) break;
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(w + ((uint32_t)k << log_t0))];
-        lm_inv_stages<R, true>(e, logN, log_t0, 0, tw, c);
+        lm_inv_stages<R, true>(e, LOGN, log_t0, 0, tw, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) st(w + ((uint32_t)k << log_t0), e[k]);
     }
 }
 
-// the inverse runs the pass list backwards so that its stage grouping mirrors the forward one
+// the inverse runs the pass list backwards: wave-local passes first, the cross-wave pass last
 template <int LOGN, int P, int LT, class Loader, class Storer>
-__device__ __forceinline__ void lm_inv_rec(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
-                                           uint32_t nthreads, Loader &ld, Storer &st) {
+__device__ __forceinline__ void lm_inv_rec(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid, Loader &ld,
+                                           Storer &st) {
     constexpr int NP = lm_npasses(LOGN), R = lm_pass_r(LOGN, NP - 1 - P);
+    constexpr bool cross = lm_cross_r(LOGN) > 0;
     if constexpr (P == 0)
-        lm_inv_first<R>(sm, LOGN, tw, c, tid, nthreads, ld);
+        lm_inv_first<LOGN, R>(sm, tw, c, tid, ld);
     else if constexpr (P == NP - 1)
-        lm_inv_last<R>(sm, LOGN, tw, c, tid, nthreads, st);
+        lm_inv_last<LOGN, R>(sm, tw, c, tid, st);
     else
-        lm_inv_mid<R, (LT >= 6)>(sm, LOGN, LT, tw, c, tid, nthreads);
+        lm_inv_mid<LOGN, R, LT>(sm, tw, c, tid);
     if constexpr (P + 1 < NP) {
-        __syncthreads();
-        lm_inv_rec<LOGN, P + 1, LT + R>(sm, tw, c, tid, nthreads, ld, st);
+        if constexpr (P + 2 == NP && cross)
+            __syncthreads();
+        else
+            lm_wave_sync();
+        lm_inv_rec<LOGN, P + 1, LT + R>(sm, tw, c, tid, ld, st);
     }
 }
 template <int LOGN, class Loader, class Storer>
-__device__ __forceinline__ void lm_ntt_inverse(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid,
-                                               uint32_t nthreads, Loader &ld, Storer &st) {
-    lm_inv_rec<LOGN, 0, 0>(sm, tw, c, tid, nthreads, ld, st);
+__device__ __forceinline__ void lm_ntt_inverse(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid, uint32_t,
+                                               Loader &ld, Storer &st) {
+    static_assert(lm_npasses(LOGN) >= 2, "a transform needs a loading and a storing pass");
+    lm_inv_rec<LOGN, 0, 0>(sm, tw, c, tid, ld, st);
 }
 
 // ---- stock loaders / storers

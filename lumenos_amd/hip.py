@@ -86,9 +86,11 @@ def load(build=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if build:
-        path = _build.build()
+    path = os.environ.get("LUMEN_HIP_LIB")  # A/B runs of two builds of this same library
+    if not path:
+        path = _build.LIB
+        if build:
+            path = _build.build()
     if not os.path.exists(path):
         raise LumenError(f"{path} is missing: build it with `python -m lumenos_amd._build` "
                          "(there is no CPU fallback for the HIP path)")

@@ -6,7 +6,14 @@
 //     c'_i = (c_i - u_i) * q_l^-1               mod q_i,   i < l;  limb l dropped
 // Exact modular arithmetic, canonical outputs.
 //
-// Two kernels per dropped limb, both built on the LDS-resident limb transform:
+// Dropping SEVERAL limbs (the path's case: 12 -> 2) does not need a transform per remaining limb and
+// step.  NTT_i is a ring isomorphism and every step is coefficient-wise, so
+//     INTT_i(c'_i) = (INTT_i(c_i) - ((t mod q_i) - (half mod q_i))) * q_l^-1   mod q_i
+// i.e. the whole chain of steps can run on coefficients: INTT every limb once, run the l-loop per
+// coefficient in registers (k_rescale_coef), NTT the surviving limbs.  nl + target transforms per
+// polynomial instead of sum_l l (14 instead of 75 for 12 -> 2); same canonical residues.
+//
+// Dropping ONE limb keeps the per-step form -- two kernels built on the LDS-resident limb transform:
 //   k_rescale_last : one workgroup per polynomial, INTT of the last limb fused
 //                    with the N^-1 scaling and the +half; writes t (8N bytes).
 //   k_rescale_limb : one workgroup per (polynomial, remaining limb): the
@@ -66,9 +73,116 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rescale_limb(const u64
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)limb * N, c, tid, nthreads, ld, st);
 }
 
+// ---- multi-step rescale on coefficients
+struct rs_step_t {
+    u64 k;    // half_l + M * q_j, M = floor(q_l / q_j) + 1: keeps c_j + k - t non-negative
+    u64 pad;
+    tw_t inv; // q_l^-1 mod q_j
+};
+struct rs_half_t {
+    u64 h[LM_MAX_LIMBS]; // (q_l - 1) / 2
+};
+struct RescaleTables {
+    rs_step_t *d_steps = nullptr; // [LM_MAX_LIMBS][LM_MAX_LIMBS], entry l * LM_MAX_LIMBS + j for j < l
+    rs_half_t half;
+    ~RescaleTables() {
+        if (d_steps) hipFree(d_steps);
+    }
+};
+
+static int get_rescale_tables(lumen_ctx *ctx, RescaleTables **out) {
+    auto it = ctx->ext.find("rescale_tables");
+    if (it != ctx->ext.end()) {
+        *out = static_cast<RescaleTables *>(it->second.get());
+        return 0;
+    }
+    auto sp = std::make_shared<RescaleTables>();
+    std::vector<rs_step_t> steps((size_t)LM_MAX_LIMBS * LM_MAX_LIMBS);
+    memset(steps.data(), 0, steps.size() * sizeof(rs_step_t));
+    for (uint32_t l = 0; l < LM_MAX_LIMBS; l++) {
+        const uint64_t ql = ctx->mod[l < ctx->L ? l : 0], half = (ql - 1) >> 1;
+        sp->half.h[l] = half;
+        for (uint32_t j = 0; j < l && l < ctx->L; j++) {
+            const uint64_t qj = ctx->mod[j];
+            rs_step_t &e = steps[(size_t)l * LM_MAX_LIMBS + j];
+            // c_j (< 3 q_j) + k - t with t < q_l: k - t > 0 and the sum stays far below 2^64
+            // (q_j, q_l < 2^58.4 by lumen_ctx_create, so M <= 2^58.4 / 2^20 only for absurd ratios:
+            // refuse those)
+            const uint64_t M = ql / qj + 1;
+            if (M > 16) return lm_fail(ctx, "rescale: moduli %u and %u differ by more than 16x", l, j);
+            e.k = half + M * qj;
+            e.inv = h_tw(h_invmod(ql % qj, qj), qj);
+        }
+    }
+    LM_HIP(ctx, hipMalloc((void **)&sp->d_steps, steps.size() * sizeof(rs_step_t)));
+    LM_HIP(ctx, hipMemcpy(sp->d_steps, steps.data(), steps.size() * sizeof(rs_step_t), hipMemcpyHostToDevice));
+    ctx->ext["rescale_tables"] = sp;
+    *out = sp.get();
+    return 0;
+}
+
+// One thread per coefficient: limbs [0, nl) of the coefficient-domain polynomial in registers, the
+// rescale steps l = nl-1 .. target applied in order, limbs [0, target) written (canonical).
+// Intermediate limbs stay lazy in [0, 3q); a limb is made canonical when it becomes the last one.
+__global__ __launch_bounds__(256) void k_rescale_coef(const u64 *__restrict__ coef, size_t src_poly_stride,
+                                                      u64 *__restrict__ dst, size_t dst_poly_stride, uint32_t nl,
+                                                      uint32_t target, uint32_t logN, size_t total, lm_mods mods,
+                                                      const rs_step_t *__restrict__ steps, rs_half_t half) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const size_t poly = idx >> logN, i = idx & (((size_t)1 << logN) - 1);
+    const u64 *p = coef + poly * src_poly_stride + i;
+    u64 c[LM_MAX_LIMBS];
+#pragma unroll
+    for (int j = 0; j < LM_MAX_LIMBS; j++) c[j] = (uint32_t)j < nl ? p[(size_t)j << logN] : 0;
+#pragma unroll
+    for (int l = LM_MAX_LIMBS - 1; l >= 1; l--) {
+        if ((uint32_t)l < nl && (uint32_t)l >= target) { // wave-uniform
+            const u64 ql = mods.m[l].q;
+            u64 t = lm_csub(lm_csub(c[l], 2 * ql), ql);
+            t = lm_addmod(t, half.h[l], ql);
+#pragma unroll
+            for (int j = 0; j < l; j++) {
+                const rs_step_t e = steps[l * LM_MAX_LIMBS + j];
+                c[j] = lm_shoup3<true>(c[j] + e.k - t, e.inv.w, e.inv.wp, 0 - mods.m[j].q);
+            }
+        }
+    }
+    u64 *o = dst + poly * dst_poly_stride + i;
+#pragma unroll
+    for (int j = 0; j < LM_MAX_LIMBS; j++)
+        if ((uint32_t)j < target) {
+            const u64 qj = mods.m[j].q;
+            o[(size_t)j << logN] = lm_csub(lm_csub(c[j], 2 * qj), qj);
+        }
+}
+
+static int rescale_polys_coef(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target, uint32_t npoly,
+                              u64 *work) {
+    RescaleTables *tb = nullptr;
+    if (int rc = get_rescale_tables(ctx, &tb)) return rc;
+    const uint32_t N = ctx->N;
+    if (int rc = lm_launch_ntt_strided(ctx, src, (size_t)nl * N, work, (size_t)nl * N, npoly, lm_map_q(nl), true,
+                                       "rescale_intt", nullptr))
+        return rc;
+    {
+        lm_prof_scope ps(ctx, "rescale_coef", npoly);
+        const size_t total = (size_t)npoly * N;
+        hipLaunchKernelGGL(k_rescale_coef, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, work,
+                           (size_t)nl * N, dst, (size_t)target * N, nl, target, ctx->logN, total, ctx->mods,
+                           tb->d_steps, tb->half);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    return lm_launch_ntt_strided(ctx, dst, (size_t)target * N, dst, (size_t)target * N, npoly, lm_map_q(target), false,
+                                 "rescale_ntt", nullptr);
+}
+
 template <int LOGN>
 static int rescale_polys_t(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
                            uint32_t npoly, u64 *work, u64 *tbuf) {
+    // transforms per polynomial: per-step form sum_{l=target+1..nl} l, coefficient form nl + target
+    if (work && (uint64_t)(nl + target + 1) * (nl - target) / 2 > (uint64_t)nl + target)
+        return rescale_polys_coef(ctx, src, nl, dst, target, npoly, work);
     const uint32_t N = ctx->N;
     const size_t lds_i = lm_inv_lds(ctx->logN), lds_f = lm_fwd_lds(ctx->logN);
     const uint32_t thr_i = lm_inv_threads(ctx->logN), thr_f = lm_fwd_threads(ctx->logN);

@@ -36,21 +36,20 @@ static uint32_t ks_batch() { // LUMEN_KS_BATCH overrides the default (tuning kno
 }
 
 // v = uint64(float64(y0)/float64(m0) + float64(y1)/float64(m1))  ([LATTIGO-RECALL] reconstructRNS).
-// The double expression is within 2^-49 of S = (y0*m1 + y1*m0) / (m0*m1), so unless S is that close
-// to 1 its truncation equals [S >= 1], which is decided exactly in 128-bit integers; only the
-// (probability ~2^-46) near-tie falls back to the literal double computation.
-__device__ __forceinline__ u32 bx_v(u64 y0, u64 y1, u64 m0, u64 m1) {
-    const u128 A = (u128)y0 * m1 + (u128)y1 * m0, M = (u128)m0 * m1;
-    const u128 D = A >= M ? A - M : M - A;
-    if ((u64)(D >> 64) >= 8) return A >= M ? 1u : 0u;
+// The double expression is within 2^-49 of S = A / M, A = y0*m1 + y1*m0, M = m0*m1, and S < 2: unless
+// S is that close to 1 or to 2 its truncation equals [S >= 1], which is decided exactly in 128-bit
+// integers; only the (probability ~2^-46) near-ties fall back to the literal double computation.
+__device__ __forceinline__ u32 bx_v(u128 A, u128 M, u64 y0, u64 y1, u64 m0, u64 m1) {
+    const u128 D1 = A >= M ? A - M : M - A, D2 = 2 * M - A;
+    if ((u64)(D1 >> 64) >= 8 && (u64)(D2 >> 64) >= 8) return A >= M ? 1u : 0u;
     double vf = 0.0;
     vf += (double)y0 / (double)m0;
     vf += (double)y1 / (double)m1;
     return (u32)(u64)vf;
 }
 
-// y0[b][i] |= v << 63 for every two-limb source group.  y: [npoly][stride] with the group's two
-// limbs at limb offsets lo, lo+1.
+// (y0, y1)[b][i] -> (hi, lo) of W = y0*m1 + y1*m0 + (2 - v)*M for every two-limb source group
+// (lm_ks_dev.h).  y: [npoly][stride] with the group's two limbs at limb offsets lo, lo+1.
 __global__ void k_pack_v(u64 *__restrict__ y, size_t poly_stride, uint32_t npoly, uint32_t ngroups,
                          uint32_t group_limbs, uint32_t first_mod, uint32_t nlimbs_total, uint32_t logN,
                          lm_mods mods) {
@@ -60,10 +59,14 @@ __global__ void k_pack_v(u64 *__restrict__ y, size_t poly_stride, uint32_t npoly
         const uint32_t i = (uint32_t)(g & (N - 1));
         const uint32_t grp = (uint32_t)((g >> logN) % ngroups), p = (uint32_t)((g >> logN) / ngroups);
         const uint32_t l0 = grp * group_limbs;
-        if (l0 + 1 >= nlimbs_total) continue; // single-limb group: no correction term
+        if (l0 + 1 >= nlimbs_total) continue; // single-limb group: nothing to reconstruct
         u64 *y0 = y + (size_t)p * poly_stride + (size_t)l0 * N + i;
         const u64 a = *y0, b = y0[N];
-        *y0 = a | ((u64)bx_v(a, b, mods.m[first_mod + l0].q, mods.m[first_mod + l0 + 1].q) << LM_V_BIT);
+        const u64 m0 = mods.m[first_mod + l0].q, m1 = mods.m[first_mod + l0 + 1].q;
+        const u128 A = (u128)a * m1 + (u128)b * m0, M = (u128)m0 * m1;
+        const u128 W = A + (u128)(2u - bx_v(A, M, a, b, m0, m1)) * M; // v <= 2
+        *y0 = (u64)(W >> LM_W_SPLIT);
+        y0[N] = (u64)W & ((1ull << LM_W_SPLIT) - 1);
     }
 }
 
@@ -190,7 +193,9 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (k < count) {
-                u64 x = lm_shoup_cs(lm_submod(uv[k], lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64), qc.q), pi, qc.q, qc.nq);
+                // (u - lift) * P^-1 with the lift only lazily reduced: u + 3q - lift' < 4q
+                const u64 lift = lm_shoup3<true>(v[k], 1ull, qc.qinv64, qc.nq);
+                u64 x = lm_shoup_cs(uv[k] + qc.q3 - lift, pi, qc.q, qc.nq);
                 if (w == 0) x = lm_addmod(x, cv[k], qc.q);
                 sm[LM_PAD(i0 + k)] = x; // the slots this work item just consumed
             }
@@ -232,14 +237,9 @@ bx_t make_bx(const uint64_t *src, uint32_t ns, uint64_t t) {
     memset(&c, 0, sizeof(c));
     c.ns = ns;
     uint64_t m_mod_t = 1;
-    for (uint32_t a = 0; a < ns; a++) {
-        uint64_t ht = 1;
-        for (uint32_t b = 0; b < ns; b++)
-            if (b != a) ht = h_mulmod(ht, src[b] % t, t);
-        c.hat_mod_t[a] = h_tw(ht, t);
-        m_mod_t = h_mulmod(m_mod_t, src[a] % t, t);
-    }
-    c.t_minus_m = t - m_mod_t;
+    for (uint32_t a = 0; a < ns; a++) m_mod_t = h_mulmod(m_mod_t, src[a] % t, t);
+    c.b57 = h_tw((1ull << LM_W_SPLIT) % t, t);
+    c.c_t = (t - h_mulmod(2 % t, m_mod_t, t)) % t;
     return c;
 }
 

@@ -218,12 +218,15 @@ __device__ __forceinline__ void lm_bfly_fwd(u64 &x, u64 &y, const tw_t W, const 
     y = ((x << 1) + c.q3) - s;                          // x + 3q - v as one shift-add and one subtract
     x = s;
 }
-// inverse (Gentleman-Sande) butterfly on values in [0, 3q), outputs in [0, 3q)
+// inverse (Gentleman-Sande) butterfly, lazy inside a pass: in stage st of a pass both inputs are
+// below C = 3q * 2^st; the sum is left to grow (x < 2C), the difference goes through the Shoup
+// multiplication (any input below 2^64) and lands in [0, 3q).  lm_inv_stages brings the sums back
+// under 3q once per pass instead of once per butterfly.
 template <bool UW>
-__device__ __forceinline__ void lm_bfly_inv(u64 &x, u64 &y, const tw_t W, const lm_qc &c) {
+__device__ __forceinline__ void lm_bfly_inv(u64 &x, u64 &y, const tw_t W, const lm_qc &c, u64 C) {
     const u64 u = x, v = y;
-    x = lm_csub(u + v, c.q3);
-    y = lm_shoup3<UW>(u + c.q3 - v, W.w, W.wp, c.nq);
+    x = u + v;
+    y = lm_shoup3<UW>(u + C - v, W.w, W.wp, c.nq);
 }
 
 template <bool UW>
@@ -248,19 +251,37 @@ __device__ __forceinline__ void lm_fwd_stages(u64 *e, uint32_t s0, uint32_t blk,
     }
 }
 
-// R inverse stages; log_t0 = log2 of the first stage's butterfly distance
-template <int R, bool UW>
+// R inverse stages on inputs in [0, 3q); log_t0 = log2 of the first stage's butterfly distance.
+// Output e[i] has taken the sum branch in its last k stages (k = R for i = 0, else R-1-floor(log2 i))
+// and is below 3q * 2^k <= 48q.  Unless this is the transform's last pass (whose storer multiplies by
+// N^-1 and takes any value below 2^64) the outputs are brought back under 3q: k conditional
+// subtractions, or one multiplication-free Shoup reduction when k >= 3.
+template <int R, bool UW, bool LAST>
 __device__ __forceinline__ void lm_inv_stages(u64 *e, uint32_t logN, uint32_t log_t0, uint32_t blk,
                                               const tw_t *__restrict__ tw, const lm_qc &c) {
+    static_assert(R <= 4, "3q * 2^R must stay below 2^64");
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int half = 1 << st, span = half << 1;
         const uint32_t m = 1u << (logN - log_t0 - st - 1);
+        const u64 C = c.q3 << st;
 #pragma unroll
         for (int g = 0; g < ((1 << R) / span); g++) {
             const tw_t W = lm_tw_load<UW>(tw, m + (blk << (R - st - 1)) + g);
 #pragma unroll
-            for (int k = 0; k < half; k++) lm_bfly_inv<UW>(e[g * span + k], e[g * span + k + half], W, c);
+            for (int k = 0; k < half; k++) lm_bfly_inv<UW>(e[g * span + k], e[g * span + k + half], W, c, C);
+        }
+    }
+    if (!LAST) {
+#pragma unroll
+        for (int i = 0; i < (1 << R) / 2; i++) {
+            const int k = i == 0 ? R : R - 1 - lm_ilog2(i);
+            if (k >= 3) {
+                e[i] = lm_shoup3<true>(e[i], 1ull, c.qinv64, c.nq);
+            } else {
+#pragma unroll
+                for (int j = k - 1; j >= 0; j--) e[i] = lm_csub(e[i], c.q3 << j);
+            }
         }
     }
 }
@@ -377,7 +398,7 @@ __device__ __forceinline__ void lm_ntt_forward(u64 *sm, const tw_t *tw, const lm
 
 // ------------------------------------------------------------------ inverse
 // Loader: void operator()(uint32_t i0, u64 *v, int count) -> `count` consecutive coefficients in [0, q)
-// Storer: void operator()(uint32_t i, u64 v) -> lazy result (< 3q, before the N^-1 scaling)
+// Storer: void operator()(uint32_t i, u64 v) -> lazy result (any value below 2^64, before the N^-1 scaling)
 template <int LOGN, int R, class Loader>
 __device__ __forceinline__ void lm_inv_first(u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Loader &ld) {
     using D = lm_deal<LOGN, R>;
@@ -388,7 +409,7 @@ __device__ __forceinline__ void lm_inv_first(u64 *s, const tw_t *tw, const lm_qc
         const uint32_t base = w << R;
         u64 e[1 << R];
         ld(base, e, 1 << R);
-        lm_inv_stages<R, false>(e, LOGN, 0, w, tw, c);
+        lm_inv_stages<R, false, false>(e, LOGN, 0, w, tw, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + k)] = e[k];
     }
@@ -406,7 +427,7 @@ __device__ __forceinline__ void lm_inv_mid(u64 *s, const tw_t *tw, const lm_qc &
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << LT))];
-        lm_inv_stages<R, (LT >= 6)>(e, LOGN, LT, blk, tw, c);
+        lm_inv_stages<R, (LT >= 6), false>(e, LOGN, LT, blk, tw, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << LT))] = e[k];
     }
@@ -423,7 +444,7 @@ __device__ __forceinline__ void lm_inv_last(const u64 *s, const tw_t *tw, const 
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(w + ((uint32_t)k << log_t0))];
-        lm_inv_stages<R, true>(e, LOGN, log_t0, 0, tw, c);
+        lm_inv_stages<R, true, true>(e, LOGN, log_t0, 0, tw, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) st(w + ((uint32_t)k << log_t0), e[k]);
     }

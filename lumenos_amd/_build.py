@@ -27,6 +27,7 @@ def build(force=False, verbose=False):
     objs = []
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+    flags += os.environ.get("LUMEN_HIPCC_FLAGS", "").split()  # tuning experiments (-DLM_MAC_COLS=8 ...)
     procs = []
     for s in srcs:
         o = s[:-4] + ".o"

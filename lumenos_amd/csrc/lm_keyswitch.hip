@@ -119,31 +119,79 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
 
 // ---- step 3: gadget product.  u[b][w][t][i] = sum_d ext[b][d][t][i] * key[d][w][t][i]
 // key in Montgomery form (k * 2^64 mod q): 128-bit accumulation, one Montgomery reduction.
+// COLS columns share one read of the key limb (the key is re-read B/COLS times per launch, out of
+// L2 / Infinity Cache); VEC consecutive coefficients per thread move as one VEC*8-byte access.
+#ifndef LM_MAC_COLS
 #define LM_MAC_COLS 4
+#endif
+#ifndef LM_MAC_VEC
+#define LM_MAC_VEC 1
+#endif
+template <int VEC>
+struct mac_vec;
+template <>
+struct mac_vec<1> {
+    u64 v[1];
+    static __device__ __forceinline__ mac_vec load(const u64 *p) { return mac_vec{{*p}}; }
+    __device__ __forceinline__ void store(u64 *p) const { *p = v[0]; }
+};
+template <>
+struct mac_vec<2> {
+    u64 v[2];
+    static __device__ __forceinline__ mac_vec load(const u64 *p) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p);
+        return mac_vec{{a.x, a.y}};
+    }
+    __device__ __forceinline__ void store(u64 *p) const {
+        ulonglong2 a;
+        a.x = v[0], a.y = v[1];
+        *reinterpret_cast<ulonglong2 *>(p) = a;
+    }
+};
 __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, const u64 *__restrict__ acc,
                                                 const u64 *__restrict__ key, u64 *__restrict__ u, uint32_t B,
                                                 uint32_t L, uint32_t K, uint32_t beta, uint32_t logN,
                                                 lm_mods mods) {
+    typedef mac_vec<LM_MAC_VEC> vec;
     const uint32_t N = 1u << logN, LK = L + K;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // coefficient
-    const uint32_t t = blockIdx.y;                            // modulus index
-    const uint32_t b0 = blockIdx.z * LM_MAC_COLS;
+    // 1-D grid, XCD-aware: workgroup k runs on XCD k % 8 (round-robin dispatch) and each XCD has its own
+    // L2, so the G column groups that share one slice of the key are dealt to the SAME XCD back to
+    // back -- the slice is fetched into that L2 once instead of once per column group.
+    const uint32_t G = (B + LM_MAC_COLS - 1) / LM_MAC_COLS, per_limb = N / (256 * LM_MAC_VEC) ? N / (256 * LM_MAC_VEC) : 1;
+    const uint32_t slices = per_limb * LK;
+    uint32_t slice, z;
+    if (slices % 8 == 0) {
+        const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        z = j % G;
+        slice = (j / G) * 8 + xcd;
+    } else {
+        z = blockIdx.x % G;
+        slice = blockIdx.x / G;
+    }
+    const uint32_t i = ((slice % per_limb) * 256 + threadIdx.x) * LM_MAC_VEC; // first coefficient
+    const uint32_t t = slice / per_limb;                                      // modulus index
+    const uint32_t b0 = z * LM_MAC_COLS;
     if (i >= N) return;
     const mod_t md = mods.m[t];
     const uint32_t own = t < L ? t / K : 0xFFFFFFFFu; // digit whose limbs include t: its "extension" is c1 itself
-    u128 a0[LM_MAC_COLS], a1[LM_MAC_COLS];
+    u128 a0[LM_MAC_COLS][LM_MAC_VEC], a1[LM_MAC_COLS][LM_MAC_VEC];
 #pragma unroll
-    for (int c = 0; c < LM_MAC_COLS; c++) a0[c] = 0, a1[c] = 0;
+    for (int c = 0; c < LM_MAC_COLS; c++)
+#pragma unroll
+        for (int e = 0; e < LM_MAC_VEC; e++) a0[c][e] = 0, a1[c][e] = 0;
     for (uint32_t d = 0; d < beta; d++) {
-        const u64 k0 = key[(((size_t)d * 2 + 0) * LK + t) * N + i];
-        const u64 k1 = key[(((size_t)d * 2 + 1) * LK + t) * N + i];
+        const vec k0 = vec::load(key + (((size_t)d * 2 + 0) * LK + t) * N + i);
+        const vec k1 = vec::load(key + (((size_t)d * 2 + 1) * LK + t) * N + i);
 #pragma unroll
         for (int c = 0; c < LM_MAC_COLS; c++) {
             if (b0 + c < B) {
-                const u64 x = d == own ? acc[((size_t)((b0 + c) * 2 + 1) * L + t) * N + i]
-                                       : ext[(((size_t)(b0 + c) * beta + d) * LK + t) * N + i];
-                a0[c] += (u128)x * k0;
-                a1[c] += (u128)x * k1;
+                const vec x = vec::load(d == own ? acc + ((size_t)((b0 + c) * 2 + 1) * L + t) * N + i
+                                                 : ext + (((size_t)(b0 + c) * beta + d) * LK + t) * N + i);
+#pragma unroll
+                for (int e = 0; e < LM_MAC_VEC; e++) {
+                    a0[c][e] += (u128)x.v[e] * k0.v[e];
+                    a1[c][e] += (u128)x.v[e] * k1.v[e];
+                }
             }
         }
     }
@@ -151,8 +199,14 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
     for (int c = 0; c < LM_MAC_COLS; c++) {
         if (b0 + c < B) {
             u64 *o = u + ((size_t)(b0 + c) * 2 * LK + t) * N + i;
-            o[0] = lm_mont_reduce((u64)a0[c], (u64)(a0[c] >> 64), md.q, md.qneg);
-            o[(size_t)LK * N] = lm_mont_reduce((u64)a1[c], (u64)(a1[c] >> 64), md.q, md.qneg);
+            vec r0, r1;
+#pragma unroll
+            for (int e = 0; e < LM_MAC_VEC; e++) {
+                r0.v[e] = lm_mont_reduce((u64)a0[c][e], (u64)(a0[c][e] >> 64), md.q, md.qneg);
+                r1.v[e] = lm_mont_reduce((u64)a1[c][e], (u64)(a1[c][e] >> 64), md.q, md.qneg);
+            }
+            r0.store(o);
+            r1.store(o + (size_t)LK * N);
         }
     }
 }
@@ -342,8 +396,10 @@ int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s, int lan
 // product, correction-bit pass) overlap the VALU-bound transforms of the other.
 static uint32_t ks_lanes() {
     static const uint32_t n = [] {
+        // one lane by default: with two, independent column batches overlap on two streams (about 1 %
+        // faster end to end) but per-kernel event timings then include the other lane's kernels
         const char *e = getenv("LUMEN_KS_LANES");
-        return (e && atoi(e) == 1) ? 1u : 2u;
+        return (e && atoi(e) == 2) ? 2u : 1u;
     }();
     return n;
 }
@@ -393,7 +449,7 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
     // 3. gadget product
     {
         lm_prof_scope ps(ctx, "ks_mac", (uint64_t)B);
-        dim3 grid((N + 255) / 256, LK, (B + LM_MAC_COLS - 1) / LM_MAC_COLS);
+        dim3 grid(((N / LM_MAC_VEC + 255) / 256) * LK * ((B + LM_MAC_COLS - 1) / LM_MAC_COLS));
         hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, s.ext, acc, gk.d_key, s.u, B, L, K, beta,
                            ctx->logN, ctx->mods);
         LM_HIP(ctx, hipGetLastError());

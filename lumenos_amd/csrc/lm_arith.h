@@ -51,6 +51,19 @@ __device__ __forceinline__ u64 lm_mont_reduce(u64 lo, u64 hi, u64 q, u64 qneg) {
     return lm_csub(r, q);
 }
 
+// the same for sums of `terms` products x * k with x < 2^64, k < q (terms * q < 2^63): the quotient
+// step leaves a value below (terms + 1) * q, brought home by conditional subtractions when that is
+// at most 8q and by one Barrett step otherwise
+__device__ __forceinline__ u64 lm_mont_reduce_wide(u64 lo, u64 hi, u64 q, u64 qneg, u64 qinv64, uint32_t terms) {
+    u64 m = lo * qneg;
+    u64 carry = lo != 0;
+    u64 r = hi + lm_mulhi(m, q) + carry;
+    if (terms > 7) return lm_reduce(r, q, qinv64);
+    r = lm_csub(r, 4 * q);
+    r = lm_csub(r, 2 * q);
+    return lm_csub(r, q);
+}
+
 // per-modulus constants, passed by value to kernels
 struct mod_t {
     u64 q;

@@ -105,15 +105,10 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
     const u64 *s0 = coef + ((size_t)b * L + d * K) * N;
     const u64 *s1 = c.ns == 2 ? s0 + N : s0; // second limb of the digit
     auto ld = [&](uint32_t i) { return bx_apply(c, s0[i], s1[i], qc); };
-    // the extended digit is left in [0, 3q): beta * 3q * q < q * 2^64, so the gadget product's
-    // 128-bit accumulation and its single Montgomery reduction still hold
-    auto st = [&](uint32_t i0, const u64 *v, int count) {
-        u64 rr[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (k < count) rr[k] = lm_shoup3<true>(v[k], 1ull, qc.qinv64, qc.nq);
-        lm_store_run(o, i0, rr, count);
-    };
+    // the extended digit is stored as it leaves the last butterfly (any value below 2^64): the gadget
+    // product accumulates beta products x * k, k < q, in 128 bits (beta * 2^64 * q < 2^127: at most
+    // 12 digits of moduli below 2^58.4) and its reduction takes any such sum
+    auto st = [&](uint32_t i0, const u64 *v, int count) { lm_store_run(o, i0, v, count); };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);
 }
 
@@ -148,6 +143,60 @@ struct mac_vec<2> {
         *reinterpret_cast<ulonglong2 *>(p) = a;
     }
 };
+// One accumulator of the gadget product: sum of 64x64-bit products kept as three 64-bit columns
+// (weights 1, 2^32, 2^64) plus counters of the carries out of the first two, so that a product costs
+// four multiply-adds and three add-with-carry -- the compiler's 128-bit accumulate costs ~29
+// instructions, and this kernel is co-limited by VALU issue and HBM.
+// The third column only takes x1 * k1 with k < q < 2^58.4: no carry for up to 32 terms.
+struct mac_acc {
+    u64 a0, a1, a3;
+    u32 c0, c1;
+    __device__ __forceinline__ void clear() { a0 = a1 = a3 = 0, c0 = c1 = 0; }
+    __device__ __forceinline__ void value(u64 &lo, u64 &hi) const {
+        lo = a0 + (a1 << 32);
+        hi = a3 + c0 + (a1 >> 32) + ((u64)c1 << 32) + (lo < a0 ? 1 : 0);
+    }
+};
+// p += x * k0, q += x * k1 (the two polynomials of the key share the digit x).  gfx950 needs two
+// wait states between a VALU write of an SGPR pair (a carry) and the VALU read of it.
+__device__ __forceinline__ void mac2(mac_acc &p, mac_acc &q, u64 x, u64 k0, u64 k1) {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+#if LM_ASM_SHOUP
+    asm("v_mad_u64_u32 %[pa0], s[98:99], %[x0], %[k00], %[pa0]\n\t"
+        "v_mad_u64_u32 %[qa0], s[100:101], %[x0], %[k10], %[qa0]\n\t"
+        "v_mad_u64_u32 %[pa1], s[94:95], %[x0], %[k01], %[pa1]\n\t"
+        "v_addc_co_u32_e64 %[pc0], s[96:97], %[pc0], 0, s[98:99]\n\t"
+        "v_mad_u64_u32 %[qa1], s[92:93], %[x0], %[k11], %[qa1]\n\t"
+        "v_addc_co_u32_e64 %[qc0], s[96:97], %[qc0], 0, s[100:101]\n\t"
+        "v_mad_u64_u32 %[pa3], s[96:97], %[x1], %[k01], %[pa3]\n\t"
+        "v_addc_co_u32_e64 %[pc1], s[96:97], %[pc1], 0, s[94:95]\n\t"
+        "v_mad_u64_u32 %[pa1], s[98:99], %[x1], %[k00], %[pa1]\n\t"
+        "v_addc_co_u32_e64 %[qc1], s[96:97], %[qc1], 0, s[92:93]\n\t"
+        "v_mad_u64_u32 %[qa1], s[100:101], %[x1], %[k10], %[qa1]\n\t"
+        "v_mad_u64_u32 %[qa3], s[96:97], %[x1], %[k11], %[qa3]\n\t"
+        "v_addc_co_u32_e64 %[pc1], s[96:97], %[pc1], 0, s[98:99]\n\t"
+        "v_addc_co_u32_e64 %[qc1], s[96:97], %[qc1], 0, s[100:101]"
+        : [pa0] "+v"(p.a0), [pa1] "+v"(p.a1), [pa3] "+v"(p.a3), [pc0] "+v"(p.c0), [pc1] "+v"(p.c1),
+          [qa0] "+v"(q.a0), [qa1] "+v"(q.a1), [qa3] "+v"(q.a3), [qc0] "+v"(q.c0), [qc1] "+v"(q.c1)
+        : [x0] "v"(x0), [x1] "v"(x1), [k00] "v"((u32)k0), [k01] "v"((u32)(k0 >> 32)), [k10] "v"((u32)k1),
+          [k11] "v"((u32)(k1 >> 32))
+        : "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101");
+#else
+    auto one = [&](mac_acc &r, u64 k) {
+        const u32 k0w = (u32)k, k1w = (u32)(k >> 32);
+        u64 t = r.a0 + (u64)x0 * k0w;
+        r.c0 += t < r.a0, r.a0 = t;
+        t = r.a1 + (u64)x0 * k1w;
+        r.c1 += t < r.a1, r.a1 = t;
+        t = r.a1 + (u64)x1 * k0w;
+        r.c1 += t < r.a1, r.a1 = t;
+        r.a3 += (u64)x1 * k1w;
+    };
+    one(p, k0);
+    one(q, k1);
+#endif
+}
+
 __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, const u64 *__restrict__ acc,
                                                 const u64 *__restrict__ key, u64 *__restrict__ u, uint32_t B,
                                                 uint32_t L, uint32_t K, uint32_t beta, uint32_t logN,
@@ -174,26 +223,36 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
     if (i >= N) return;
     const mod_t md = mods.m[t];
     const uint32_t own = t < L ? t / K : 0xFFFFFFFFu; // digit whose limbs include t: its "extension" is c1 itself
-    u128 a0[LM_MAC_COLS][LM_MAC_VEC], a1[LM_MAC_COLS][LM_MAC_VEC];
+    mac_acc a0[LM_MAC_COLS][LM_MAC_VEC], a1[LM_MAC_COLS][LM_MAC_VEC];
 #pragma unroll
     for (int c = 0; c < LM_MAC_COLS; c++)
 #pragma unroll
-        for (int e = 0; e < LM_MAC_VEC; e++) a0[c][e] = 0, a1[c][e] = 0;
-    for (uint32_t d = 0; d < beta; d++) {
-        const vec k0 = vec::load(key + (((size_t)d * 2 + 0) * LK + t) * N + i);
-        const vec k1 = vec::load(key + (((size_t)d * 2 + 1) * LK + t) * N + i);
+        for (int e = 0; e < LM_MAC_VEC; e++) a0[c][e].clear(), a1[c][e].clear();
+    // columns past the end of the batch re-read the last one (never stored): all loads of a digit are
+    // then unconditional and issued together, one digit ahead of the multiply-adds that consume them
+    struct digit_t {
+        vec k0, k1, x[LM_MAC_COLS];
+    };
+    auto fetch = [&](uint32_t d) {
+        digit_t g;
+        g.k0 = vec::load(key + (((size_t)d * 2 + 0) * LK + t) * N + i);
+        g.k1 = vec::load(key + (((size_t)d * 2 + 1) * LK + t) * N + i);
 #pragma unroll
         for (int c = 0; c < LM_MAC_COLS; c++) {
-            if (b0 + c < B) {
-                const vec x = vec::load(d == own ? acc + ((size_t)((b0 + c) * 2 + 1) * L + t) * N + i
-                                                 : ext + (((size_t)(b0 + c) * beta + d) * LK + t) * N + i);
-#pragma unroll
-                for (int e = 0; e < LM_MAC_VEC; e++) {
-                    a0[c][e] += (u128)x.v[e] * k0.v[e];
-                    a1[c][e] += (u128)x.v[e] * k1.v[e];
-                }
-            }
+            const uint32_t bc = b0 + c < B ? b0 + c : B - 1;
+            g.x[c] = vec::load(d == own ? acc + ((size_t)(bc * 2 + 1) * L + t) * N + i
+                                        : ext + (((size_t)bc * beta + d) * LK + t) * N + i);
         }
+        return g;
+    };
+    digit_t cur = fetch(0);
+    for (uint32_t d = 0; d < beta; d++) {
+        const digit_t nxt = fetch(d + 1 < beta ? d + 1 : d);
+#pragma unroll
+        for (int c = 0; c < LM_MAC_COLS; c++)
+#pragma unroll
+            for (int e = 0; e < LM_MAC_VEC; e++) mac2(a0[c][e], a1[c][e], cur.x[c].v[e], cur.k0.v[e], cur.k1.v[e]);
+        cur = nxt;
     }
 #pragma unroll
     for (int c = 0; c < LM_MAC_COLS; c++) {
@@ -202,8 +261,11 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
             vec r0, r1;
 #pragma unroll
             for (int e = 0; e < LM_MAC_VEC; e++) {
-                r0.v[e] = lm_mont_reduce((u64)a0[c][e], (u64)(a0[c][e] >> 64), md.q, md.qneg);
-                r1.v[e] = lm_mont_reduce((u64)a1[c][e], (u64)(a1[c][e] >> 64), md.q, md.qneg);
+                u64 lo, hi;
+                a0[c][e].value(lo, hi);
+                r0.v[e] = lm_mont_reduce_wide(lo, hi, md.q, md.qneg, md.qinv64, beta);
+                a1[c][e].value(lo, hi);
+                r1.v[e] = lm_mont_reduce_wide(lo, hi, md.q, md.qneg, md.qinv64, beta);
             }
             r0.store(o);
             r1.store(o + (size_t)LK * N);

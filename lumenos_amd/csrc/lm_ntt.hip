@@ -2,17 +2,10 @@
 // (negacyclic, natural order in, bit-reversed evaluation order out, canonical
 // residues in and out -- SURVEY Appendix A.1).
 //
-// One workgroup owns one limb of one polynomial and keeps all N coefficients
-// in LDS (N*8 B = 32/64/128 KiB for N = 2^12/2^13/2^14, under the 160 KiB of a
-// gfx950 CU), so a transform reads and writes HBM exactly once: 16*N bytes.
-// Threads walk the log2(N) Cooley-Tukey stages three at a time: 8 coefficients
-// per work item live in VGPRs for three butterfly levels, then go back to LDS.
-// Butterflies are lazy (Shoup multiplication lands in [0,2q), sums are left to
-// grow: 58-bit moduli leave 6 bits of headroom, enough for 14 forward stages)
-// and are reduced to [0,q) once, on the way out.
-//
-// LDS index padding i + (i >> 5) spreads the stride-8 accesses of the last
-// pass (8 consecutive coefficients per lane) over all 64 banks.
+// One workgroup of N/16 threads owns one limb of one polynomial and keeps all N coefficients in LDS
+// (N*9 B with padding: 36/72/144 KiB for N = 2^12/2^13/2^14, under the 160 KiB of a gfx950 CU), so a
+// transform reads and writes HBM exactly once: 16*N bytes.  Pass structure, wave-owned blocks,
+// lazy butterflies and the hand-scheduled Shoup multiplication: lm_ntt_dev.h.
 #include "lm_ntt_dev.h"
 
 template <int LOGN, bool INV>

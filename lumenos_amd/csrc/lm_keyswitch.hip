@@ -9,7 +9,7 @@
 //      other Q limb and to the P limbs with the float64-corrected RNS
 //      reconstruction, NTT each extended limb (own limbs reuse the NTT values)
 //   3. (u0,u1) = sum_d digit_d (.) evk_d  over all L+K limbs
-//   4. ModDown: INTT the P limbs, extend P -> Q, NTT, (u_Q - lift) * P^-1
+//   4. ModDown: INTT the P limbs, extend P -> Q, NTT, (u_Q - lift) * P^-1  (P^-1 pre-folded into the key)
 //   5. add c0, permute both polynomials by the automorphism table, accumulate.
 // Everything but the correction term v is exact modular arithmetic; v is
 // computed in IEEE double exactly as the oracle does (this file is compiled
@@ -309,9 +309,10 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (k < count) {
-                // (u - lift) * P^-1 with the lift only lazily reduced: u + 3q - lift' < 4q
-                const u64 lift = lm_shoup3<true>(v[k], 1ull, qc.qinv64, qc.nq);
-                u64 x = lm_shoup_cs(uv[k] + qc.q3 - lift, pi, qc.q, qc.nq);
+                // u' - lift * P^-1 (u' = u * P^-1 comes out of the gadget product, see
+                // lumen_load_galois_key); the multiplication takes the unreduced lift: < 4q
+                u64 x = uv[k] + qc.q3 - lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq);
+                x = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
                 if (w == 0) x = lm_addmod(x, cv[k], qc.q);
                 sm[LM_PAD(i0 + k)] = x; // the slots this work item just consumed
             }
@@ -627,13 +628,20 @@ extern "C" int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint
              (unsigned long long)gal_el);
     const uint32_t beta = (L + K - 1) / K;
     const size_t words = (size_t)beta * 2 * LK * N;
-    // to Montgomery form on the host (one-off per key)
+    // to Montgomery form on the host (one-off per key).  The Q limbs also absorb P^-1 mod q_t: the
+    // gadget product then yields u * P^-1 directly and ModDown is u' - lift * P^-1, one multiplication
+    // on the unreduced lift (exact: (sum x*k) * P^-1 == sum x * (k * P^-1) mod q_t)
     std::vector<u64> mont(words);
     for (uint32_t d = 0; d < beta; d++)
         for (uint32_t w = 0; w < 2; w++)
             for (uint32_t t = 0; t < LK; t++) {
                 const uint64_t q = ctx->mod[t];
-                const uint64_t r = (uint64_t)((((u128)1) << 64) % q);
+                uint64_t r = (uint64_t)((((u128)1) << 64) % q);
+                if (t < L) {
+                    uint64_t P = 1;
+                    for (uint32_t a = 0; a < K; a++) P = h_mulmod(P, ctx->mod[L + a] % q, q);
+                    r = h_mulmod(r, h_invmod(P, q), q);
+                }
                 const size_t off = (((size_t)d * 2 + w) * LK + t) * N;
                 for (uint32_t k = 0; k < N; k++) {
                     const uint64_t x = evk[off + k];

@@ -129,10 +129,9 @@ class Job:
         # ---- Commit: leaves (fhe/ligero.go:126-183) on this rank's columns
         lvl1 = ctx.rescale(mine, 2)
         mine.free()
-        dig = ctx.leaf_digests(lvl1)
-        if dist is not None and self.world > 1:
-            dig = all_gather_digests(dist, dig, my_cols, self.S, self.world)
-        nodes, root = ctx.merkle_build(dig)  # core/tree.go:113-163
+        # the leaves are hashed on a side stream while the inner products run: Prove samples r without
+        # the root in the transcript (fhe/ligero.go:198-199), so nothing below depends on them
+        ctx.leaf_digests_begin(lvl1)
         # ---- Prove: <r, M> and <b, M> (fhe/ligero.go:231-242, 299-370) on this rank's columns
         cols = self.matrix.slice(self.col_lo, self.col_hi - self.col_lo)
         mat_r = ctx.matrix_inner_sum(cols, self.r_pt, self.rows)
@@ -143,6 +142,11 @@ class Job:
             ctx.ring_switch(mat_z)
         # ---- Prove: query columns (fhe/ligero.go:261-280): already at level 1 from Commit
         q = ctx.gather(lvl1, owned_queries(self.query_idx, my_cols))
+        # ---- Commit, concluded: digests -> (all-gather) -> Merkle tree (core/tree.go:113-163)
+        dig = ctx.leaf_digests_end()
+        if dist is not None and self.world > 1:
+            dig = all_gather_digests(dist, dig, my_cols, self.S, self.world)
+        nodes, root = ctx.merkle_build(dig)
         ctx.sync()
         for s in (q, mat_r, mat_z, lvl1):
             s.free()

@@ -114,6 +114,13 @@ int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t target_limbs, lu
  * (ct.WriteTo, fhe/ligero.go:156-157) and SHA-256 it (core/tree.go:96-111).
  * digests: host buffer, count*32 bytes. */
 int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8_t *digests);
+/* The same, split in two so that the caller can overlap it with the inner products: Prove does
+ * not write the root to the transcript before sampling r (fhe/ligero.go:198-199), so nothing of
+ * matrixInnerSumEval depends on the leaves.  _begin enqueues the hashing of `level1` on a side
+ * stream of the context, behind everything already enqueued, and returns; `level1` must stay alive
+ * and unmodified until _end, which waits and writes count*32 bytes.  One job in flight per context. */
+int lumen_leaf_digests_begin(lumen_ctx *ctx, const lumen_set *level1);
+int lumen_leaf_digests_end(lumen_ctx *ctx, uint8_t *digests);
 /* core.NewTree over leaf digests (core/tree.go:113-163): nodes = all levels,
  * bottom-up, (returns node count through n_nodes); root: 32 bytes. */
 int lumen_merkle_build(lumen_ctx *ctx, const uint8_t *leaf_digests, uint32_t n_leaves,

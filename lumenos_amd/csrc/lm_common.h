@@ -53,6 +53,11 @@ struct lumen_ctx {
     hipStream_t stream = nullptr;  // where every entry point enqueues (may be swapped to stream2 internally)
     hipStream_t stream2 = nullptr; // second lane for independent column batches (key-switch pipeline)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream_aux = nullptr; // side jobs that overlap the main stream (leaf hashing)
+    hipEvent_t ev_aux = nullptr;
+    uint32_t aux_digests = 0;         // leaves of the lumen_leaf_digests_begin job in flight
+    uint8_t *aux_host = nullptr;      // pinned staging of its digests
+    size_t aux_host_cap = 0;
     uint32_t logN = 0, N = 0, L = 0, K = 0;
     uint64_t T = 0;
     uint64_t mod[LM_MAX_LIMBS] = {0};

@@ -123,6 +123,8 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
     LM_HIP(ctx, hipStreamCreate(&ctx->stream2));
     LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    LM_HIP(ctx, hipStreamCreate(&ctx->stream_aux));
+    LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
     ctx->logN = desc->log_n;
     ctx->N = 1u << desc->log_n;
     ctx->L = desc->num_q;
@@ -192,6 +194,10 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
     hipEventDestroy(ctx->tm0);
     hipEventDestroy(ctx->tm1);
+    if (ctx->stream_aux) hipStreamSynchronize(ctx->stream_aux);
+    if (ctx->aux_host) hipHostFree(ctx->aux_host);
+    hipEventDestroy(ctx->ev_aux);
+    hipStreamDestroy(ctx->stream_aux);
     hipEventDestroy(ctx->ev_fork);
     hipEventDestroy(ctx->ev_join);
     hipStreamDestroy(ctx->stream2);

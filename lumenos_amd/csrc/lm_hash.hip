@@ -136,6 +136,49 @@ extern "C" int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8
     return 0;
 }
 
+extern "C" int lumen_leaf_digests_begin(lumen_ctx *ctx, const lumen_set *level1) {
+    LM_CHECK(nullptr, ctx && level1, "lumen_leaf_digests_begin: NULL argument");
+    LM_CHECK(ctx, !ctx->aux_digests, "a lumen_leaf_digests_begin job is already in flight");
+    if (!level1->count) return 0;
+    const size_t words = (size_t)2 * level1->nl * ctx->N, bytes = (size_t)level1->count * 32;
+    LM_CHECK(ctx, words >= 6, "ciphertext too small to serialise");
+    uint8_t *dd = (uint8_t *)lm_scratch(ctx, "digests_async", bytes);
+    if (!dd) return 1;
+    if (ctx->aux_host_cap < bytes) {
+        if (ctx->aux_host) LM_HIP(ctx, hipHostFree(ctx->aux_host));
+        ctx->aux_host = nullptr, ctx->aux_host_cap = 0;
+        LM_HIP(ctx, hipHostMalloc((void **)&ctx->aux_host, bytes, hipHostMallocDefault));
+        ctx->aux_host_cap = bytes;
+    }
+    // the side stream starts behind the work that produces `level1`
+    LM_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
+    LM_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_aux, 0));
+    {
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->stream_aux; // profiling events of this scope belong on the side stream
+        {
+            lm_prof_scope ps(ctx, "leaf_sha256", level1->count);
+            hipLaunchKernelGGL(k_leaf_sha256, dim3((level1->count + 63) / 64), dim3(64), 0, ctx->stream_aux,
+                               level1->d, words, level1->count, level1->nl, ctx->N, dd);
+        }
+        ctx->stream = main_stream;
+        LM_HIP(ctx, hipGetLastError());
+    }
+    LM_HIP(ctx, hipMemcpyAsync(ctx->aux_host, dd, bytes, hipMemcpyDeviceToHost, ctx->stream_aux));
+    ctx->aux_digests = level1->count;
+    return 0;
+}
+
+extern "C" int lumen_leaf_digests_end(lumen_ctx *ctx, uint8_t *digests) {
+    LM_CHECK(nullptr, ctx && digests, "lumen_leaf_digests_end: NULL argument");
+    LM_CHECK(ctx, ctx->aux_digests, "no lumen_leaf_digests_begin job in flight");
+    const uint32_t n = ctx->aux_digests;
+    ctx->aux_digests = 0;
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+    memcpy(digests, ctx->aux_host, (size_t)n * 32);
+    return 0;
+}
+
 static void host_sha256_64(const uint8_t in[64], uint8_t out[32]) {
     // SHA-256 of exactly 64 bytes (two child digests): one data block + one padding block
     u32 h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};

@@ -60,6 +60,8 @@ SYMBOLS = {
     "lumen_encode_shard": (C.c_int, [_vp, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, _vpp, _u32p, _u32p]),
     "lumen_rescale": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
     "lumen_leaf_digests": (C.c_int, [_vp, _vp, _u8p]),
+    "lumen_leaf_digests_begin": (C.c_int, [_vp, _vp]),
+    "lumen_leaf_digests_end": (C.c_int, [_vp, _u8p]),
     "lumen_merkle_build": (C.c_int, [_vp, _u8p, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t), _u8p]),
     "lumen_load_galois_key": (C.c_int, [_vp, C.c_uint64, _u64p]),
     "lumen_inner_sum_galois_elements": (C.c_uint32, [_vp, C.c_uint32, _u64p]),
@@ -185,6 +187,8 @@ class Context:
         self.L, self.K = len(q), len(p)
         self.q, self.p, self.T = list(q), list(p), plaintext_modulus
 
+    _pending_leaves = 0
+
     def _ck(self, rc):
         if rc:
             raise LumenError(self.lib.lumen_last_error(self.h).decode())
@@ -241,6 +245,19 @@ class Context:
     def leaf_digests(self, s):
         out = np.zeros((s.count, 32), dtype=np.uint8)
         self._ck(self.lib.lumen_leaf_digests(self.h, s.h, out.ctypes.data_as(_u8p)))
+        return out
+
+    def leaf_digests_begin(self, s):
+        """Start hashing the leaves of `s` on the context's side stream (overlaps later calls)."""
+        self._pending_leaves = s.count
+        if s.count:
+            self._ck(self.lib.lumen_leaf_digests_begin(self.h, s.h))
+
+    def leaf_digests_end(self):
+        out = np.zeros((self._pending_leaves, 32), dtype=np.uint8)
+        if self._pending_leaves:
+            self._ck(self.lib.lumen_leaf_digests_end(self.h, out.ctypes.data_as(_u8p)))
+        self._pending_leaves = 0
         return out
 
     def merkle_build(self, digests):

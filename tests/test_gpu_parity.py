@@ -87,6 +87,20 @@ def test_rescale_matches_oracle(oracle, small):
             assert np.array_equal(got[c], ref), (target, c)
 
 
+def test_leaf_digests_async_matches_sync(small):
+    """lumen_leaf_digests_begin/_end (side stream, overlapped with later work) == lumen_leaf_digests."""
+    P, ctx = small
+    s = ctx.new_set(37, 2).fill_random(11)
+    want = ctx.leaf_digests(s)
+    ctx.leaf_digests_begin(s)
+    other = ctx.new_set(8, 2).fill_random(12)  # unrelated work on the main stream meanwhile
+    ctx.set_ntt(other, False)
+    got = ctx.leaf_digests_end()
+    assert np.array_equal(got, want)
+    other.free()
+    s.free()
+
+
 def test_leaf_digests_and_merkle(oracle, small):
     P, ctx = small
     cts = random_cts(P, 37, 2, seed=31)  # odd count: unpaired node duplicated (tree.go:127-131)

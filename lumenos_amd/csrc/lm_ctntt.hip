@@ -29,7 +29,7 @@
 #include <cstring>
 #include <numeric>
 
-#include "lm_common.h"
+#include "lm_ntt_dev.h"
 
 #define LM_CT_GROUP 128 // max slots per component (LDS tile = GROUP * W * 8 B)
 #define LM_CT_W 32      // lanes per tile
@@ -353,17 +353,37 @@ struct ct_pass_args {
     size_t ctw;
 };
 
+// One workgroup = one component (group of <= LM_CT_GROUP slots) x one tile of W lanes.  The group's
+// op list and layer table are staged in LDS next to the tile: fetched from global memory inside the
+// layers, each op word sat on the critical path of its butterfly (one L2 round trip per iteration).
+// Values stay in [0, 2q) between layers (one conditional subtraction of 2q per result, decided on the
+// sign of the upper word) and are made canonical on the way out.
+// Measured at 16384x4096 (tools/encode_only.py): 70.8 ms per Encode with the ops in global memory,
+// 57.7 ms staged; moving the tiles alone (no layers) takes 32.7 ms.  Also tried: 4 tiles per workgroup
+// with the next tile prefetched into registers (58.8 ms: the registers cost the occupancy the
+// prefetch buys), scalars staged in LDS and ops batched 4 at a time (71 ms).
+__device__ __forceinline__ u64 ct_csub2q(u64 v, u64 n2q) { // v < 4q -> [0, 2q); n2q = 2^64 - 2q
+    const u64 t = v + n2q;
+    return (int32_t)(t >> 32) < 0 ? v : t;
+}
 __global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mods mods) {
-    extern __shared__ __attribute__((aligned(16))) u64 buf[]; // [gsize][W]
+    extern __shared__ __attribute__((aligned(16))) u64 buf[]; // [gsize][W] coefficients | ops [total] | layers
     const uint32_t tid = threadIdx.x, l = tid % LM_CT_W, r = tid / LM_CT_W;
     constexpr uint32_t R = LM_CT_THREADS / LM_CT_W;
     const uint32_t group = blockIdx.y + a.group0;
     const size_t lane = (size_t)blockIdx.x * LM_CT_W + l;
-    const uint32_t limb = (uint32_t)((lane >> a.logN) % a.nl);
-    const u64 q = mods.m[limb].q;
+    // tiles are aligned runs of W <= N lanes: the limb is uniform in the workgroup
+    const uint32_t limb = (uint32_t)(((size_t)blockIdx.x * LM_CT_W) >> a.logN) % a.nl;
+    const u64 q = mods.m[limb].q, q2 = 2 * q, n2q = 0 - q2;
     const tw_t *scal = a.scal + (size_t)limb * a.fieldN1;
     const uint32_t *slots = a.slots + (size_t)group * a.gsize;
-
+    uint32_t *ops = reinterpret_cast<uint32_t *>(buf + (size_t)a.gsize * LM_CT_W);
+    uint32_t *layer = ops + a.total;
+    {
+        const uint32_t *gops = a.ops + (size_t)group * a.total;
+        for (uint32_t i = tid; i < a.total; i += LM_CT_THREADS) ops[i] = gops[i];
+        for (uint32_t i = tid; i < 3 * a.nlayers; i += LM_CT_THREADS) layer[i] = a.layer[i];
+    }
     for (uint32_t s = r; s < a.gsize; s += R) {
         const uint32_t slot = slots[s];
         if (slot == LM_NOSLOT) continue;
@@ -371,22 +391,22 @@ __global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mo
         buf[s * LM_CT_W + l] = src[lane];
     }
     __syncthreads();
-    const uint32_t *ops = a.ops + (size_t)group * a.total;
     for (uint32_t ly = 0; ly < a.nlayers; ly++) {
-        const uint32_t off = a.layer[3 * ly], nb = a.layer[3 * ly + 1], nm = a.layer[3 * ly + 2];
+        const uint32_t off = layer[3 * ly], nb = layer[3 * ly + 1], nm = layer[3 * ly + 2];
         for (uint32_t i = r; i < nb; i += R) {
             const uint32_t op = ops[off + i];
             if (op == LM_NOSLOT) continue;
             const uint32_t ia = (op & 0xFFFF) * LM_CT_W + l, ib = (op >> 16) * LM_CT_W + l;
             const u64 x = buf[ia], y = buf[ib];
-            buf[ia] = lm_addmod(x, y, q); // Evaluator.Add
-            buf[ib] = lm_submod(x, y, q); // Evaluator.Sub
+            buf[ia] = ct_csub2q(x + y, n2q);      // Evaluator.Add
+            buf[ib] = ct_csub2q(x + q2 - y, n2q); // Evaluator.Sub
         }
         for (uint32_t i = r; i < nm; i += R) {
             const uint32_t op = ops[off + nb + i];
             if (op == LM_NOSLOT) continue;
             const uint32_t ia = (op & 0xFF) * LM_CT_W + l;
-            buf[ia] = lm_shoup(buf[ia], scal[op >> 8], q); // Evaluator.Mul(ct, uint64)
+            const tw_t sc = scal[op >> 8];
+            buf[ia] = ct_csub2q(lm_shoup3_c(buf[ia], sc.w, sc.wp, 0 - q), n2q); // Evaluator.Mul(ct, uint64): < 3q
         }
         __syncthreads();
     }
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mo
         const uint32_t slot = slots[s];
         if (slot == LM_NOSLOT) continue;
         const uint32_t pos = a.out_pos ? a.out_pos[slot] : slot;
-        a.dst[(size_t)pos * a.ctw + lane] = buf[s * LM_CT_W + l];
+        a.dst[(size_t)pos * a.ctw + lane] = lm_csub(buf[s * LM_CT_W + l], q);
     }
 }
 
@@ -424,7 +444,7 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
         a.fieldN1 = ctx->fieldN + 1, a.logN = ctx->logN, a.nl = nl, a.ctw = ctw;
         const uint32_t ng = final_pass && final_ng ? final_ng : d.ngroups;
         dim3 grid((uint32_t)(ctw / LM_CT_W), ng);
-        size_t lds = (size_t)d.gsize * LM_CT_W * sizeof(u64);
+        size_t lds = (size_t)d.gsize * LM_CT_W * sizeof(u64) + ((size_t)d.total + 3 * d.nlayers) * sizeof(uint32_t);
         lm_prof_scope ps(ctx, "ct_axis_pass", (uint64_t)ng * d.gsize);
         hipLaunchKernelGGL(k_ct_pass, grid, dim3(LM_CT_THREADS), lds, ctx->stream, a, ctx->mods);
         LM_HIP(ctx, hipGetLastError());

@@ -129,6 +129,25 @@ __device__ __forceinline__ u64 lm_keep(u64 x) {
     "v_add_u32 v87, v87, v88\n\t"                                    /* hi(lo') += up            */           \
     "v_mad_u64_u32 %[o], s[96:97], v84, %[n0], v[86:87]"              /* {lo', upper} + t0*n0     */
 
+// compiler-scheduled form of the same chain (no pinned registers): for kernels whose occupancy must
+// not be tied to the v[80:89] temporaries of the hand-scheduled one
+__device__ __forceinline__ u64 lm_shoup3_c(u64 a, u64 w, u64 wp, u64 nq, u64 x = 0) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
+    const u32 w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    const u64 m1 = (u64)a0 * p1;
+    const u64 m2 = lm_keep((u64)a1 * p0 + (u32)m1);
+    const u64 t = (u64)a1 * p1 + (m1 >> 32) + (m2 >> 32);
+    const u32 t0 = (u32)t, t1 = (u32)(t >> 32);
+    // everything below is arithmetic mod 2^64: partial sums may wrap
+    const u64 lo = lm_keep((u64)a0 * w0 + x) + (u64)t0 * n0;
+    u64 acc = (u64)a0 * w1 + (lo >> 32);
+    acc += (u64)a1 * w0;
+    acc += (u64)t0 * n1;
+    acc += (u64)t1 * n0;
+    acc = lm_keep(acc);
+    return (acc << 32) | (u32)lo;
+}
+
 template <bool UW>
 __device__ __forceinline__ u64 lm_shoup3(u64 a, u64 w, u64 wp, u64 nq, u64 x) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
@@ -149,18 +168,7 @@ __device__ __forceinline__ u64 lm_shoup3(u64 a, u64 w, u64 wp, u64 nq, u64 x) {
             : LM_SHOUP_CLOBBERS);
     return o;
 #else
-    const u64 m1 = (u64)a0 * p1;
-    const u64 m2 = lm_keep((u64)a1 * p0 + (u32)m1);
-    const u64 t = (u64)a1 * p1 + (m1 >> 32) + (m2 >> 32);
-    const u32 t0 = (u32)t, t1 = (u32)(t >> 32);
-    // everything below is arithmetic mod 2^64: partial sums may wrap
-    const u64 lo = lm_keep((u64)a0 * w0 + x) + (u64)t0 * n0;
-    u64 acc = (u64)a0 * w1 + (lo >> 32);
-    acc += (u64)a1 * w0;
-    acc += (u64)t0 * n1;
-    acc += (u64)t1 * n0;
-    acc = lm_keep(acc);
-    return (acc << 32) | (u32)lo;
+    return lm_shoup3_c(a, w, wp, nq, x);
 #endif
 }
 template <bool UW>

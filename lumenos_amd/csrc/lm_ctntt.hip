@@ -32,7 +32,9 @@
 #include "lm_ntt_dev.h"
 
 #define LM_CT_GROUP 128 // max slots per component (LDS tile = GROUP * W * 8 B)
+#ifndef LM_CT_W
 #define LM_CT_W 32      // lanes per tile
+#endif
 #define LM_CT_THREADS 512
 #define LM_NOSLOT 0xFFFFFFFFu
 
@@ -445,6 +447,7 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
         const uint32_t ng = final_pass && final_ng ? final_ng : d.ngroups;
         dim3 grid((uint32_t)(ctw / LM_CT_W), ng);
         size_t lds = (size_t)d.gsize * LM_CT_W * sizeof(u64) + ((size_t)d.total + 3 * d.nlayers) * sizeof(uint32_t);
+        LM_LDS_ATTR(ctx, k_ct_pass, lds);
         lm_prof_scope ps(ctx, "ct_axis_pass", (uint64_t)ng * d.gsize);
         hipLaunchKernelGGL(k_ct_pass, grid, dim3(LM_CT_THREADS), lds, ctx->stream, a, ctx->mods);
         LM_HIP(ctx, hipGetLastError());

@@ -35,6 +35,17 @@ static uint32_t ks_batch() { // LUMEN_KS_BATCH overrides the default (tuning kno
     return v;
 }
 
+// 64 x 64 -> 128-bit product as four 32x32+64 multiply-adds (the compiler's __int128 multiply goes
+// through v_mul_lo/hi_u32, twice as slow each)
+__device__ __forceinline__ void mul128(u64 a, u64 b, u64 &lo, u64 &hi) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0;
+    const u64 p1 = lm_keep((u64)a0 * b1 + (p0 >> 32));
+    const u64 p2 = lm_keep((u64)a1 * b0 + (u32)p1);
+    hi = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    lo = (p2 << 32) | (u32)p0;
+}
+
 // v = uint64(float64(y0)/float64(m0) + float64(y1)/float64(m1))  ([LATTIGO-RECALL] reconstructRNS).
 // The double expression is within 2^-49 of S = A / M, A = y0*m1 + y1*m0, M = m0*m1, and S < 2: unless
 // S is that close to 1 or to 2 its truncation equals [S >= 1], which is decided exactly in 128-bit
@@ -50,23 +61,40 @@ __device__ __forceinline__ u32 bx_v(u128 A, u128 M, u64 y0, u64 y1, u64 m0, u64 
 
 // (y0, y1)[b][i] -> (hi, lo) of W = y0*m1 + y1*m0 + (2 - v)*M for every two-limb source group
 // (lm_ks_dev.h).  y: [npoly][stride] with the group's two limbs at limb offsets lo, lo+1.
-__global__ void k_pack_v(u64 *__restrict__ y, size_t poly_stride, uint32_t npoly, uint32_t ngroups,
-                         uint32_t group_limbs, uint32_t first_mod, uint32_t nlimbs_total, uint32_t logN,
-                         lm_mods mods) {
+// One thread per PAIR of coefficients (16-byte accesses); the group is uniform per workgroup row.
+__global__ __launch_bounds__(256) void k_pack_v(u64 *__restrict__ y, size_t poly_stride, uint32_t npoly,
+                                                uint32_t ngroups, uint32_t group_limbs, uint32_t first_mod,
+                                                uint32_t nlimbs_total, uint32_t logN, lm_mods mods) {
     const uint32_t N = 1u << logN;
-    const size_t total = (size_t)npoly * ngroups * N, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t total = (size_t)npoly * ngroups * (N / 2), stride = (size_t)gridDim.x * blockDim.x;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const uint32_t i = (uint32_t)(g & (N - 1));
-        const uint32_t grp = (uint32_t)((g >> logN) % ngroups), p = (uint32_t)((g >> logN) / ngroups);
+        const uint32_t i = (uint32_t)(g & (N / 2 - 1)) * 2;
+        const uint32_t grp = (uint32_t)((g >> (logN - 1)) % ngroups), p = (uint32_t)((g >> (logN - 1)) / ngroups);
         const uint32_t l0 = grp * group_limbs;
         if (l0 + 1 >= nlimbs_total) continue; // single-limb group: nothing to reconstruct
         u64 *y0 = y + (size_t)p * poly_stride + (size_t)l0 * N + i;
-        const u64 a = *y0, b = y0[N];
+        const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(y0);
+        const ulonglong2 bv = *reinterpret_cast<const ulonglong2 *>(y0 + N);
         const u64 m0 = mods.m[first_mod + l0].q, m1 = mods.m[first_mod + l0 + 1].q;
-        const u128 A = (u128)a * m1 + (u128)b * m0, M = (u128)m0 * m1;
-        const u128 W = A + (u128)(2u - bx_v(A, M, a, b, m0, m1)) * M; // v <= 2
-        *y0 = (u64)(W >> LM_W_SPLIT);
-        y0[N] = (u64)W & ((1ull << LM_W_SPLIT) - 1);
+        u64 Ml, Mh;
+        mul128(m0, m1, Ml, Mh);
+        const u128 M = ((u128)Mh << 64) | Ml;
+        ulonglong2 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const u64 a = e ? av.y : av.x, b = e ? bv.y : bv.x;
+            u64 l1, h1, l2, h2;
+            mul128(a, m1, l1, h1);
+            mul128(b, m0, l2, h2);
+            const u128 A = (((u128)h1 << 64) | l1) + (((u128)h2 << 64) | l2);
+            const u32 v = bx_v(A, M, a, b, m0, m1);
+            const u128 W = A + (v == 0 ? 2 * M : (v == 1 ? M : (u128)0)); // + (2 - v) * M, v <= 2
+            const u64 hi = (u64)(W >> LM_W_SPLIT), lo = (u64)W & ((1ull << LM_W_SPLIT) - 1);
+            if (e) hv.y = hi, lv.y = lo;
+            else hv.x = hi, lv.x = lo;
+        }
+        *reinterpret_cast<ulonglong2 *>(y0) = hv;
+        *reinterpret_cast<ulonglong2 *>(y0 + N) = lv;
     }
 }
 

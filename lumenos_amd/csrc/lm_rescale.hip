@@ -109,7 +109,7 @@ static int get_rescale_tables(lumen_ctx *ctx, RescaleTables **out) {
             // (q_j, q_l < 2^58.4 by lumen_ctx_create, so M <= 2^58.4 / 2^20 only for absurd ratios:
             // refuse those)
             const uint64_t M = ql / qj + 1;
-            if (M > 16) return lm_fail(ctx, "rescale: moduli %u and %u differ by more than 16x", l, j);
+            if (M > 16) return 2; // moduli of very different sizes: the caller keeps the per-step form
             e.k = half + M * qj;
             e.inv = h_tw(h_invmod(ql % qj, qj), qj);
         }
@@ -181,8 +181,10 @@ template <int LOGN>
 static int rescale_polys_t(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
                            uint32_t npoly, u64 *work, u64 *tbuf) {
     // transforms per polynomial: per-step form sum_{l=target+1..nl} l, coefficient form nl + target
-    if (work && (uint64_t)(nl + target + 1) * (nl - target) / 2 > (uint64_t)nl + target)
-        return rescale_polys_coef(ctx, src, nl, dst, target, npoly, work);
+    if (work && (uint64_t)(nl + target + 1) * (nl - target) / 2 > (uint64_t)nl + target) {
+        const int rc = rescale_polys_coef(ctx, src, nl, dst, target, npoly, work);
+        if (rc != 2) return rc; // 2: no coefficient-form tables for this modulus chain
+    }
     const uint32_t N = ctx->N;
     const size_t lds_i = lm_inv_lds(ctx->logN), lds_f = lm_fwd_lds(ctx->logN);
     const uint32_t thr_i = lm_inv_threads(ctx->logN), thr_f = lm_fwd_threads(ctx->logN);

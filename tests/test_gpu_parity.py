@@ -334,3 +334,104 @@ def test_ring_switch_matches_oracle(oracle, log_n, logn_small):
         assert np.array_equal(P.decrypt_small_coeffs(sk_small, logn_small, got[c]),
                               P.decrypt_big_coeffs_l0(sk, cts[c])[::gap])
     ctx.close()
+
+
+# ------------------------------------------------------------------ lazy-arithmetic headroom
+def _ntt_primes_near(limit, two_n, count, down=True):
+    """`count` primes == 1 mod 2N just below (or from) `limit`."""
+    from lumenos_amd import params as lp
+    p = limit - ((limit - 1) % two_n) if down else limit + ((1 - limit) % two_n)
+    out = []
+    while len(out) < count:
+        if lp.is_prime(p):
+            out.append(p)
+        p += -two_n if down else two_n
+    return out
+
+
+def _adversarial_cts(P, nl, seed):
+    """Rows: all q-1, all 0, alternating q-1/0, single spike, uniform random."""
+    cts = random_cts(P, 3, nl, seed=seed)
+    for l in range(nl):
+        q = P.moduli[l]
+        cts[0, 0, l, :] = q - 1
+        cts[0, 1, l, :] = 0
+        cts[1, 0, l, ::2], cts[1, 0, l, 1::2] = q - 1, 0
+        cts[1, 1, l, :] = 0
+        cts[1, 1, l, P.N - 1] = q - 1
+    return cts
+
+
+@pytest.mark.parametrize("log_n", [10, 12, 13, 14])
+def test_limb_ntt_largest_moduli_adversarial_inputs(oracle, log_n):
+    """Moduli right under the context's bound (3*logN+8)*q < 2^64 and a 21-bit one, inputs that
+    maximise every lazy intermediate (all q-1): forward/inverse transforms stay bit-exact."""
+    from oracle.loader import Params
+    two_n = 2 << log_n
+    qmax = (2**64 - 1) // (3 * log_n + 8)
+    q = _ntt_primes_near(qmax, two_n, 2) + _ntt_primes_near(1 << 20, two_n, 1, down=False)
+    P = Params.from_moduli(oracle, log_n, q, [], T_REF)
+    ctx = make_context(P)
+    cts = _adversarial_cts(P, 3, seed=log_n)
+    s = ctx.upload(cts)
+    ctx.set_ntt(s, inverse=False)
+    got = s.download()
+    for c in range(3):
+        for k in range(2):
+            for l in range(3):
+                assert np.array_equal(got[c, k, l], P.limb_ntt(cts[c, k, l], l)), (c, k, l)
+    ctx.set_ntt(s, inverse=True)
+    assert np.array_equal(s.download(), cts)
+    s2 = ctx.upload(cts)
+    ctx.set_ntt(s2, inverse=True)
+    got = s2.download()
+    for c in range(2):
+        for l in range(3):
+            assert np.array_equal(got[c, 0, l], P.limb_intt(cts[c, 0, l], l)), (c, l)
+    ctx.close()
+
+
+def test_key_switch_and_rescale_largest_moduli(oracle):
+    """The whole evaluator chain (MulNew, InnerSum with its key switches, Rescale to level 1) on a
+    modulus chain right under the bound, with the adversarial rows among the inputs."""
+    from oracle.loader import Params
+    log_n, two_n = 10, 2 << 10
+    qmax = (2**64 - 1) // (3 * log_n + 8)
+    pr = _ntt_primes_near(qmax, two_n, 7)
+    P = Params.from_moduli(oracle, log_n, pr[:5], pr[5:], T_REF)
+    P.seed(5)
+    sk = P.keygen_secret()
+    ctx = make_context(P)
+    n = 16
+    gl = P.inner_sum_galois_elements(n)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    cts = _adversarial_cts(P, 5, seed=3)
+    pt = P.encode(np.arange(1, P.N + 1, dtype=np.uint64))
+    got = ctx.matrix_inner_sum(ctx.upload(cts), pt, n).download()
+    assert np.array_equal(got, P.matrix_inner_sum(cts, pt, n, evks))
+    lvl1 = ctx.rescale(ctx.upload(cts), 1).download()
+    for c in range(3):
+        ref = cts[c]
+        while ref.shape[1] > 1:
+            ref = P.rescale(ref)
+        assert np.array_equal(lvl1[c], ref), c
+    ctx.close()
+
+
+def test_rescale_mixed_size_moduli_falls_back(oracle):
+    """Moduli more than 16x apart have no coefficient-form tables: the per-step path answers."""
+    from oracle.loader import Params
+    log_n, two_n = 10, 2 << 10
+    q = _ntt_primes_near(1 << 58, two_n, 2) + _ntt_primes_near(1 << 30, two_n, 2, down=False)
+    P = Params.from_moduli(oracle, log_n, q, [], T_REF)
+    ctx = make_context(P)
+    cts = _adversarial_cts(P, 4, seed=8)
+    got = ctx.rescale(ctx.upload(cts), 1).download()
+    for c in range(3):
+        ref = cts[c]
+        while ref.shape[1] > 1:
+            ref = P.rescale(ref)
+        assert np.array_equal(got[c], ref), c
+    ctx.close()

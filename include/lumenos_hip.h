@@ -126,6 +126,18 @@ int lumen_leaf_digests_end(lumen_ctx *ctx, uint8_t *digests);
 int lumen_merkle_build(lumen_ctx *ctx, const uint8_t *leaf_digests, uint32_t n_leaves,
                        uint8_t *nodes, size_t nodes_cap, size_t *n_nodes, uint8_t *root);
 
+/* ---- server-side witness encryption: server.EncryptNew per column
+ * (cmd/server/main.go:199-208; fhe/bfv.go:13-58 holds the rlwe.Encryptor with the public key).
+ * pk: [2][L][N], NTT domain.  plaintexts: host, [count][L][N] NTT-domain RNS plaintexts as
+ * Encoder.Encode leaves them (m * T^-1 form), or NULL for encryptions of zero (fhe/code.go:21-25).
+ * The reference's encryption is randomised; this one is deterministic in (seed, first_index + i):
+ * ciphertext i draws its ternary u and Gaussian e0, e1 from ChaCha20(seed, first_index + i), so a
+ * column encrypts to the same bits on whichever GPU it lands.  out: new set of `count` ciphertexts
+ * at the top level. */
+int lumen_load_public_key(lumen_ctx *ctx, const uint64_t *pk);
+int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint32_t count, const uint8_t seed[32],
+                     uint64_t first_index, lumen_set **out);
+
 /* ---- Galois keys: rlwe.EvaluationKeySet entries used by InnerSum.
  * evk host layout [digit(beta)][b|a][limb(L+K)][N], NTT domain, standard form
  * (the Go shim converts from Lattigo's Montgomery-form GadgetCiphertext). */

@@ -1,0 +1,272 @@
+// Server-side witness encryption: server.EncryptNew per column
+// (cmd/server/main.go:199-208), i.e. rlwe.Encryptor under a public key at the top level
+// [LATTIGO-RECALL: encryptZero with pk, no P-extension]:
+//     c0 = u*pk0 + e0 + pt,   c1 = u*pk1 + e1
+// u ternary (P(-1) = P(1) = 1/3), e0/e1 discrete Gaussians of sigma 3.2 truncated at |e| <= 19.
+// The reference's encryption is RANDOMISED (PRNG keyed from crypto/rand): there are no reference
+// ciphertext bits to match; the contract is decryption and the error distribution.  The sampler here
+// is deterministic in (seed, ciphertext index) -- see oracle/lo_encdet.c for its definition, shared
+// bit for bit with the CPU checker -- so that any sharding of the columns over GPUs yields the same
+// ciphertexts:
+//     keystream(c, s) = ChaCha20(key = seed, nonce = LE64(c) || LE32(s), counter = block)
+//     u  coefficient k  <- word k of stream 0:  ((w * 3) >> 32) - 1
+//     e0/e1 coefficient k <- words 2k, 2k+1 of stream 1/2: r = w0 | w1 << 32, m = r >> 1,
+//         |e| = #{ i < 19 : m >= CDT[i] },  sign = r & 1.
+//
+// Two kernels: k_sample_small (one thread per ChaCha20 block -> int8 coefficients, 3N bytes per
+// ciphertext), k_encrypt_ntt (one workgroup per (ciphertext, limb): lift + NTT of e0, e1, u through
+// the LDS-resident limb transform, the pk products and the sums fused into the stores).
+#include <cstring>
+
+#include "lm_ntt_dev.h"
+
+struct enc_seed_t {
+    u32 k[8];
+};
+struct enc_cdt_t {
+    u64 t[19];
+};
+static const u64 H_GAUSS_CDT[19] = {
+    0x0ff52b40a5917f1dull, 0x2e5a25d4bf0e400eull, 0x489ae26955b04bd6ull, 0x5d2bc20f621bf185ull,
+    0x6bc8694c3cc80ff4ull, 0x7532d89ac6ba7dceull, 0x7ab396cb74436798ull, 0x7d9e4e916643eb07ull,
+    0x7f05495819eb2051ull, 0x7fa1ce9c0039a957ull, 0x7fdfb3f212e8c4e8ull, 0x7ff5e6f9d2314fccull,
+    0x7ffd1f97bc4406a2ull, 0x7fff40fa0088d11dull, 0x7fffd2e835e1c57dull, 0x7ffff6524386ff1eull,
+    0x7ffffe1db4769da5ull, 0x7fffffac0a1dcb08ull, 0x7ffffff428673853ull};
+
+#define LM_QR(a, b, c, d)                    \
+    a += b, d ^= a, d = (d << 16) | (d >> 16); \
+    c += d, b ^= c, b = (b << 12) | (b >> 20); \
+    a += b, d ^= a, d = (d << 8) | (d >> 24);  \
+    c += d, b ^= c, b = (b << 7) | (b >> 25);
+
+// RFC 8439 block function
+__device__ __forceinline__ void chacha20_block(const enc_seed_t &key, u32 counter, u32 n0, u32 n1, u32 n2,
+                                               u32 out[16]) {
+    u32 s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
+                 key.k[4],    key.k[5],    key.k[6],    key.k[7],    counter,  n0,       n1,       n2};
+    u32 x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        LM_QR(x[0], x[4], x[8], x[12])
+        LM_QR(x[1], x[5], x[9], x[13])
+        LM_QR(x[2], x[6], x[10], x[14])
+        LM_QR(x[3], x[7], x[11], x[15])
+        LM_QR(x[0], x[5], x[10], x[15])
+        LM_QR(x[1], x[6], x[11], x[12])
+        LM_QR(x[2], x[7], x[8], x[13])
+        LM_QR(x[3], x[4], x[9], x[14])
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+
+// small: [count][3][N] int8.  Per ciphertext N/16 blocks of stream 0 and N/8 blocks of streams 1, 2.
+__global__ __launch_bounds__(256) void k_sample_small(int8_t *__restrict__ small, uint32_t count, u64 first_index,
+                                                      uint32_t logN, enc_seed_t seed, enc_cdt_t cdt) {
+    const uint32_t N = 1u << logN, per_ct = (N >> 4) * 5; // N/16 + 2 * N/8 blocks
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)count * per_ct) return;
+    const uint32_t c = (uint32_t)(g / per_ct), j = (uint32_t)(g % per_ct);
+    uint32_t stream, blk;
+    if (j < (N >> 4))
+        stream = 0, blk = j;
+    else if (j < (N >> 4) * 3)
+        stream = 1, blk = j - (N >> 4);
+    else
+        stream = 2, blk = j - (N >> 4) * 3;
+    const u64 index = first_index + c;
+    u32 w[16];
+    chacha20_block(seed, blk, (u32)index, (u32)(index >> 32), stream, w);
+    int8_t *o = small + ((size_t)c * 3 + stream) * N;
+    if (stream == 0) {
+        union {
+            int8_t b[16];
+            uint4 v;
+        } r;
+#pragma unroll
+        for (int i = 0; i < 16; i++) r.b[i] = (int8_t)((int)(((u64)w[i] * 3) >> 32) - 1);
+        *reinterpret_cast<uint4 *>(o + (size_t)blk * 16) = r.v;
+    } else {
+        union {
+            int8_t b[8];
+            uint2 v;
+        } r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u64 x = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32), m = x >> 1;
+            int a = 0;
+#pragma unroll
+            for (int t = 0; t < 19; t++) a += m >= cdt.t[t];
+            r.b[i] = (int8_t)((x & 1) ? -a : a);
+        }
+        *reinterpret_cast<uint2 *>(o + (size_t)blk * 8) = r.v;
+    }
+}
+
+// One workgroup per (ciphertext c, limb l).  pk: [2][L][N] in Shoup form; pt: [count][L][N] or NULL;
+// out: [count][2][L][N].
+template <int LOGN>
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_encrypt_ntt(const int8_t *__restrict__ small,
+                                                                     const tw_t *__restrict__ pk,
+                                                                     const u64 *__restrict__ pt, u64 *__restrict__ out,
+                                                                     uint32_t count, uint32_t L, lm_mods mods,
+                                                                     const tw_t *__restrict__ tw_all) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm[];
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    const uint32_t l = blockIdx.x / count, c = blockIdx.x % count; // limb-major: one twiddle table hot per XCD
+    const lm_qc qc = lm_make_qc(mods.m[l]);
+    const tw_t *tw = tw_all + (size_t)l * N;
+    const int8_t *su = small + (size_t)c * 3 * N, *se0 = su + N, *se1 = su + 2 * N;
+    u64 *c0 = out + ((size_t)c * 2 * L + l) * N, *c1 = c0 + (size_t)L * N;
+    const u64 *p = pt ? pt + ((size_t)c * L + l) * N : nullptr;
+    const tw_t *pk0 = pk + (size_t)l * N, *pk1 = pk + (size_t)(L + l) * N;
+    auto lift = [&](int8_t v) { return v >= 0 ? (u64)v : qc.q - (u64)(-(int)v); };
+    { // c0 = NTT(e0) + pt
+        auto ld = [&](uint32_t i) { return lift(se0[i]); };
+        auto st = [&](uint32_t i0, const u64 *v, int n) {
+            u64 r[8], pv[8];
+            if (p) lm_load_run(p, i0, pv, n);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < n) {
+                    r[k] = lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64);
+                    if (p) r[k] = lm_addmod(r[k], pv[k], qc.q);
+                }
+            lm_store_run(c0, i0, r, n);
+        };
+        lm_ntt_forward<LOGN>(sm, tw, qc, tid, nthreads, ld, st);
+    }
+    __syncthreads(); // LDS is reused by the next transform
+    {                // c1 = NTT(e1)
+        auto ld = [&](uint32_t i) { return lift(se1[i]); };
+        auto st = [&](uint32_t i0, const u64 *v, int n) {
+            u64 r[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < n) r[k] = lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64);
+            lm_store_run(c1, i0, r, n);
+        };
+        lm_ntt_forward<LOGN>(sm, tw, qc, tid, nthreads, ld, st);
+    }
+    __syncthreads();
+    { // c0 += NTT(u) * pk0, c1 += NTT(u) * pk1: a work item meets the coefficients it stored above
+        auto ld = [&](uint32_t i) { return lift(su[i]); };
+        auto st = [&](uint32_t i0, const u64 *v, int n) {
+            u64 a[8], b[8];
+            lm_load_run(c0, i0, a, n);
+            lm_load_run(c1, i0, b, n);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < n) {
+                    const tw_t k0 = pk0[i0 + k], k1 = pk1[i0 + k];
+                    u64 x = lm_shoup3<false>(v[k], k0.w, k0.wp, qc.nq, a[k]); // a + u*pk0, lazily: < 4q
+                    u64 y = lm_shoup3<false>(v[k], k1.w, k1.wp, qc.nq, b[k]);
+                    a[k] = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
+                    b[k] = lm_csub(lm_csub(y, 2 * qc.q), qc.q);
+                }
+            lm_store_run(c0, i0, a, n);
+            lm_store_run(c1, i0, b, n);
+        };
+        lm_ntt_forward<LOGN>(sm, tw, qc, tid, nthreads, ld, st);
+    }
+}
+
+struct PkTable {
+    tw_t *d_pk = nullptr; // [2][L][N] Shoup form
+    ~PkTable() {
+        if (d_pk) hipFree(d_pk);
+    }
+};
+
+extern "C" int lumen_load_public_key(lumen_ctx *ctx, const uint64_t *pk) {
+    LM_CHECK(nullptr, ctx && pk, "lumen_load_public_key: NULL argument");
+    const uint32_t N = ctx->N, L = ctx->L;
+    std::vector<tw_t> tab((size_t)2 * L * N);
+    for (uint32_t w = 0; w < 2; w++)
+        for (uint32_t l = 0; l < L; l++) {
+            const uint64_t q = ctx->mod[l];
+            for (uint32_t k = 0; k < N; k++) {
+                const uint64_t x = pk[((size_t)w * L + l) * N + k];
+                if (x >= q) return lm_fail(ctx, "public key residue out of range (poly %u limb %u)", w, l);
+                tab[((size_t)w * L + l) * N + k] = h_tw(x, q);
+            }
+        }
+    auto sp = std::make_shared<PkTable>();
+    LM_HIP(ctx, hipMalloc((void **)&sp->d_pk, tab.size() * sizeof(tw_t)));
+    LM_HIP(ctx, hipMemcpy(sp->d_pk, tab.data(), tab.size() * sizeof(tw_t), hipMemcpyHostToDevice));
+    ctx->ext["public_key"] = sp;
+    return 0;
+}
+
+template <int LOGN>
+static int encrypt_t(lumen_ctx *ctx, const int8_t *small, const tw_t *pk, const u64 *pt, u64 *out, uint32_t count) {
+    const size_t lds = lm_fwd_lds(ctx->logN);
+    LM_LDS_ATTR(ctx, k_encrypt_ntt<LOGN>, lds);
+    lm_prof_scope ps(ctx, "encrypt_pk_ntt", (uint64_t)count * ctx->L * 3);
+    hipLaunchKernelGGL(k_encrypt_ntt<LOGN>, dim3(count * ctx->L), dim3(lm_fwd_threads(ctx->logN)), lds, ctx->stream,
+                       small, pk, pt, out, count, ctx->L, ctx->mods, ctx->d_tw_fwd);
+    LM_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint32_t count, const uint8_t seed[32],
+                                uint64_t first_index, lumen_set **out) {
+    LM_CHECK(nullptr, ctx && seed && out, "lumen_encrypt_pk: NULL argument");
+    auto it = ctx->ext.find("public_key");
+    LM_CHECK(ctx, it != ctx->ext.end(), "no public key loaded (lumen_load_public_key)");
+    const PkTable *pkt = static_cast<const PkTable *>(it->second.get());
+    const uint32_t N = ctx->N, L = ctx->L;
+    lumen_set *o = nullptr;
+    if (int rc = lumen_set_create(ctx, count, L, &o)) return rc;
+    *out = o;
+    if (!count) return 0;
+    enc_seed_t key;
+    memcpy(key.k, seed, 32); // little-endian words, as RFC 8439 reads the key
+    enc_cdt_t cdt;
+    memcpy(cdt.t, H_GAUSS_CDT, sizeof(cdt.t));
+    // chunks bound the staging buffers (plaintexts: 8*L*N bytes per ciphertext)
+    const uint32_t chunk = std::min<uint32_t>(count, 256);
+    int8_t *small = (int8_t *)lm_scratch(ctx, "enc_small", (size_t)chunk * 3 * N);
+    u64 *dpt = plaintexts ? (u64 *)lm_scratch(ctx, "enc_pt", (size_t)chunk * L * N * sizeof(u64)) : nullptr;
+    if (!small || (plaintexts && !dpt)) {
+        lumen_set_destroy(ctx, o);
+        *out = nullptr;
+        return 1;
+    }
+    int rc = 0;
+    for (uint32_t first = 0; first < count && !rc; first += chunk) {
+        const uint32_t n = std::min(chunk, count - first);
+        if (plaintexts) {
+            // the staging buffer is reused: stream order puts this copy behind the previous chunk's kernels
+            LM_HIP(ctx, hipMemcpyAsync(dpt, plaintexts + (size_t)first * L * N, (size_t)n * L * N * sizeof(u64),
+                                       hipMemcpyHostToDevice, ctx->stream));
+        }
+        {
+            lm_prof_scope ps(ctx, "encrypt_pk_sample", n);
+            const size_t threads = (size_t)n * (N >> 4) * 5;
+            hipLaunchKernelGGL(k_sample_small, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, ctx->stream, small,
+                               n, first_index + first, ctx->logN, key, cdt);
+            LM_HIP(ctx, hipGetLastError());
+        }
+        u64 *dst = o->d + (size_t)first * 2 * L * N;
+        switch (ctx->logN) {
+#define LM_CASE(k) \
+    case k:        \
+        rc = encrypt_t<k>(ctx, small, pkt->d_pk, dpt, dst, n); \
+        break;
+            LM_FOR_EACH_LOGN(LM_CASE)
+#undef LM_CASE
+        default:
+            rc = lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
+        }
+    }
+    if (!rc && plaintexts) LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `plaintexts` is caller memory
+    if (rc) {
+        lumen_set_destroy(ctx, o);
+        *out = nullptr;
+    }
+    return rc;
+}

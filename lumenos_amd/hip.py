@@ -60,6 +60,8 @@ SYMBOLS = {
     "lumen_encode_shard": (C.c_int, [_vp, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, _vpp, _u32p, _u32p]),
     "lumen_rescale": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
     "lumen_leaf_digests": (C.c_int, [_vp, _vp, _u8p]),
+    "lumen_load_public_key": (C.c_int, [_vp, _u64p]),
+    "lumen_encrypt_pk": (C.c_int, [_vp, _u64p, C.c_uint32, _u8p, C.c_uint64, C.POINTER(_vp)]),
     "lumen_leaf_digests_begin": (C.c_int, [_vp, _vp]),
     "lumen_leaf_digests_end": (C.c_int, [_vp, _u8p]),
     "lumen_merkle_build": (C.c_int, [_vp, _u8p, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t), _u8p]),
@@ -246,6 +248,23 @@ class Context:
         out = np.zeros((s.count, 32), dtype=np.uint8)
         self._ck(self.lib.lumen_leaf_digests(self.h, s.h, out.ctypes.data_as(_u8p)))
         return out
+
+    def load_public_key(self, pk):
+        pk = np.ascontiguousarray(pk, dtype=np.uint64)
+        assert pk.shape == (2, self.L, self.N), pk.shape
+        self._ck(self.lib.lumen_load_public_key(self.h, _p64(pk)))
+
+    def encrypt_pk(self, plaintexts, count, seed, first_index=0):
+        """count ciphertexts of `plaintexts` ([count][L][N], or None: zeros) under the loaded public key."""
+        seed = np.ascontiguousarray(seed, dtype=np.uint8)
+        assert seed.size == 32
+        if plaintexts is not None:
+            plaintexts = np.ascontiguousarray(plaintexts, dtype=np.uint64)
+            assert plaintexts.shape == (count, self.L, self.N), plaintexts.shape
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_encrypt_pk(self.h, _p64(plaintexts) if plaintexts is not None else None, count,
+                                           seed.ctypes.data_as(_u8p), first_index, C.byref(h)))
+        return DeviceSet(self, h)
 
     def leaf_digests_begin(self, s):
         """Start hashing the leaves of `s` on the context's side stream (overlaps later calls)."""

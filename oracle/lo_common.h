@@ -208,6 +208,12 @@ void lo_encode(const lo_params *p, const uint64_t *values, uint32_t nvalues, uin
 /* Encryptor.EncryptNew with pk */
 void lo_encrypt_pk(const lo_params *p, lo_rng *r, const uint64_t *pk, const uint64_t *pt,
                    uint32_t nl, uint64_t *ct);
+/* deterministic variant shared bit for bit with the HIP path (lo_encdet.c): small polynomials from
+ * ChaCha20(seed, ciphertext index, stream) */
+extern const uint64_t LO_GAUSS_CDT[19];
+void lo_det_small(const uint8_t seed[32], uint64_t index, uint32_t stream, uint32_t N, int8_t *out);
+void lo_encrypt_pk_det(const lo_params *p, const uint64_t *pk, const uint64_t *pt, uint32_t nl,
+                       const uint8_t seed[32], uint64_t index, uint64_t *ct);
 /* Decrypt + decode `nvalues` slots; ct must have nl <= 2 limbs (phase is
  * CRT-reconstructed in 128 bits).  scale_inv: multiply decoded slots by this
  * (mod T) to undo rescale scaling; pass 1 for none. */

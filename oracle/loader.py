@@ -102,6 +102,8 @@ class Oracle:
             "lo_keygen_galois": (None, [vp, vp, u64p, C.c_uint64, u64p]),
             "lo_encode": (None, [vp, u64p, C.c_uint32, C.c_uint32, u64p]),
             "lo_encrypt_pk": (None, [vp, vp, u64p, u64p, C.c_uint32, u64p]),
+            "lo_det_small": (None, [u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_int8)]),
+            "lo_encrypt_pk_det": (None, [vp, u64p, u64p, C.c_uint32, u8p, C.c_uint64, u64p]),
             "lo_decrypt_phase": (None, [vp, u64p, u64p, C.c_uint32, u64p]),
             "lo_decode_coeffs": (None, [vp, u64p, C.c_uint64, u64p, C.c_uint32]),
             "lo_decrypt_decode": (C.c_int, [vp, u64p, u64p, C.c_uint32, C.c_uint64, u64p, C.c_uint32]),
@@ -356,6 +358,24 @@ class Params:
         nl = self.L if nl is None else nl
         ct = np.zeros((2, nl, self.N), dtype=np.uint64)
         self.o.lib.lo_encrypt_pk(self.h, self._r(), _p64(pk), _p64(pt) if pt is not None else None, nl, _p64(ct))
+        return ct
+
+    def det_small(self, seed, index, stream):
+        """Small polynomial `stream` (0: ternary u, 1/2: Gaussian e0/e1) of ciphertext `index` (lo_encdet.c)."""
+        seed = np.ascontiguousarray(seed, dtype=np.uint8)
+        assert seed.size == 32
+        out = np.zeros(self.N, dtype=np.int8)
+        self.o.lib.lo_det_small(_p8(seed), index, stream, self.N, out.ctypes.data_as(C.POINTER(C.c_int8)))
+        return out
+
+    def encrypt_det(self, pk, pt, seed, index, nl=None):
+        """Deterministic pk encryption shared bit for bit with lumen_encrypt_pk."""
+        nl = self.L if nl is None else nl
+        seed = np.ascontiguousarray(seed, dtype=np.uint8)
+        assert seed.size == 32
+        ct = np.zeros((2, nl, self.N), dtype=np.uint64)
+        self.o.lib.lo_encrypt_pk_det(self.h, _p64(pk), _p64(pt) if pt is not None else None, nl, _p8(seed), index,
+                                     _p64(ct))
         return ct
 
     def decrypt_phase(self, sk, ct):

@@ -435,3 +435,58 @@ def test_rescale_mixed_size_moduli_falls_back(oracle):
             ref = P.rescale(ref)
         assert np.array_equal(got[c], ref), c
     ctx.close()
+
+
+# ------------------------------------------------------------------ witness encryption
+@pytest.mark.parametrize("log_n,num_q", [(10, 3), (12, 2), (14, 2)])
+def test_encrypt_pk_matches_oracle_and_decrypts(oracle, log_n, num_q):
+    """lumen_encrypt_pk == the oracle's deterministic encryption bit for bit (same ChaCha20-derived
+    u, e0, e1), decrypts to the plaintexts, and does not depend on how the columns are batched."""
+    P = make_params(oracle, log_n, num_q)
+    P.seed(log_n)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    ctx = make_context(P)
+    ctx.load_public_key(pk)
+    seed = np.frombuffer(bytes(range(7, 39)), dtype=np.uint8)
+    rng = np.random.default_rng(log_n)
+    count, first = 5, 2**33 + 11
+    vals = rng.integers(0, T_REF, size=(count, P.N), dtype=np.uint64)
+    pts = np.stack([P.encode(v) for v in vals])
+    got = ctx.encrypt_pk(pts, count, seed, first).download()
+    for i in range(count):
+        assert np.array_equal(got[i], P.encrypt_det(pk, pts[i], seed, first + i)), i
+        assert np.array_equal(P.decrypt(sk, got[i], P.N), vals[i]), i
+    # encryptions of zero (fhe/code.go:21-25 pads the matrix with one)
+    z = ctx.encrypt_pk(None, 2, seed, 77).download()
+    assert np.array_equal(z[1], P.encrypt_det(pk, None, seed, 78))
+    assert not P.decrypt(sk, z[0], P.N).any()
+    # a shard that starts in the middle produces the same ciphertexts
+    tail = ctx.encrypt_pk(pts[3:], 2, seed, first + 3).download()
+    assert np.array_equal(tail, got[3:])
+    ctx.close()
+
+
+def test_encrypted_witness_runs_through_the_prover(oracle):
+    """Encrypt a witness on the GPU, run matrixInnerSumEval on it, decrypt: sum_i r_i * W[i][j]."""
+    P = make_params(oracle, 10, 5)
+    P.seed(4)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    ctx = make_context(P)
+    ctx.load_public_key(pk)
+    rows, cols = 256, 4
+    W = oracle.witness(rows, cols, T_REF)
+    pts = np.stack([P.encode(W[:, j]) for j in range(cols)])
+    seed = np.zeros(32, dtype=np.uint8)
+    m = ctx.encrypt_pk(pts, cols, seed, 0)
+    gl = P.inner_sum_galois_elements(rows)
+    for g in gl:
+        ctx.load_galois_key(g, P.keygen_galois(sk, g))
+    r = np.random.default_rng(9).integers(0, 2**63, size=rows, dtype=np.uint64)
+    got = ctx.matrix_inner_sum(m, P.encode(r), rows).download()
+    scale = P.rescale_scale(P.L, 2)
+    for j in range(cols):
+        want = int(np.sum(W[:, j].astype(object) * (r.astype(object) % T_REF)) % T_REF)
+        assert int(P.decrypt(sk, got[j], 1, scale)[0]) == want, j
+    ctx.close()

@@ -165,3 +165,59 @@ def test_ring_switch_on_oracle(oracle, logn_small):
     assert np.array_equal(m, P.decrypt_big_coeffs_l0(sk, ct)[::P.N >> logn_small])
     if logn_small == 10:
         assert np.array_equal(P.decode_coeffs(m, P.rescale_scale(P.L, 2), 2), vals[:2])
+
+
+# ------------------------------------------------------------------ deterministic pk encryption (lo_encdet.c)
+def test_det_encrypt_decrypts_and_noise_is_small(oracle):
+    """The checker of lumen_encrypt_pk: Dec(Enc_det(pt)) = pt at the top level, encryptions of zero
+    decrypt to zero, and the phase noise stays near |u*e_pk + e0 + e1*s| <~ 2*19*N (far below q/2T)."""
+    P = make_params(oracle, 10, 3)
+    P.seed(2)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    seed = np.arange(32, dtype=np.uint8)
+    vals = np.random.default_rng(1).integers(0, T_REF, size=P.N, dtype=np.uint64)
+    for idx in (0, 1, 2**40 + 5):
+        ct = P.encrypt_det(pk, P.encode(vals), seed, idx)
+        assert np.array_equal(P.decrypt(sk, ct, P.N), vals)
+    z = P.encrypt_det(pk, None, seed, 9)
+    assert not P.decrypt(sk, z, P.N).any()
+    # different indices / seeds give different ciphertexts; the same pair repeats exactly
+    a, b = P.encrypt_det(pk, None, seed, 3), P.encrypt_det(pk, None, seed, 4)
+    assert not np.array_equal(a, b) and np.array_equal(a, P.encrypt_det(pk, None, seed, 3))
+    seed2 = seed.copy()
+    seed2[31] ^= 1
+    assert not np.array_equal(a, P.encrypt_det(pk, None, seed2, 3))
+
+
+def test_det_sampler_distribution(oracle):
+    """Ternary u: each of -1, 0, 1 with probability 1/3; e: sigma 3.2, |e| <= 19, mean 0
+    ([LATTIGO-RECALL] DefaultXs / DefaultXe)."""
+    P = make_params(oracle, 12, 1, num_p=0)
+    seed = np.frombuffer(bytes(range(100, 132)), dtype=np.uint8)
+    u = np.concatenate([P.det_small(seed, i, 0) for i in range(16)]).astype(np.int64)
+    n = u.size
+    for v in (-1, 0, 1):
+        assert abs((u == v).sum() / n - 1 / 3) < 4 * np.sqrt(2 / 9 / n)
+    e = np.concatenate([P.det_small(seed, i, s) for i in range(16) for s in (1, 2)]).astype(np.int64)
+    assert np.abs(e).max() <= 19
+    assert abs(e.mean()) < 4 * 3.2 / np.sqrt(e.size)
+    assert abs(e.var() - 10.24) < 0.25
+    assert abs((e == 0).mean() - 0.12467) < 0.005
+    # streams are independent of each other
+    assert not np.array_equal(P.det_small(seed, 0, 1), P.det_small(seed, 0, 2))
+
+
+def test_det_sampler_chacha_layout(oracle):
+    """Coefficient k of stream 0 is word k of ChaCha20(seed, nonce = LE64(index) || LE32(0)):
+    checked against the RFC 8439 keystream the oracle's ChaCha20 produces."""
+    import ctypes as C
+    P = make_params(oracle, 10, 1, num_p=0)
+    seed = np.arange(32, dtype=np.uint8)
+    idx = 0x0102030405060708
+    nonce = np.frombuffer(idx.to_bytes(8, "little") + (0).to_bytes(4, "little"), dtype=np.uint8).copy()
+    ks = np.zeros(4 * P.N, dtype=np.uint8)
+    oracle.lib.lo_chacha20_xor(seed.ctypes.data_as(C.POINTER(C.c_uint8)), nonce.ctypes.data_as(C.POINTER(C.c_uint8)),
+                               0, ks.ctypes.data_as(C.POINTER(C.c_uint8)), ks.size)
+    w = ks.view("<u4").astype(np.uint64)
+    assert np.array_equal(P.det_small(seed, idx, 0).astype(np.int64), ((w * 3) >> 32).astype(np.int64) - 1)

@@ -183,6 +183,8 @@ ServerBFV::ServerBFV(core::PrimeField *plaintextField, const Parameters &params,
     g_ring_degree[ctx_] = (uint32_t)params.N();
     check(lumen_field_set(ctx_, plaintextField->RootsForward().data(), (uint32_t)plaintextField->N()), "lumen_field_set");
     for (const auto &kv : evk) check(lumen_load_galois_key(ctx_, kv.first, kv.second.data()), "lumen_load_galois_key");
+    check(lumen_load_public_key(ctx_, pk_.data()), "lumen_load_public_key");
+    for (auto &b : enc_seed_) b = (uint8_t)rng_(); // the reference keys its PRNG from crypto/rand
     // encoder tables ([LATTIGO-RECALL] bgv.Encoder: slot i of row 0 sits at 5^i, row 1 at -5^i)
     const uint64_t T = params.T, two_n = 2ull << params.LogN;
     psiT_ = PowMod(core::PrimitiveRoot(T), (T - 1) / two_n, T);
@@ -253,6 +255,21 @@ std::vector<uint64_t> ServerBFV::EncryptNew(const Plaintext &pt) {
         }
     }
     return ct;
+}
+
+Ciphertexts ServerBFV::EncryptNewBatch(const std::vector<Plaintext> &pts) {
+    // the EncryptNew loop of cmd/server/main.go:199-208 as one device call; column i of this server's
+    // lifetime draws its randomness from ChaCha20(enc_seed_, i)
+    const size_t N = (size_t)params_.N(), L = params_.Q.size();
+    std::vector<uint64_t> flat(pts.size() * L * N);
+    for (size_t i = 0; i < pts.size(); i++) {
+        if ((size_t)pts[i].Level + 1 != L) throw std::invalid_argument("EncryptNewBatch: plaintexts must be at MaxLevel");
+        memcpy(&flat[i * L * N], pts[i].Value.data(), L * N * 8);
+    }
+    lumen_set *set = nullptr;
+    check(lumen_encrypt_pk(ctx_, flat.data(), (uint32_t)pts.size(), enc_seed_, enc_next_, &set), "lumen_encrypt_pk");
+    enc_next_ += pts.size();
+    return Ciphertexts(ctx_, set);
 }
 
 // ------------------------------------------------------------------ ring switch

@@ -89,6 +89,9 @@ class ServerBFV {
     Plaintext Encode(const std::vector<uint64_t> &values) const;
     // Encryptor.EncryptNew(pt) under pk, host layout [2][L][N]
     std::vector<uint64_t> EncryptNew(const Plaintext &pt);
+    // the same for a batch of MaxLevel plaintexts, on the device (lumen_encrypt_pk): the witness
+    // encryption loop of cmd/server/main.go:199-208; the result stays in HBM
+    Ciphertexts EncryptNewBatch(const std::vector<Plaintext> &pts);
     void check(int rc, const char *what) const; // throws std::runtime_error with lumen_last_error
     void SetRingSwitchServer(RingSwitchServer *rs) { rs_ = rs; } // bfv.go:48-50
     RingSwitchServer *RingSwitch() const { return rs_; }          // bfv.go:52-54
@@ -102,6 +105,8 @@ class ServerBFV {
     uint64_t psiT_ = 0;
     std::vector<uint32_t> slot_index_;
     RingSwitchServer *rs_ = nullptr;
+    uint8_t enc_seed_[32] = {0};
+    uint64_t enc_next_ = 0;
 };
 
 // fhe.RingSwitchServer (fhe/ring_switch.go:93-113)

@@ -67,14 +67,14 @@ int main(int argc, char **argv) {
     printf("Number of queried columns: %d\n", ligero.Metadata.Queries);
     REQUIRE(ligero.Metadata.Queries == 309, "queries");
     core::Span *span = core::Span::StartSpan("Encrypt matrix", nullptr);
-    std::vector<uint64_t> host_cts((size_t)cols * 2 * L * N);
+    std::vector<fhe::Plaintext> batched(cols);
     for (int j = 0; j < cols; j++) {
         std::vector<uint64_t> column(rows);
         for (int i = 0; i < rows; i++) column[i] = matrix[(size_t)i * cols + j];
-        std::vector<uint64_t> ct = server.EncryptNew(server.Encode(column));
-        memcpy(&host_cts[(size_t)j * 2 * L * N], ct.data(), ct.size() * 8);
+        batched[j] = server.Encode(column);
     }
-    fhe::Ciphertexts ciphertexts = fhe::Ciphertexts::Upload(server, host_cts, cols, L - 1);
+    fhe::Ciphertexts ciphertexts = server.EncryptNewBatch(batched); // on the device (lumen_encrypt_pk)
+    batched.clear();
     span->End();
 
     span = core::Span::StartSpan("Commit FHE evaluation", nullptr, "Commit FHE evaluation...");

@@ -1,6 +1,6 @@
 """Quick device timing of the building blocks (not the contract bench)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle.loader import Oracle
 from tests.helpers import make_params, make_context, T_REF

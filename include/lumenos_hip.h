@@ -135,6 +135,15 @@ int lumen_merkle_build(lumen_ctx *ctx, const uint8_t *leaf_digests, uint32_t n_l
  * column encrypts to the same bits on whichever GPU it lands.  out: new set of `count` ciphertexts
  * at the top level. */
 int lumen_load_public_key(lumen_ctx *ctx, const uint64_t *pk);
+/* The same from the raw witness: Encoder.Encode + EncryptNew for `count` columns of `rows` slot
+ * values each (cmd/server/main.go:188-208), host [count][rows]; 8*rows bytes cross PCIe per column
+ * instead of the 8*L*N of an encoded plaintext.  lumen_encoder_set hands over the primitive 2N-th
+ * root of unity modulo T of the encoder's Z_T ring (Lattigo: params.RingT()), like `psi` for the
+ * limbs.  Encoding [LATTIGO-RECALL bgv.Encoder]: slot i of row 0 at the evaluation point 5^i, row 1
+ * at -5^i; INTT over Z_T; scale by T^-1 mod q_l; NTT (fused here into the encryption's transforms). */
+int lumen_encoder_set(lumen_ctx *ctx, uint64_t psi_t);
+int lumen_encrypt_values(lumen_ctx *ctx, const uint64_t *values, uint32_t rows, uint32_t count,
+                         const uint8_t seed[32], uint64_t first_index, lumen_set **out);
 int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint32_t count, const uint8_t seed[32],
                      uint64_t first_index, lumen_set **out);
 

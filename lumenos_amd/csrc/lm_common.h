@@ -176,9 +176,14 @@ struct lm_ninv_t;
 int lm_launch_ntt_strided(lumen_ctx *ctx, const u64 *src, size_t src_poly_stride, u64 *dst,
                           size_t dst_poly_stride, uint32_t npoly, const lm_modmap &map, bool inverse,
                           const char *prof_name, const lm_ninv_t *inv_scale = nullptr);
+// explicit_mod: transform modulo a modulus that is not one of the context's limbs (the plaintext
+// modulus T of the encoder); otherwise the modulus is mods.m[mod_idx]
 int lm_launch_ntt_subring(lumen_ctx *ctx, uint32_t logn, const tw_t *tw, tw_t ninv_scale, const u64 *src,
                           size_t src_poly_stride, u64 *dst, size_t dst_poly_stride, uint32_t npoly,
-                          uint32_t mod_idx, bool inverse);
+                          uint32_t mod_idx, bool inverse, const mod_t *explicit_mod = nullptr);
+mod_t lm_make_mod(uint64_t q);
+// bit-reversed psi-power tables of a negacyclic transform, forward and inverse, Shoup form
+void lm_build_tw(uint64_t q, uint64_t psi, uint32_t logN, std::vector<tw_t> &fwd, std::vector<tw_t> &inv);
 int lm_rescale_polys(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
                      uint32_t npoly, u64 *work, u64 *tbuf);
 lm_modmap lm_map_q(uint32_t nl);

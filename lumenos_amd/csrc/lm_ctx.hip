@@ -87,8 +87,20 @@ lm_modmap lm_map_q(uint32_t nl) {
     return m;
 }
 
-static void build_tw(uint64_t q, uint64_t psi, uint32_t logN, std::vector<tw_t> &fwd,
-                     std::vector<tw_t> &inv) {
+mod_t lm_make_mod(uint64_t q) {
+    mod_t m;
+    m.q = q;
+    m.qinv64 = (u64)((((u128)1) << 64) / q);
+    // -q^-1 mod 2^64 by Newton iteration
+    u64 inv = 1;
+    for (int it = 0; it < 6; it++) inv *= 2 - (u64)q * inv;
+    m.qneg = (u64)0 - inv;
+    u64 r = (u64)((((u128)1) << 64) % q);
+    m.r2 = h_mulmod(r, r, q);
+    return m;
+}
+
+void lm_build_tw(uint64_t q, uint64_t psi, uint32_t logN, std::vector<tw_t> &fwd, std::vector<tw_t> &inv) {
     uint32_t N = 1u << logN;
     fwd.resize(N);
     inv.resize(N);
@@ -149,15 +161,7 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
         }
         ctx->mod[i] = q;
         ctx->psi[i] = psi;
-        mod_t &m = ctx->mods.m[i];
-        m.q = q;
-        m.qinv64 = (u64)((((u128)1) << 64) / q);
-        // -q^-1 mod 2^64 by Newton iteration
-        u64 inv = 1;
-        for (int it = 0; it < 6; it++) inv *= 2 - (u64)q * inv;
-        m.qneg = (u64)0 - inv;
-        u64 r = (u64)((((u128)1) << 64) % q);
-        m.r2 = h_mulmod(r, r, q);
+        ctx->mods.m[i] = lm_make_mod(q);
         ctx->ninv[i] = h_tw(h_invmod(N % q, q), q);
     }
     for (uint32_t i = LK; i < LM_MAX_LIMBS; i++) ctx->mods.m[i] = ctx->mods.m[0];
@@ -165,7 +169,7 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
     LM_HIP(ctx, hipMalloc((void **)&ctx->d_tw_inv, (size_t)LK * N * sizeof(tw_t)));
     std::vector<tw_t> f, b;
     for (uint32_t i = 0; i < LK; i++) {
-        build_tw(ctx->mod[i], ctx->psi[i], ctx->logN, f, b);
+        lm_build_tw(ctx->mod[i], ctx->psi[i], ctx->logN, f, b);
         LM_HIP(ctx, hipMemcpy(ctx->d_tw_fwd + (size_t)i * N, f.data(), N * sizeof(tw_t), hipMemcpyHostToDevice));
         LM_HIP(ctx, hipMemcpy(ctx->d_tw_inv + (size_t)i * N, b.data(), N * sizeof(tw_t), hipMemcpyHostToDevice));
     }

@@ -107,12 +107,19 @@ __global__ __launch_bounds__(256) void k_sample_small(int8_t *__restrict__ small
 
 // One workgroup per (ciphertext c, limb l).  pk: [2][L][N] in Shoup form; pt: [count][L][N] or NULL;
 // out: [count][2][L][N].
+// mcoef/tinv: alternatively to `pt`, the plaintexts as coefficient vectors modulo T ([count][N],
+// the encoder's INTT output) with T^-1 mod q_l per limb: NTT is linear, so the scaled message rides in
+// the load of the e0 transform, NTT(e0 + m * T^-1), and costs no transform of its own.
+struct enc_tinv_t {
+    tw_t t[LM_MAX_LIMBS];
+};
 template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_encrypt_ntt(const int8_t *__restrict__ small,
                                                                      const tw_t *__restrict__ pk,
-                                                                     const u64 *__restrict__ pt, u64 *__restrict__ out,
-                                                                     uint32_t count, uint32_t L, lm_mods mods,
-                                                                     const tw_t *__restrict__ tw_all) {
+                                                                     const u64 *__restrict__ pt,
+                                                                     const u64 *__restrict__ mcoef, enc_tinv_t tinv,
+                                                                     u64 *__restrict__ out, uint32_t count, uint32_t L,
+                                                                     lm_mods mods, const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
     constexpr uint32_t N = 1u << LOGN;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
@@ -124,8 +131,13 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_encrypt_ntt(const int8
     const u64 *p = pt ? pt + ((size_t)c * L + l) * N : nullptr;
     const tw_t *pk0 = pk + (size_t)l * N, *pk1 = pk + (size_t)(L + l) * N;
     auto lift = [&](int8_t v) { return v >= 0 ? (u64)v : qc.q - (u64)(-(int)v); };
-    { // c0 = NTT(e0) + pt
-        auto ld = [&](uint32_t i) { return lift(se0[i]); };
+    { // c0 = NTT(e0 [+ m * T^-1]) [+ pt]
+        const u64 *mc = mcoef ? mcoef + (size_t)c * N : nullptr;
+        const tw_t ti = tinv.t[l];
+        auto ld = [&](uint32_t i) {
+            const u64 e = lift(se0[i]);
+            return mc ? lm_shoup3<true>(mc[i], ti.w, ti.wp, qc.nq, e) : e; // < 4q
+        };
         auto st = [&](uint32_t i0, const u64 *v, int n) {
             u64 r[8], pv[8];
             if (p) lm_load_run(p, i0, pv, n);
@@ -201,23 +213,87 @@ extern "C" int lumen_load_public_key(lumen_ctx *ctx, const uint64_t *pk) {
     return 0;
 }
 
+// ---- Encoder.Encode on the device ([LATTIGO-RECALL] bgv.Encoder: slot i of row 0 sits at the
+// evaluation point 5^i, row 1 at -5^i; slots -> INTT over Z_T -> scale by T^-1 mod q_l -> NTT)
+struct EncoderTables {
+    uint32_t *d_slot = nullptr; // [N] slot -> coefficient position of the Z_T transform
+    tw_t *d_tw_inv = nullptr;   // [N] inverse twiddles modulo T
+    mod_t modT;
+    tw_t ninvT;
+    enc_tinv_t tinv; // T^-1 mod q_l
+    ~EncoderTables() {
+        if (d_slot) hipFree(d_slot);
+        if (d_tw_inv) hipFree(d_tw_inv);
+    }
+};
+
+extern "C" int lumen_encoder_set(lumen_ctx *ctx, uint64_t psi_t) {
+    LM_CHECK(nullptr, ctx, "lumen_encoder_set: NULL ctx");
+    const uint64_t T = ctx->T;
+    const uint32_t N = ctx->N, logN = ctx->logN;
+    LM_CHECK(ctx, T > 2 && (T & (2ull * N - 1)) == 1, "plaintext modulus %llu is not 1 mod 2N", (unsigned long long)T);
+    LM_CHECK(ctx, T <= UINT64_MAX / (3ull * logN + 8), "plaintext modulus too large for the lazy transform");
+    LM_CHECK(ctx, h_powmod(psi_t, N, T) == T - 1, "psi_t is not a primitive 2N-th root of unity modulo T");
+    auto sp = std::make_shared<EncoderTables>();
+    sp->modT = lm_make_mod(T);
+    sp->ninvT = h_tw(h_invmod(N % T, T), T);
+    for (uint32_t l = 0; l < LM_MAX_LIMBS; l++) {
+        const uint64_t q = ctx->mod[l < ctx->L ? l : 0];
+        sp->tinv.t[l] = h_tw(h_invmod(T % q, q), q);
+    }
+    std::vector<tw_t> f, b;
+    lm_build_tw(T, psi_t, logN, f, b);
+    std::vector<uint32_t> slot(N);
+    const uint64_t m = 2ull * N;
+    uint64_t pos = 1;
+    for (uint32_t i = 0; i < N / 2; i++) {
+        slot[i] = h_bitrev((uint32_t)((pos - 1) >> 1), (int)logN);
+        slot[i | (N / 2)] = h_bitrev((uint32_t)((m - pos - 1) >> 1), (int)logN);
+        pos = (pos * 5) & (m - 1);
+    }
+    LM_HIP(ctx, hipMalloc((void **)&sp->d_slot, (size_t)N * 4));
+    LM_HIP(ctx, hipMalloc((void **)&sp->d_tw_inv, (size_t)N * sizeof(tw_t)));
+    LM_HIP(ctx, hipMemcpy(sp->d_slot, slot.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    LM_HIP(ctx, hipMemcpy(sp->d_tw_inv, b.data(), (size_t)N * sizeof(tw_t), hipMemcpyHostToDevice));
+    ctx->ext["encoder"] = sp;
+    return 0;
+}
+
+// m[c][slot[i]] = values[c][i] mod T for i < rows, 0 elsewhere (m pre-zeroed)
+__global__ void k_scatter_slots(const u64 *__restrict__ values, u64 *__restrict__ m, const uint32_t *__restrict__ slot,
+                                uint32_t rows, uint32_t logN, size_t total, mod_t modT) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const size_t c = g / rows;
+    const uint32_t i = (uint32_t)(g % rows);
+    m[(c << logN) + slot[i]] = lm_reduce(values[g], modT.q, modT.qinv64);
+}
+
 template <int LOGN>
-static int encrypt_t(lumen_ctx *ctx, const int8_t *small, const tw_t *pk, const u64 *pt, u64 *out, uint32_t count) {
+static int encrypt_t(lumen_ctx *ctx, const int8_t *small, const tw_t *pk, const u64 *pt, const u64 *mcoef,
+                     const enc_tinv_t &tinv, u64 *out, uint32_t count) {
     const size_t lds = lm_fwd_lds(ctx->logN);
     LM_LDS_ATTR(ctx, k_encrypt_ntt<LOGN>, lds);
     lm_prof_scope ps(ctx, "encrypt_pk_ntt", (uint64_t)count * ctx->L * 3);
     hipLaunchKernelGGL(k_encrypt_ntt<LOGN>, dim3(count * ctx->L), dim3(lm_fwd_threads(ctx->logN)), lds, ctx->stream,
-                       small, pk, pt, out, count, ctx->L, ctx->mods, ctx->d_tw_fwd);
+                       small, pk, pt, mcoef, tinv, out, count, ctx->L, ctx->mods, ctx->d_tw_fwd);
     LM_HIP(ctx, hipGetLastError());
     return 0;
 }
 
-extern "C" int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint32_t count, const uint8_t seed[32],
-                                uint64_t first_index, lumen_set **out) {
-    LM_CHECK(nullptr, ctx && seed && out, "lumen_encrypt_pk: NULL argument");
+// plaintexts (NTT-domain RNS, [count][L][N]) or values ([count][rows] slot values) or neither (zeros)
+static int encrypt_impl(lumen_ctx *ctx, const uint64_t *plaintexts, const uint64_t *values, uint32_t rows,
+                        uint32_t count, const uint8_t seed[32], uint64_t first_index, lumen_set **out) {
     auto it = ctx->ext.find("public_key");
     LM_CHECK(ctx, it != ctx->ext.end(), "no public key loaded (lumen_load_public_key)");
     const PkTable *pkt = static_cast<const PkTable *>(it->second.get());
+    const EncoderTables *enc = nullptr;
+    if (values) {
+        auto ie = ctx->ext.find("encoder");
+        LM_CHECK(ctx, ie != ctx->ext.end(), "no encoder tables (lumen_encoder_set)");
+        enc = static_cast<const EncoderTables *>(ie->second.get());
+        LM_CHECK(ctx, rows >= 1 && rows <= ctx->N, "rows=%u out of range [1, N]", rows);
+    }
     const uint32_t N = ctx->N, L = ctx->L;
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, count, L, &o)) return rc;
@@ -227,11 +303,16 @@ extern "C" int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint
     memcpy(key.k, seed, 32); // little-endian words, as RFC 8439 reads the key
     enc_cdt_t cdt;
     memcpy(cdt.t, H_GAUSS_CDT, sizeof(cdt.t));
+    enc_tinv_t tinv;
+    memset(&tinv, 0, sizeof(tinv));
+    if (enc) tinv = enc->tinv;
     // chunks bound the staging buffers (plaintexts: 8*L*N bytes per ciphertext)
     const uint32_t chunk = std::min<uint32_t>(count, 256);
     int8_t *small = (int8_t *)lm_scratch(ctx, "enc_small", (size_t)chunk * 3 * N);
     u64 *dpt = plaintexts ? (u64 *)lm_scratch(ctx, "enc_pt", (size_t)chunk * L * N * sizeof(u64)) : nullptr;
-    if (!small || (plaintexts && !dpt)) {
+    u64 *dval = values ? (u64 *)lm_scratch(ctx, "enc_val", (size_t)chunk * rows * sizeof(u64)) : nullptr;
+    u64 *dm = values ? (u64 *)lm_scratch(ctx, "enc_m", (size_t)chunk * N * sizeof(u64)) : nullptr;
+    if (!small || (plaintexts && !dpt) || (values && (!dval || !dm))) {
         lumen_set_destroy(ctx, o);
         *out = nullptr;
         return 1;
@@ -239,10 +320,24 @@ extern "C" int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint
     int rc = 0;
     for (uint32_t first = 0; first < count && !rc; first += chunk) {
         const uint32_t n = std::min(chunk, count - first);
-        if (plaintexts) {
-            // the staging buffer is reused: stream order puts this copy behind the previous chunk's kernels
+        // the staging buffers are reused: stream order puts these copies behind the previous chunk's kernels
+        if (plaintexts)
             LM_HIP(ctx, hipMemcpyAsync(dpt, plaintexts + (size_t)first * L * N, (size_t)n * L * N * sizeof(u64),
                                        hipMemcpyHostToDevice, ctx->stream));
+        if (values) { // Encoder.Encode up to the coefficient vector modulo T
+            LM_HIP(ctx, hipMemcpyAsync(dval, values + (size_t)first * rows, (size_t)n * rows * sizeof(u64),
+                                       hipMemcpyHostToDevice, ctx->stream));
+            LM_HIP(ctx, hipMemsetAsync(dm, 0, (size_t)n * N * sizeof(u64), ctx->stream));
+            const size_t total = (size_t)n * rows;
+            {
+                lm_prof_scope ps(ctx, "encode_scatter", n);
+                hipLaunchKernelGGL(k_scatter_slots, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, dval,
+                                   dm, enc->d_slot, rows, ctx->logN, total, enc->modT);
+                LM_HIP(ctx, hipGetLastError());
+            }
+            lm_prof_scope ps(ctx, "encode_intt_T", n);
+            rc = lm_launch_ntt_subring(ctx, ctx->logN, enc->d_tw_inv, enc->ninvT, dm, N, dm, N, n, 0, true, &enc->modT);
+            if (rc) break;
         }
         {
             lm_prof_scope ps(ctx, "encrypt_pk_sample", n);
@@ -255,7 +350,7 @@ extern "C" int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint
         switch (ctx->logN) {
 #define LM_CASE(k) \
     case k:        \
-        rc = encrypt_t<k>(ctx, small, pkt->d_pk, dpt, dst, n); \
+        rc = encrypt_t<k>(ctx, small, pkt->d_pk, dpt, dm, tinv, dst, n); \
         break;
             LM_FOR_EACH_LOGN(LM_CASE)
 #undef LM_CASE
@@ -263,10 +358,22 @@ extern "C" int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint
             rc = lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
         }
     }
-    if (!rc && plaintexts) LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `plaintexts` is caller memory
+    if (!rc && (plaintexts || values)) LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // caller memory
     if (rc) {
         lumen_set_destroy(ctx, o);
         *out = nullptr;
     }
     return rc;
+}
+
+extern "C" int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint32_t count, const uint8_t seed[32],
+                                uint64_t first_index, lumen_set **out) {
+    LM_CHECK(nullptr, ctx && seed && out, "lumen_encrypt_pk: NULL argument");
+    return encrypt_impl(ctx, plaintexts, nullptr, 0, count, seed, first_index, out);
+}
+
+extern "C" int lumen_encrypt_values(lumen_ctx *ctx, const uint64_t *values, uint32_t rows, uint32_t count,
+                                    const uint8_t seed[32], uint64_t first_index, lumen_set **out) {
+    LM_CHECK(nullptr, ctx && values && seed && out, "lumen_encrypt_values: NULL argument");
+    return encrypt_impl(ctx, nullptr, values, rows, count, seed, first_index, out);
 }

@@ -46,12 +46,12 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_limb_ntt(const u64 *sr
 // map.idx[0]) with its own twiddle table `tw` of 2^logn entries.
 int lm_launch_ntt_subring(lumen_ctx *ctx, uint32_t logn, const tw_t *tw, tw_t ninv_scale, const u64 *src,
                           size_t src_poly_stride, u64 *dst, size_t dst_poly_stride, uint32_t npoly,
-                          uint32_t mod_idx, bool inverse) {
+                          uint32_t mod_idx, bool inverse, const mod_t *explicit_mod) {
     if (!npoly) return 0;
     lm_modmap map = lm_map_q(1);
     map.idx[0] = 0; // the kernel adds mi * N to the table pointer: keep mi = 0 and pass the modulus in slot 0
     lm_mods mods = ctx->mods;
-    mods.m[0] = ctx->mods.m[mod_idx];
+    mods.m[0] = explicit_mod ? *explicit_mod : ctx->mods.m[mod_idx];
     lm_ninv_t ninv = lm_ninv_of(ctx);
     ninv.t[0] = ninv_scale;
     const size_t lds = inverse ? lm_inv_lds(logn) : lm_fwd_lds(logn);

@@ -62,6 +62,8 @@ SYMBOLS = {
     "lumen_leaf_digests": (C.c_int, [_vp, _vp, _u8p]),
     "lumen_load_public_key": (C.c_int, [_vp, _u64p]),
     "lumen_encrypt_pk": (C.c_int, [_vp, _u64p, C.c_uint32, _u8p, C.c_uint64, C.POINTER(_vp)]),
+    "lumen_encoder_set": (C.c_int, [_vp, C.c_uint64]),
+    "lumen_encrypt_values": (C.c_int, [_vp, _u64p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, C.POINTER(_vp)]),
     "lumen_leaf_digests_begin": (C.c_int, [_vp, _vp]),
     "lumen_leaf_digests_end": (C.c_int, [_vp, _u8p]),
     "lumen_merkle_build": (C.c_int, [_vp, _u8p, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t), _u8p]),
@@ -264,6 +266,19 @@ class Context:
         h = C.c_void_p()
         self._ck(self.lib.lumen_encrypt_pk(self.h, _p64(plaintexts) if plaintexts is not None else None, count,
                                            seed.ctypes.data_as(_u8p), first_index, C.byref(h)))
+        return DeviceSet(self, h)
+
+    def encoder_set(self, psi_t):
+        self._ck(self.lib.lumen_encoder_set(self.h, psi_t))
+
+    def encrypt_values(self, values, seed, first_index=0):
+        """Encoder.Encode + EncryptNew of every row of `values` ([count][rows] slot values)."""
+        seed = np.ascontiguousarray(seed, dtype=np.uint8)
+        values = np.ascontiguousarray(values, dtype=np.uint64)
+        assert seed.size == 32 and values.ndim == 2
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_encrypt_values(self.h, _p64(values), values.shape[1], values.shape[0],
+                                               seed.ctypes.data_as(_u8p), first_index, C.byref(h)))
         return DeviceSet(self, h)
 
     def leaf_digests_begin(self, s):

@@ -184,6 +184,8 @@ ServerBFV::ServerBFV(core::PrimeField *plaintextField, const Parameters &params,
     check(lumen_field_set(ctx_, plaintextField->RootsForward().data(), (uint32_t)plaintextField->N()), "lumen_field_set");
     for (const auto &kv : evk) check(lumen_load_galois_key(ctx_, kv.first, kv.second.data()), "lumen_load_galois_key");
     check(lumen_load_public_key(ctx_, pk_.data()), "lumen_load_public_key");
+    check(lumen_encoder_set(ctx_, PowMod(core::PrimitiveRoot(params.T), (params.T - 1) / (2ull << params.LogN), params.T)),
+          "lumen_encoder_set");
     for (auto &b : enc_seed_) b = (uint8_t)rng_(); // the reference keys its PRNG from crypto/rand
     // encoder tables ([LATTIGO-RECALL] bgv.Encoder: slot i of row 0 sits at 5^i, row 1 at -5^i)
     const uint64_t T = params.T, two_n = 2ull << params.LogN;
@@ -269,6 +271,17 @@ Ciphertexts ServerBFV::EncryptNewBatch(const std::vector<Plaintext> &pts) {
     lumen_set *set = nullptr;
     check(lumen_encrypt_pk(ctx_, flat.data(), (uint32_t)pts.size(), enc_seed_, enc_next_, &set), "lumen_encrypt_pk");
     enc_next_ += pts.size();
+    return Ciphertexts(ctx_, set);
+}
+
+Ciphertexts ServerBFV::EncryptColumnsNew(const std::vector<uint64_t> &values, int rows, int count) {
+    // Encoder.Encode + EncryptNew of `count` columns of `rows` slot values (cmd/server/main.go:188-208)
+    // in one device call: only the raw values cross PCIe
+    if ((size_t)rows * count != values.size()) throw std::invalid_argument("EncryptColumnsNew: size mismatch");
+    lumen_set *set = nullptr;
+    check(lumen_encrypt_values(ctx_, values.data(), (uint32_t)rows, (uint32_t)count, enc_seed_, enc_next_, &set),
+          "lumen_encrypt_values");
+    enc_next_ += (uint64_t)count;
     return Ciphertexts(ctx_, set);
 }
 

@@ -92,6 +92,8 @@ class ServerBFV {
     // the same for a batch of MaxLevel plaintexts, on the device (lumen_encrypt_pk): the witness
     // encryption loop of cmd/server/main.go:199-208; the result stays in HBM
     Ciphertexts EncryptNewBatch(const std::vector<Plaintext> &pts);
+    // Encoder.Encode + EncryptNew of `count` columns of `rows` values ([count][rows]), both on the device
+    Ciphertexts EncryptColumnsNew(const std::vector<uint64_t> &values, int rows, int count);
     void check(int rc, const char *what) const; // throws std::runtime_error with lumen_last_error
     void SetRingSwitchServer(RingSwitchServer *rs) { rs_ = rs; } // bfv.go:48-50
     RingSwitchServer *RingSwitch() const { return rs_; }          // bfv.go:52-54

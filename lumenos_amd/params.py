@@ -135,6 +135,12 @@ def generate_bgv_params_for_ntt(ntt_size: int, log_n: int, T: int = T_REFERENCE)
     return BGVParams(log_n, q, p, psi, T)
 
 
+def encoder_psi(T: int, log_n: int) -> int:
+    """Primitive 2N-th root of unity of the encoder's Z_T ring ([LATTIGO-RECALL] ring.NewRing(N, [T]):
+    g^((T-1)/2N) for the smallest primitive root g of T) -- the argument of lumen_encoder_set."""
+    return pow(primitive_root(T), (T - 1) // (2 << log_n), T)
+
+
 def field_roots_forward(T: int, field_n: int) -> List[int]:
     """core/field.go:138-197: RootsForward[bitrev(j)] = psi^j * 2^64 mod T, psi of order 2*fieldN."""
     nth_root = 2 * field_n

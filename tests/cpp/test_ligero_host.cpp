@@ -67,14 +67,17 @@ int main(int argc, char **argv) {
     printf("Number of queried columns: %d\n", ligero.Metadata.Queries);
     REQUIRE(ligero.Metadata.Queries == 309, "queries");
     core::Span *span = core::Span::StartSpan("Encrypt matrix", nullptr);
-    std::vector<fhe::Plaintext> batched(cols);
-    for (int j = 0; j < cols; j++) {
-        std::vector<uint64_t> column(rows);
-        for (int i = 0; i < rows; i++) column[i] = matrix[(size_t)i * cols + j];
-        batched[j] = server.Encode(column);
+    std::vector<uint64_t> columns((size_t)cols * rows); // [cols][rows]: the batched columns of the witness
+    for (int j = 0; j < cols; j++)
+        for (int i = 0; i < rows; i++) columns[(size_t)j * rows + i] = matrix[(size_t)i * cols + j];
+    // Encoder.Encode + EncryptNew on the device (lumen_encrypt_values); one column also goes through the
+    // host encoder + lumen_encrypt_pk to keep that pair exercised
+    fhe::Ciphertexts ciphertexts = server.EncryptColumnsNew(columns, rows, cols);
+    {
+        std::vector<uint64_t> col0(columns.begin(), columns.begin() + rows);
+        fhe::Ciphertexts one = server.EncryptNewBatch({server.Encode(col0)});
+        REQUIRE(one.Len() == 1, "EncryptNewBatch");
     }
-    fhe::Ciphertexts ciphertexts = server.EncryptNewBatch(batched); // on the device (lumen_encrypt_pk)
-    batched.clear();
     span->End();
 
     span = core::Span::StartSpan("Commit FHE evaluation", nullptr, "Commit FHE evaluation...");

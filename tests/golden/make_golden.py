@@ -44,8 +44,31 @@ def main():
     np.savez_compressed(os.path.join(HERE, "evaluator.npz"), cts=cts, pt=pt, rows=np.uint32(rows),
                         gal_els=np.array(gl, dtype=np.uint64), evks=evks, level1=lvl1, digests=dig,
                         matrix_inner_sum=mis, **meta)
+    encrypt_fixture(o)
     print("golden fixtures written to", HERE)
 
 
+def encrypt_fixture(o):
+    """Deterministic pk encryption (oracle/lo_encdet.c): pins the sampler (ChaCha20 word layout, CDT)
+    and the ciphertext assembly for the CPU suite and the GPU replay."""
+    P = make_params(o, 8, 2)
+    P.seed(77)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    seed = np.frombuffer(bytes((7 * i + 3) % 256 for i in range(32)), dtype=np.uint8)
+    vals = np.random.default_rng(5).integers(0, T_REF, size=(3, P.N), dtype=np.uint64)
+    pts = np.stack([P.encode(v) for v in vals])
+    first = 2**32 + 9
+    cts = np.stack([P.encrypt_det(pk, pts[i], seed, first + i) for i in range(3)])
+    small = np.stack([np.stack([P.det_small(seed, first + i, s) for s in range(3)]) for i in range(3)])
+    np.savez_compressed(os.path.join(HERE, "encrypt_det.npz"), log_n=8, q=np.array(P.moduli[:2], dtype=np.uint64),
+                        p=np.array(P.moduli[2:], dtype=np.uint64), psi=np.array(P.psi, dtype=np.uint64),
+                        T=np.uint64(T_REF), sk=sk, pk=pk, seed=seed, first=np.uint64(first), values=vals,
+                        plaintexts=pts, small=small, ciphertexts=cts)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "encrypt":  # add this fixture without rewriting the others
+        encrypt_fixture(Oracle())
+    else:
+        main()

@@ -490,3 +490,36 @@ def test_encrypted_witness_runs_through_the_prover(oracle):
         want = int(np.sum(W[:, j].astype(object) * (r.astype(object) % T_REF)) % T_REF)
         assert int(P.decrypt(sk, got[j], 1, scale)[0]) == want, j
     ctx.close()
+
+
+def test_golden_encrypt_det_gpu():
+    """The committed fixture of the deterministic encryption, replayed through lumen_encrypt_pk."""
+    g = np.load(os.path.join(GOLD, "encrypt_det.npz"))
+    ctx = _ctx_from_golden(g)
+    ctx.load_public_key(g["pk"])
+    got = ctx.encrypt_pk(g["plaintexts"], 3, g["seed"], int(g["first"])).download()
+    assert np.array_equal(got, g["ciphertexts"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("log_n,num_q,rows", [(10, 3, 1024), (10, 2, 300), (12, 2, 4096), (14, 2, 16384)])
+def test_encrypt_values_matches_oracle_encode_then_encrypt(oracle, log_n, num_q, rows):
+    """lumen_encrypt_values (Encoder.Encode on the device, fused into the encryption's transforms) ==
+    oracle Encode followed by the deterministic encryption, bit for bit; decrypts to the slot values."""
+    from lumenos_amd import params as lp
+    P = make_params(oracle, log_n, num_q)
+    P.seed(100 + log_n)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    ctx = make_context(P)
+    ctx.load_public_key(pk)
+    ctx.encoder_set(lp.encoder_psi(T_REF, log_n))
+    seed = np.frombuffer(bytes(range(50, 82)), dtype=np.uint8)
+    rng = np.random.default_rng(rows)
+    count, first = 3, 12345
+    vals = rng.integers(0, 2**64, size=(count, rows), dtype=np.uint64)  # unreduced, as Prove's r (ligero.go:202)
+    got = ctx.encrypt_values(vals, seed, first).download()
+    for i in range(count):
+        assert np.array_equal(got[i], P.encrypt_det(pk, P.encode(vals[i]), seed, first + i)), i
+        assert np.array_equal(P.decrypt(sk, got[i], rows), vals[i] % np.uint64(T_REF)), i
+    ctx.close()

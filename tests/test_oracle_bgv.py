@@ -221,3 +221,17 @@ def test_det_sampler_chacha_layout(oracle):
                                0, ks.ctypes.data_as(C.POINTER(C.c_uint8)), ks.size)
     w = ks.view("<u4").astype(np.uint64)
     assert np.array_equal(P.det_small(seed, idx, 0).astype(np.int64), ((w * 3) >> 32).astype(np.int64) - 1)
+
+
+def test_golden_encrypt_det(oracle):
+    """tests/golden/encrypt_det.npz: the sampler's small polynomials and the ciphertexts, replayed."""
+    from oracle.loader import Params
+    g = np.load(os.path.join(GOLD, "encrypt_det.npz"))
+    P = Params.from_moduli(oracle, int(g["log_n"]), [int(x) for x in g["q"]], [int(x) for x in g["p"]], int(g["T"]))
+    first = int(g["first"])
+    for i in range(3):
+        for s in range(3):
+            assert np.array_equal(P.det_small(g["seed"], first + i, s), g["small"][i, s]), (i, s)
+        ct = P.encrypt_det(g["pk"], g["plaintexts"][i], g["seed"], first + i)
+        assert np.array_equal(ct, g["ciphertexts"][i]), i
+        assert np.array_equal(P.decrypt(g["sk"], ct, P.N), g["values"][i]), i

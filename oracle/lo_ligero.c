@@ -47,12 +47,13 @@ void lo_commit_leaves(const lo_params *p, const uint64_t *encoded, uint32_t coun
 
 /* matrixInnerSumEval (fhe/ligero.go:299-370) without the ring switch:
  * out[j] = RescaleToLevel1(InnerSum(MulNew(matrix[j], pt), 1, rows)).
- * out: [cols][2][2][N]. */
+ * out: [cols][2][min(nl,2)][N]. */
 void lo_matrix_inner_sum(const lo_params *p, const uint64_t *matrix, uint32_t cols, uint32_t nl,
                          const uint64_t *pt, uint32_t rows, const uint64_t *const *evks,
                          uint64_t *out) {
     uint32_t N = p->N;
-    size_t ctw = (size_t)2 * nl * N, l1w = (size_t)4 * N;
+    /* a single-limb chain has nothing to rescale: out is then [cols][2][1][N] */
+    size_t ctw = (size_t)2 * nl * N, l1w = (size_t)2 * (nl < 2 ? nl : 2) * N;
 #pragma omp parallel
     {
         uint64_t *col = (uint64_t *)malloc(ctw * sizeof(uint64_t));

@@ -460,7 +460,7 @@ class Params:
     def matrix_inner_sum(self, matrix, pt, rows, evks):
         matrix = np.ascontiguousarray(matrix, dtype=np.uint64)
         cols, _, nl, N = matrix.shape
-        out = np.zeros((cols, 2, 2, N), dtype=np.uint64)
+        out = np.zeros((cols, 2, min(nl, 2), N), dtype=np.uint64)
         self.o.lib.lo_matrix_inner_sum(self.h, _p64(matrix), cols, nl, _p64(pt), rows, self._evk_ptrs(evks), _p64(out))
         return out
 

@@ -1,0 +1,98 @@
+"""Randomised differential run of the HIP path against the CPU oracle (developer tool, not collected
+by pytest): random ring degrees, limb counts, 1 or 2 special primes, random shapes.
+
+usage: python tests/dev/fuzz_gpu.py [cases] [seed]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+from helpers import T_REF, make_context, make_params, random_cts  # noqa: E402
+from oracle.loader import Oracle  # noqa: E402
+
+
+def one_case(o, rng, case):
+    log_n = int(rng.choice([8, 10, 10, 11, 12]))
+    num_q = int(rng.integers(1, 7))
+    num_p = int(rng.choice([1, 2]))
+    P = make_params(o, log_n, num_q, num_p)
+    P.seed(int(rng.integers(1, 2**31)))
+    ctx = make_context(P)
+    tag = f"case {case}: logN={log_n} L={num_q} K={num_p}"
+    what = []
+    # limb transforms
+    cts = random_cts(P, int(rng.integers(1, 4)), num_q, seed=int(rng.integers(1, 2**31)))
+    s = ctx.upload(cts)
+    ctx.set_ntt(s, False)
+    got = s.download()
+    for l in range(num_q):
+        assert np.array_equal(got[0, 1, l], P.limb_ntt(cts[0, 1, l], l)), (tag, "ntt", l)
+    ctx.set_ntt(s, True)
+    assert np.array_equal(s.download(), cts), (tag, "intt")
+    what.append("ntt")
+    # rescale to a random level
+    if num_q > 1:
+        target = int(rng.integers(1, num_q))
+        got = ctx.rescale(ctx.upload(cts), target).download()
+        ref = cts[0]
+        while ref.shape[1] > target:
+            ref = P.rescale(ref)
+        assert np.array_equal(got[0], ref), (tag, "rescale", target)
+        what.append(f"rescale->{target}")
+    # ciphertext-axis transform
+    S = int(rng.choice([2, 4, 8, 16, 32, 64]))
+    roots = o.field_roots(T_REF, max(S, 16))
+    ctx.field_set(roots)
+    nl = min(num_q, 2)
+    c2 = random_cts(P, S, nl, seed=case)
+    s2 = ctx.upload(c2)
+    ctx.ct_ntt(s2, S)
+    assert np.array_equal(s2.download(), P.ct_ntt(c2, S, roots)), (tag, "ct_ntt", S)
+    what.append(f"ct_ntt{S}")
+    # key switch: InnerSum of a random power-of-two length, then the whole matrixInnerSumEval
+    sk = P.keygen_secret()
+    n = 1 << int(rng.integers(1, min(log_n, 6) + 1))
+    gl = P.inner_sum_galois_elements(n)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    c3 = random_cts(P, int(rng.integers(1, 4)), num_q, seed=case + 7)
+    got = ctx.inner_sum(ctx.upload(c3), n).download()
+    for c in range(c3.shape[0]):
+        assert np.array_equal(got[c], P.inner_sum(c3[c], n, evks)), (tag, "inner_sum", n, c)
+    pt = P.encode(rng.integers(0, 2**63, size=n, dtype=np.uint64))
+    got = ctx.matrix_inner_sum(ctx.upload(c3), pt, n).download()
+    assert np.array_equal(got, P.matrix_inner_sum(c3, pt, n, evks)), (tag, "matrix_inner_sum", n)
+    what.append(f"inner_sum{n}")
+    # encryption
+    pk = P.keygen_public(sk)
+    ctx.load_public_key(pk)
+    seed = rng.integers(0, 256, size=32, dtype=np.uint8)
+    first = int(rng.integers(0, 2**62))
+    pts = np.stack([P.encode(rng.integers(0, T_REF, size=P.N, dtype=np.uint64)) for _ in range(2)])
+    got = ctx.encrypt_pk(pts, 2, seed, first).download()
+    assert np.array_equal(got[1], P.encrypt_det(pk, pts[1], seed, first + 1)), (tag, "encrypt")
+    what.append("encrypt")
+    ctx.close()
+    print(tag, "ok:", " ".join(what), flush=True)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    o = Oracle()
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    for case in range(cases):
+        one_case(o, rng, case)
+    print(f"{cases} random cases bit-exact in {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()

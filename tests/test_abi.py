@@ -50,3 +50,29 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not pat.search(src), os.path.join(dirpath, f)
                 assert "liblumen_oracle" not in src, os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c99_and_a_c_consumer_compiles():
+    """The boundary is a C ABI: the header parses as pedantic C99 and a C translation unit using it
+    compiles (what a cgo preamble needs)."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(inc, "lumenos_hip.h")])
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + inc, "-fsyntax-only",
+                           os.path.join(ROOT, "tests", "cpp", "abi_smoke.c")])
+
+
+@pytest.mark.gpu
+def test_c_consumer_runs_on_the_gpu():
+    """tests/cpp/abi_smoke.c linked against liblumenos_hip.so only: context from explicit moduli,
+    NTT/INTT round trip, error convention."""
+    import subprocess
+    from lumenos_amd import _build
+    lib = _build.build()
+    exe = os.path.join(ROOT, "tests", "cpp", "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "abi_smoke.c"), "-o", exe,
+                           "-L" + os.path.dirname(lib), "-llumenos_hip", "-Wl,-rpath," + os.path.dirname(lib)])
+    out = subprocess.check_output([exe]).decode()
+    assert "abi_smoke OK" in out

@@ -1,7 +1,7 @@
 """Randomised differential run of the HIP path against the CPU oracle (developer tool, not collected
 by pytest): random ring degrees, limb counts, 1 or 2 special primes, random shapes.
 
-usage: python tests/dev/fuzz_gpu.py [cases] [seed]
+usage: [FUZZ_LOGN=13,14] python tests/dev/fuzz_gpu.py [cases] [seed]
 """
 import os
 import sys
@@ -18,7 +18,7 @@ from oracle.loader import Oracle  # noqa: E402
 
 
 def one_case(o, rng, case):
-    log_n = int(rng.choice([8, 10, 10, 11, 12]))
+    log_n = int(rng.choice([int(x) for x in os.environ.get("FUZZ_LOGN", "8,10,10,11,12").split(",")]))
     num_q = int(rng.integers(1, 7))
     num_p = int(rng.choice([1, 2]))
     P = make_params(o, log_n, num_q, num_p)

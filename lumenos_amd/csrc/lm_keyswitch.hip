@@ -116,19 +116,18 @@ template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *__restrict__ coef, const u64 *__restrict__ acc,
                                                     u64 *__restrict__ ext, const bx_t *__restrict__ bx,
                                                     uint32_t B, uint32_t L, uint32_t K, uint32_t beta,
-                                                    lm_mods mods, const tw_t *__restrict__ tw_all) {
+                                                    const uint16_t *__restrict__ pairs, lm_mods mods,
+                                                    const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
     constexpr uint32_t N = 1u << LOGN;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
-    // target-major order keeps one twiddle table hot per XCD L2
-    uint32_t r = blockIdx.x;
-    const uint32_t b = r % B;
-    r /= B;
-    const uint32_t d = r % beta;
-    const uint32_t t = r / beta; // modulus index (Q limbs then P limbs)
+    // the grid only holds the (digit, target) pairs that need an extension (a digit's own limbs reuse
+    // the NTT-domain c1: a workgroup that merely exited would still have held a CU's LDS while it was
+    // dispatched), target-major: one twiddle table stays hot per XCD L2
+    const uint32_t b = blockIdx.x % B, pr = pairs[blockIdx.x / B];
+    const uint32_t d = pr & 0xFF, t = pr >> 8; // t: modulus index (Q limbs then P limbs)
     const bx_t c = bx[d * LK + t];
     u64 *o = ext + (((size_t)b * beta + d) * LK + t) * N;
-    if (c.own) return; // own limb: the gadget product reads the original NTT-domain c1 directly
     const lm_qc qc = lm_make_qc(mods.m[t]);
     const u64 *s0 = coef + ((size_t)b * L + d * K) * N;
     const u64 *s1 = c.ns == 2 ? s0 + N : s0; // second limb of the digit
@@ -370,7 +369,10 @@ struct KsTables {
     tw_t *d_pinv = nullptr;  // [L]  P^-1 mod q_t
     uint32_t beta = 0;
     lm_ninv_t yscale; // per modulus: N^-1 * (M/m)^-1 mod m of the source group the modulus sits in
+    uint16_t *d_pairs = nullptr; // (digit | target << 8) of every extension the key switch needs, target-major
+    uint32_t npairs = 0;
     ~KsTables() {
+        hipFree(d_pairs);
         hipFree(d_bx);
         hipFree(d_bxp);
         hipFree(d_pinv);
@@ -436,6 +438,13 @@ int get_tables(lumen_ctx *ctx, KsTables **out) {
         for (uint32_t a = 0; a < K; a++) P = h_mulmod(P, ctx->mod[L + a] % q, q);
         pinv[t] = h_tw(h_invmod(P, q), q);
     }
+    std::vector<uint16_t> pairs;
+    for (uint32_t t = 0; t < LK; t++)
+        for (uint32_t d = 0; d < tb.beta; d++)
+            if (!bx[(size_t)d * LK + t].own) pairs.push_back((uint16_t)(d | (t << 8)));
+    tb.npairs = (uint32_t)pairs.size();
+    LM_HIP(ctx, hipMalloc((void **)&tb.d_pairs, pairs.size() * sizeof(uint16_t)));
+    LM_HIP(ctx, hipMemcpy(tb.d_pairs, pairs.data(), pairs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     LM_HIP(ctx, hipMalloc((void **)&tb.d_bx, bx.size() * sizeof(bx_t)));
     LM_HIP(ctx, hipMalloc((void **)&tb.d_bxp, bxp.size() * sizeof(bx_t)));
     LM_HIP(ctx, hipMalloc((void **)&tb.d_pinv, pinv.size() * sizeof(tw_t)));
@@ -521,14 +530,14 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
     }
     // 2. digit extension + NTT
     {
-        const uint64_t nb = (uint64_t)B * beta * LK;
-        lm_prof_scope ps(ctx, "ks_modup_ntt", (uint64_t)B * (beta * LK - L));
+        const uint64_t nb = (uint64_t)B * tb->npairs;
+        lm_prof_scope ps(ctx, "ks_modup_ntt", nb);
         switch (ctx->logN) {
 #define LM_CASE(n)                                                                                            \
     case n:                                                                                                   \
         LM_LDS_ATTR(ctx, k_modup_ntt<n>, lds);               \
         hipLaunchKernelGGL(k_modup_ntt<n>, dim3((uint32_t)nb), dim3(threads), lds, ctx->stream, s.coef, acc,  \
-                           s.ext, tb->d_bx, B, L, K, beta, ctx->mods, ctx->d_tw_fwd);                         \
+                           s.ext, tb->d_bx, B, L, K, beta, tb->d_pairs, ctx->mods, ctx->d_tw_fwd);            \
         break;
             LM_FOR_EACH_LOGN(LM_CASE)
 #undef LM_CASE

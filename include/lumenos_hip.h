@@ -147,6 +147,16 @@ int lumen_encrypt_values(lumen_ctx *ctx, const uint64_t *values, uint32_t rows, 
 int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint32_t count, const uint8_t seed[32],
                      uint64_t first_index, lumen_set **out);
 
+/* ---- client-side decryption of the proof's ciphertexts: EncryptedProof.Decrypt /
+ * decryptBatchedParallel (fhe/ligero.go:381-502, 577-636) = Decryptor.DecryptNew + Encoder.Decode.
+ * For a client that owns a GPU and for end-to-end tests: the proving server never holds sk.
+ * sk: [L][N], NTT domain.  set: ciphertexts of one or two limbs (level <= 1, what Prove returns).
+ * scale: the ciphertexts' Scale, i.e. the product of the dropped moduli's inverses modulo T that the
+ * rescales left behind (1 if none); values: host, [count][nvalues] slot values.
+ * Needs lumen_encoder_set. */
+int lumen_load_secret_key(lumen_ctx *ctx, const uint64_t *sk);
+int lumen_decrypt(lumen_ctx *ctx, const lumen_set *set, uint64_t scale, uint32_t nvalues, uint64_t *values);
+
 /* ---- Galois keys: rlwe.EvaluationKeySet entries used by InnerSum.
  * evk host layout [digit(beta)][b|a][limb(L+K)][N], NTT domain, standard form
  * (the Go shim converts from Lattigo's Montgomery-form GadgetCiphertext). */

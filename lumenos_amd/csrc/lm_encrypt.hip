@@ -218,12 +218,14 @@ extern "C" int lumen_load_public_key(lumen_ctx *ctx, const uint64_t *pk) {
 struct EncoderTables {
     uint32_t *d_slot = nullptr; // [N] slot -> coefficient position of the Z_T transform
     tw_t *d_tw_inv = nullptr;   // [N] inverse twiddles modulo T
+    tw_t *d_tw_fwd = nullptr;   // [N] forward twiddles modulo T (Encoder.Decode)
     mod_t modT;
     tw_t ninvT;
     enc_tinv_t tinv; // T^-1 mod q_l
     ~EncoderTables() {
         if (d_slot) hipFree(d_slot);
         if (d_tw_inv) hipFree(d_tw_inv);
+        if (d_tw_fwd) hipFree(d_tw_fwd);
     }
 };
 
@@ -255,6 +257,8 @@ extern "C" int lumen_encoder_set(lumen_ctx *ctx, uint64_t psi_t) {
     LM_HIP(ctx, hipMalloc((void **)&sp->d_tw_inv, (size_t)N * sizeof(tw_t)));
     LM_HIP(ctx, hipMemcpy(sp->d_slot, slot.data(), (size_t)N * 4, hipMemcpyHostToDevice));
     LM_HIP(ctx, hipMemcpy(sp->d_tw_inv, b.data(), (size_t)N * sizeof(tw_t), hipMemcpyHostToDevice));
+    LM_HIP(ctx, hipMalloc((void **)&sp->d_tw_fwd, (size_t)N * sizeof(tw_t)));
+    LM_HIP(ctx, hipMemcpy(sp->d_tw_fwd, f.data(), (size_t)N * sizeof(tw_t), hipMemcpyHostToDevice));
     ctx->ext["encoder"] = sp;
     return 0;
 }
@@ -376,4 +380,174 @@ extern "C" int lumen_encrypt_values(lumen_ctx *ctx, const uint64_t *values, uint
                                     const uint8_t seed[32], uint64_t first_index, lumen_set **out) {
     LM_CHECK(nullptr, ctx && values && seed && out, "lumen_encrypt_values: NULL argument");
     return encrypt_impl(ctx, nullptr, values, rows, count, seed, first_index, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Client-side decryption of level-<=1 ciphertexts: EncryptedProof.Decrypt /
+// decryptBatchedParallel (fhe/ligero.go:381-502, 577-636) = Decryptor.DecryptNew + Encoder.Decode
+// [LATTIGO-RECALL]: phase = c0 + c1*s, to the coefficient domain, times T; CRT over the (<= 2) limbs,
+// centred, reduced modulo T; NTT over Z_T; slot i read at the encoder's index; divided by the scale
+// the rescales left behind.  The secret key lives with the client: this entry point is for a client
+// that owns a GPU and for end-to-end tests, not for the proving server.
+struct SkTable {
+    tw_t *d_sk = nullptr; // [L][N] Shoup form
+    ~SkTable() {
+        if (d_sk) hipFree(d_sk);
+    }
+};
+
+extern "C" int lumen_load_secret_key(lumen_ctx *ctx, const uint64_t *sk) {
+    LM_CHECK(nullptr, ctx && sk, "lumen_load_secret_key: NULL argument");
+    const uint32_t N = ctx->N, L = ctx->L;
+    std::vector<tw_t> tab((size_t)L * N);
+    for (uint32_t l = 0; l < L; l++) {
+        const uint64_t q = ctx->mod[l];
+        for (uint32_t k = 0; k < N; k++) {
+            const uint64_t x = sk[(size_t)l * N + k];
+            if (x >= q) return lm_fail(ctx, "secret key residue out of range (limb %u)", l);
+            tab[(size_t)l * N + k] = h_tw(x, q);
+        }
+    }
+    auto sp = std::make_shared<SkTable>();
+    LM_HIP(ctx, hipMalloc((void **)&sp->d_sk, tab.size() * sizeof(tw_t)));
+    LM_HIP(ctx, hipMemcpy(sp->d_sk, tab.data(), tab.size() * sizeof(tw_t), hipMemcpyHostToDevice));
+    ctx->ext["secret_key"] = sp;
+    return 0;
+}
+
+// phase[c][l] = INTT(c0 + c1 * s) * T   (one workgroup per (ciphertext, limb); T * N^-1 folded)
+struct dec_scale_t {
+    tw_t t[2];
+};
+template <int LOGN>
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_decrypt_phase(const u64 *__restrict__ ct, const tw_t *__restrict__ sk,
+                                                                       u64 *__restrict__ phase, uint32_t count, uint32_t nl,
+                                                                       dec_scale_t scale, lm_mods mods,
+                                                                       const tw_t *__restrict__ tw_all) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm[];
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    const uint32_t l = blockIdx.x / count, c = blockIdx.x % count;
+    const lm_qc qc = lm_make_qc(mods.m[l]);
+    const u64 *c0 = ct + ((size_t)c * 2 * nl + l) * N, *c1 = c0 + (size_t)nl * N;
+    const tw_t *s = sk + (size_t)l * N;
+    u64 *o = phase + ((size_t)c * nl + l) * N;
+    const tw_t sc = scale.t[l];
+    auto ld = [&](uint32_t i0, u64 *v, int n) {
+        u64 a[8], b[8];
+        lm_load_run(c0, i0, a, n);
+        lm_load_run(c1, i0, b, n);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < n) {
+                const tw_t sv = s[i0 + k];
+                const u64 x = lm_shoup3<false>(b[k], sv.w, sv.wp, qc.nq, a[k]); // c0 + c1*s, lazily: < 4q
+                v[k] = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
+            }
+    };
+    auto st = [&](uint32_t i, u64 v) { o[i] = lm_shoup_cs(v, sc, qc.q, qc.nq); };
+    lm_ntt_inverse<LOGN>(sm, tw_all + (size_t)l * N, qc, tid, nthreads, ld, st);
+}
+
+// m[c][k] = centre_Q(CRT(phase limbs)) mod T
+__global__ void k_decrypt_crt(const u64 *__restrict__ phase, u64 *__restrict__ m, uint32_t nl, uint32_t logN, size_t total,
+                              mod_t m0, mod_t m1, tw_t q0inv_mod_q1, mod_t modT) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const size_t c = g >> logN, k = g & (((size_t)1 << logN) - 1);
+    const u64 *p = phase + ((c * nl) << logN) + k;
+    const u64 T = modT.q, y0 = p[0];
+    if (nl == 1) {
+        const u64 q0 = m0.q;
+        m[g] = y0 > (q0 >> 1) ? (T - lm_reduce(q0 - y0, T, modT.qinv64)) % T : lm_reduce(y0, T, modT.qinv64);
+        return;
+    }
+    const u64 q0 = m0.q, q1 = m1.q, y1 = p[(size_t)1 << logN];
+    // Garner: y = y0 + q0 * ((y1 - y0) * q0^-1 mod q1)
+    const u64 h = lm_shoup(lm_submod(y1, lm_reduce(y0, q1, m1.qinv64), q1), q0inv_mod_q1, q1);
+    const u128 Q = (u128)q0 * q1, y = (u128)y0 + (u128)q0 * h;
+    m[g] = y > (Q >> 1) ? (T - (u64)((Q - y) % T)) % T : (u64)(y % T);
+}
+
+// values[c][i] = t[c][slot[i]] * scale^-1 mod T
+__global__ void k_decrypt_slots(const u64 *__restrict__ t, const uint32_t *__restrict__ slot, u64 *__restrict__ values,
+                                uint32_t nvalues, uint32_t logN, size_t total, tw_t sinv, u64 T) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const size_t c = g / nvalues;
+    const uint32_t i = (uint32_t)(g % nvalues);
+    values[g] = lm_shoup(t[(c << logN) + slot[i]], sinv, T);
+}
+
+template <int LOGN>
+static int decrypt_phase_t(lumen_ctx *ctx, const u64 *ct, const tw_t *sk, u64 *phase, uint32_t count, uint32_t nl,
+                           const dec_scale_t &sc) {
+    const size_t lds = lm_inv_lds(ctx->logN);
+    LM_LDS_ATTR(ctx, k_decrypt_phase<LOGN>, lds);
+    lm_prof_scope ps(ctx, "decrypt_phase_intt", (uint64_t)count * nl);
+    hipLaunchKernelGGL(k_decrypt_phase<LOGN>, dim3(count * nl), dim3(lm_inv_threads(ctx->logN)), lds, ctx->stream, ct, sk,
+                       phase, count, nl, sc, ctx->mods, ctx->d_tw_inv);
+    LM_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int lumen_decrypt(lumen_ctx *ctx, const lumen_set *set, uint64_t scale, uint32_t nvalues, uint64_t *values) {
+    LM_CHECK(nullptr, ctx && set && values, "lumen_decrypt: NULL argument");
+    LM_CHECK(ctx, set->nl >= 1 && set->nl <= 2, "lumen_decrypt takes ciphertexts of one or two limbs (have %u)", set->nl);
+    LM_CHECK(ctx, nvalues >= 1 && nvalues <= ctx->N, "nvalues=%u out of range [1, N]", nvalues);
+    auto is = ctx->ext.find("secret_key");
+    LM_CHECK(ctx, is != ctx->ext.end(), "no secret key loaded (lumen_load_secret_key)");
+    auto ie = ctx->ext.find("encoder");
+    LM_CHECK(ctx, ie != ctx->ext.end(), "no encoder tables (lumen_encoder_set)");
+    const SkTable *sk = static_cast<const SkTable *>(is->second.get());
+    const EncoderTables *enc = static_cast<const EncoderTables *>(ie->second.get());
+    const uint32_t N = ctx->N, nl = set->nl, count = set->count;
+    const uint64_t T = ctx->T;
+    LM_CHECK(ctx, scale % T != 0, "scale is 0 modulo T");
+    if (!count) return 0;
+    u64 *phase = (u64 *)lm_scratch(ctx, "dec_phase", (size_t)count * nl * N * sizeof(u64));
+    u64 *m = (u64 *)lm_scratch(ctx, "dec_m", (size_t)count * N * sizeof(u64));
+    u64 *dv = (u64 *)lm_scratch(ctx, "dec_values", (size_t)count * nvalues * sizeof(u64));
+    if (!phase || !m || !dv) return 1;
+    dec_scale_t sc;
+    for (uint32_t l = 0; l < 2; l++) {
+        const uint64_t q = ctx->mod[l < nl ? l : 0];
+        sc.t[l] = h_tw(h_mulmod(ctx->ninv[l < nl ? l : 0].w, T % q, q), q);
+    }
+    int rc = 0;
+    switch (ctx->logN) {
+#define LM_CASE(k) \
+    case k:        \
+        rc = decrypt_phase_t<k>(ctx, set->d, sk->d_sk, phase, count, nl, sc); \
+        break;
+        LM_FOR_EACH_LOGN(LM_CASE)
+#undef LM_CASE
+    default:
+        rc = lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
+    }
+    if (rc) return rc;
+    {
+        lm_prof_scope ps(ctx, "decrypt_crt", count);
+        const size_t total = (size_t)count * N;
+        const uint64_t q0 = ctx->mod[0], q1 = ctx->mod[nl > 1 ? 1 : 0];
+        const tw_t q0inv = nl > 1 ? h_tw(h_invmod(q0 % q1, q1), q1) : h_tw(1, q1);
+        hipLaunchKernelGGL(k_decrypt_crt, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, phase, m, nl,
+                           ctx->logN, total, ctx->mods.m[0], ctx->mods.m[nl > 1 ? 1 : 0], q0inv, enc->modT);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    {
+        lm_prof_scope ps(ctx, "decode_ntt_T", count);
+        if (int r2 = lm_launch_ntt_subring(ctx, ctx->logN, enc->d_tw_fwd, enc->ninvT, m, N, m, N, count, 0, false, &enc->modT))
+            return r2;
+    }
+    {
+        const size_t total = (size_t)count * nvalues;
+        const tw_t sinv = h_tw(h_invmod(scale % T, T), T);
+        hipLaunchKernelGGL(k_decrypt_slots, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, m, enc->d_slot,
+                           dv, nvalues, ctx->logN, total, sinv, T);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    LM_HIP(ctx, hipMemcpyAsync(values, dv, (size_t)count * nvalues * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
 }

@@ -63,6 +63,8 @@ SYMBOLS = {
     "lumen_load_public_key": (C.c_int, [_vp, _u64p]),
     "lumen_encrypt_pk": (C.c_int, [_vp, _u64p, C.c_uint32, _u8p, C.c_uint64, C.POINTER(_vp)]),
     "lumen_encoder_set": (C.c_int, [_vp, C.c_uint64]),
+    "lumen_load_secret_key": (C.c_int, [_vp, _u64p]),
+    "lumen_decrypt": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, _u64p]),
     "lumen_encrypt_values": (C.c_int, [_vp, _u64p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, C.POINTER(_vp)]),
     "lumen_leaf_digests_begin": (C.c_int, [_vp, _vp]),
     "lumen_leaf_digests_end": (C.c_int, [_vp, _u8p]),
@@ -280,6 +282,17 @@ class Context:
         self._ck(self.lib.lumen_encrypt_values(self.h, _p64(values), values.shape[1], values.shape[0],
                                                seed.ctypes.data_as(_u8p), first_index, C.byref(h)))
         return DeviceSet(self, h)
+
+    def load_secret_key(self, sk):
+        sk = np.ascontiguousarray(sk, dtype=np.uint64)[:self.L]
+        assert sk.shape == (self.L, self.N), sk.shape
+        self._ck(self.lib.lumen_load_secret_key(self.h, _p64(np.ascontiguousarray(sk))))
+
+    def decrypt(self, s, nvalues, scale=1):
+        """Slot values of every ciphertext of `s` (one or two limbs): [count][nvalues]."""
+        out = np.zeros((s.count, nvalues), dtype=np.uint64)
+        self._ck(self.lib.lumen_decrypt(self.h, s.h, scale, nvalues, _p64(out)))
+        return out
 
     def leaf_digests_begin(self, s):
         """Start hashing the leaves of `s` on the context's side stream (overlaps later calls)."""

@@ -523,3 +523,55 @@ def test_encrypt_values_matches_oracle_encode_then_encrypt(oracle, log_n, num_q,
         assert np.array_equal(got[i], P.encrypt_det(pk, P.encode(vals[i]), seed, first + i)), i
         assert np.array_equal(P.decrypt(sk, got[i], rows), vals[i] % np.uint64(T_REF)), i
     ctx.close()
+
+
+# ------------------------------------------------------------------ client-side decryption
+@pytest.mark.parametrize("log_n,num_q", [(10, 2), (10, 1), (12, 2), (14, 2)])
+def test_decrypt_matches_oracle(oracle, log_n, num_q):
+    """lumen_decrypt == the oracle's Decrypt + Decode on real encryptions (one and two limbs),
+    including a non-trivial scale."""
+    from lumenos_amd import params as lp
+    P = make_params(oracle, log_n, num_q)
+    P.seed(3 * log_n + num_q)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    ctx = make_context(P)
+    ctx.encoder_set(lp.encoder_psi(T_REF, log_n))
+    ctx.load_secret_key(sk)
+    rng = np.random.default_rng(log_n)
+    vals = rng.integers(0, T_REF, size=(3, P.N), dtype=np.uint64)
+    cts = np.stack([P.encrypt(pk, P.encode(v)) for v in vals])
+    s = ctx.upload(cts)
+    got = ctx.decrypt(s, P.N)
+    if num_q > 1:  # one 58-bit limb cannot hold T * noise for the 57-bit T: nothing decrypts there,
+        assert np.array_equal(got, vals)  # the device must then still agree with the oracle's output
+    for scale in (1, 12345678901234567):
+        got = ctx.decrypt(s, 17, scale)
+        for i in range(3):
+            assert np.array_equal(got[i], P.decrypt(sk, cts[i], 17, scale)), (scale, i)
+    ctx.close()
+
+
+def test_gpu_only_round_trip_encrypt_prove_decrypt(oracle):
+    """Witness -> lumen_encrypt_values -> matrixInnerSumEval -> lumen_decrypt, no oracle arithmetic in
+    between: slot 0 of column j is sum_i r_i * W[i][j] mod T (the check Verify performs on MatR)."""
+    from lumenos_amd import params as lp
+    P = make_params(oracle, 10, 5)
+    P.seed(21)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    ctx = make_context(P)
+    ctx.encoder_set(lp.encoder_psi(T_REF, 10))
+    ctx.load_public_key(pk)
+    ctx.load_secret_key(sk)
+    rows, cols = 512, 5
+    W = oracle.witness(rows, cols, T_REF)
+    m = ctx.encrypt_values(np.ascontiguousarray(W.T), np.arange(32, dtype=np.uint8), 0)
+    for g in P.inner_sum_galois_elements(rows):
+        ctx.load_galois_key(g, P.keygen_galois(sk, g))
+    r = np.random.default_rng(2).integers(0, 2**63, size=rows, dtype=np.uint64)
+    out = ctx.matrix_inner_sum(m, P.encode(r), rows)
+    got = ctx.decrypt(out, 1, P.rescale_scale(P.L, 2))[:, 0]
+    want = [int(np.sum(W[:, j].astype(object) * (r.astype(object) % T_REF)) % T_REF) for j in range(cols)]
+    assert [int(x) for x in got] == want
+    ctx.close()

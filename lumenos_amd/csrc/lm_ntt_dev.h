@@ -35,8 +35,13 @@ struct lm_ninv_t {
 
 __host__ __device__ constexpr int lm_ilog2(int x) { return x <= 1 ? 0 : 1 + lm_ilog2(x >> 1); }
 // launch geometry: 16 coefficients per lane, at least one wave, at most 1024 threads
+#ifndef LM_COEFS_PER_LANE
+#define LM_COEFS_PER_LANE 16
+#endif
 __host__ __device__ constexpr int lm_nthreads(int logN) {
-    return (1 << logN) / 16 < 64 ? 64 : ((1 << logN) / 16 > 1024 ? 1024 : (1 << logN) / 16);
+    return (1 << logN) / LM_COEFS_PER_LANE < 64
+               ? 64
+               : ((1 << logN) / LM_COEFS_PER_LANE > 1024 ? 1024 : (1 << logN) / LM_COEFS_PER_LANE);
 }
 __host__ __device__ constexpr int lm_max_threads(int logN) { return lm_nthreads(logN); }
 __host__ __device__ constexpr int lm_log_epl(int logN) { return logN - lm_ilog2(lm_nthreads(logN)); } // log2 coefficients per lane
@@ -102,7 +107,7 @@ __device__ __forceinline__ u64 lm_keep(u64 x) {
 // The compiler's rendering of this chain costs ~19 instructions: every time the HIGH word of one
 // product feeds the next multiply-add it copies that word into a zero-extended, 64-bit-aligned
 // register pair (gfx950 only takes even-aligned VGPR tuples) and then adds pairs.  LM_ASM_SHOUP
-// writes the chain by hand on fixed temporaries v[80:89]: 10 multiply-adds and 2 adds.
+// writes the chain by hand on eight fixed temporaries: 10 multiply-adds and 2 adds.
 //   * "x += zext(hi word)" is itself a multiply-add by the inline constant 1 (the word is read as a
 //     32-bit source, so its alignment does not matter);
 //   * S = a1*p0 + m1 is a 65-bit sum: its carry-out (an SGPR pair) is added to the upper word of t;
@@ -114,20 +119,51 @@ __device__ __forceinline__ u64 lm_keep(u64 x) {
 #ifndef LM_ASM_SHOUP
 #define LM_ASM_SHOUP 1
 #endif
-#define LM_SHOUP_CLOBBERS "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "s96", "s97", "s98", "s99"
+// the eight temporaries: an even-aligned block v[B:B+7] (LM_SHOUP_TEMP_BASE = 80 by default; a lower
+// block lets a kernel stay under 64 VGPRs)
+#ifndef LM_SHOUP_TEMP_BASE
+#define LM_SHOUP_TEMP_BASE 80
+#endif
+#if LM_SHOUP_TEMP_BASE == 80
+#define LM_T(i) LM_T80_##i
+#define LM_T80_0 "80"
+#define LM_T80_1 "81"
+#define LM_T80_2 "82"
+#define LM_T80_3 "83"
+#define LM_T80_4 "84"
+#define LM_T80_5 "85"
+#define LM_T80_6 "86"
+#define LM_T80_7 "87"
+#elif LM_SHOUP_TEMP_BASE == 56
+#define LM_T(i) LM_T56_##i
+#define LM_T56_0 "56"
+#define LM_T56_1 "57"
+#define LM_T56_2 "58"
+#define LM_T56_3 "59"
+#define LM_T56_4 "60"
+#define LM_T56_5 "61"
+#define LM_T56_6 "62"
+#define LM_T56_7 "63"
+#else
+#error "LM_SHOUP_TEMP_BASE must be 56 or 80"
+#endif
+#define LM_V(i) "v" LM_T(i)
+#define LM_VP(i, j) "v[" LM_T(i) ":" LM_T(j) "]"
+#define LM_SHOUP_CLOBBERS LM_V(0), LM_V(1), LM_V(2), LM_V(3), LM_V(4), LM_V(5), LM_V(6), LM_V(7), "s96", "s97", "s98", "s99"
+// v[0:1]: m1, later `up`;  v[2:3]: S;  v[4:5]: t;  v[6:7]: lo'
 #define LM_SHOUP_BODY(ADDEND)                                                                                   \
-    "v_mad_u64_u32 v[80:81], s[96:97], %[a0], %[p1], 0\n\t"          /* m1 = a0*p1               */           \
-    "v_mad_u64_u32 v[82:83], s[98:99], %[a1], %[p0], v[80:81]\n\t"   /* S, carry -> s[98:99]     */           \
-    "v_mad_u64_u32 v[84:85], s[96:97], %[a1], %[p1], 0\n\t"          /* t = a1*p1                */           \
-    "v_mad_u64_u32 v[86:87], s[96:97], %[a0], %[w0], " ADDEND "\n\t"  /* lo' = a0*w0 + x          */           \
-    "v_mad_u64_u32 v[84:85], s[96:97], v83, 1, v[84:85]\n\t"         /* t += hi(S)               */           \
-    "v_mad_u64_u32 v[88:89], s[96:97], %[a0], %[w1], 0\n\t"          /* up = a0*w1               */           \
-    "v_addc_co_u32_e64 v85, s[96:97], v85, 0, s[98:99]\n\t"          /* t += carry << 32         */           \
-    "v_mad_u64_u32 v[88:89], s[96:97], %[a1], %[w0], v[88:89]\n\t"   /* up += a1*w0              */           \
-    "v_mad_u64_u32 v[88:89], s[96:97], v84, %[n1], v[88:89]\n\t"     /* up += t0*n1              */           \
-    "v_mad_u64_u32 v[88:89], s[96:97], v85, %[n0], v[88:89]\n\t"     /* up += t1*n0              */           \
-    "v_add_u32 v87, v87, v88\n\t"                                    /* hi(lo') += up            */           \
-    "v_mad_u64_u32 %[o], s[96:97], v84, %[n0], v[86:87]"              /* {lo', upper} + t0*n0     */
+    "v_mad_u64_u32 " LM_VP(0, 1) ", s[96:97], %[a0], %[p1], 0\n\t"                 /* m1 = a0*p1           */ \
+    "v_mad_u64_u32 " LM_VP(2, 3) ", s[98:99], %[a1], %[p0], " LM_VP(0, 1) "\n\t"   /* S, carry -> s[98:99] */ \
+    "v_mad_u64_u32 " LM_VP(4, 5) ", s[96:97], %[a1], %[p1], 0\n\t"                 /* t = a1*p1            */ \
+    "v_mad_u64_u32 " LM_VP(6, 7) ", s[96:97], %[a0], %[w0], " ADDEND "\n\t"        /* lo' = a0*w0 + x      */ \
+    "v_mad_u64_u32 " LM_VP(4, 5) ", s[96:97], " LM_V(3) ", 1, " LM_VP(4, 5) "\n\t" /* t += hi(S)           */ \
+    "v_mad_u64_u32 " LM_VP(0, 1) ", s[96:97], %[a0], %[w1], 0\n\t"                 /* up = a0*w1           */ \
+    "v_addc_co_u32_e64 " LM_V(5) ", s[96:97], " LM_V(5) ", 0, s[98:99]\n\t"        /* t += carry << 32     */ \
+    "v_mad_u64_u32 " LM_VP(0, 1) ", s[96:97], %[a1], %[w0], " LM_VP(0, 1) "\n\t"   /* up += a1*w0          */ \
+    "v_mad_u64_u32 " LM_VP(0, 1) ", s[96:97], " LM_V(4) ", %[n1], " LM_VP(0, 1) "\n\t" /* up += t0*n1      */ \
+    "v_mad_u64_u32 " LM_VP(0, 1) ", s[96:97], " LM_V(5) ", %[n0], " LM_VP(0, 1) "\n\t" /* up += t1*n0      */ \
+    "v_add_u32 " LM_V(7) ", " LM_V(7) ", " LM_V(0) "\n\t"                          /* hi(lo') += up        */ \
+    "v_mad_u64_u32 %[o], s[96:97], " LM_V(4) ", %[n0], " LM_VP(6, 7)                /* {lo', upper} + t0*n0 */
 
 // compiler-scheduled form of the same chain (no pinned registers): for kernels whose occupancy must
 // not be tied to the v[80:89] temporaries of the hand-scheduled one

@@ -575,3 +575,47 @@ def test_gpu_only_round_trip_encrypt_prove_decrypt(oracle):
     want = [int(np.sum(W[:, j].astype(object) * (r.astype(object) % T_REF)) % T_REF) for j in range(cols)]
     assert [int(x) for x in got] == want
     ctx.close()
+
+
+# ------------------------------------------------------------------ error convention
+def test_error_paths_report_status_and_message(oracle, small):
+    """Every entry point returns non-zero and leaves a message (the cgo convention of the reference,
+    vdec/prover.go:121-232): misuse must never reach a kernel with operands it does not expect."""
+    from lumenos_amd.hip import LumenError
+    from lumenos_amd import params as lp
+    P, ctx = small
+    s4 = ctx.new_set(2, 4).fill_random(1)
+    s2 = ctx.new_set(2, 2).fill_random(2)
+    seed = np.zeros(32, dtype=np.uint8)
+
+    def fails(fn, text):
+        with pytest.raises(LumenError) as e:
+            fn()
+        assert text in str(e.value), str(e.value)
+
+    fails(lambda: ctx.new_set(1, 99), "num_limbs")
+    fails(lambda: ctx.rescale(s2, 3), "target_limbs")
+    fails(lambda: ctx.gather(s2, np.array([5], dtype=np.uint32)), "out of range")
+    fails(lambda: ctx.inner_sum(s2, 8), "top level")
+    fails(lambda: ctx.inner_sum(s4, 6), "power of two")
+    pt = np.zeros((4, P.N), dtype=np.uint64)
+    fails(lambda: ctx.matrix_inner_sum(s4, pt, 1 << 30), "power of two")
+    fails(lambda: ctx.load_galois_key(4, np.zeros(P.evk_shape(), dtype=np.uint64)), "odd residue")
+    # the encryption / decryption entry points without their keys or tables
+    from helpers import make_context
+    fresh = make_context(P)
+    fails(lambda: fresh.encrypt_pk(None, 1, seed, 0), "no public key")
+    fresh.load_public_key(np.zeros((2, P.L, P.N), dtype=np.uint64))
+    fails(lambda: fresh.encrypt_values(np.zeros((1, 8), dtype=np.uint64), seed, 0), "no encoder tables")
+    fails(lambda: fresh.encoder_set(12345), "primitive 2N-th root")
+    fresh.encoder_set(lp.encoder_psi(T_REF, P.logN))
+    fails(lambda: fresh.decrypt(fresh.new_set(1, 2), 1), "no secret key")
+    fresh.load_secret_key(np.zeros((P.L, P.N), dtype=np.uint64))
+    fails(lambda: fresh.decrypt(fresh.new_set(1, 3), 1), "one or two limbs")
+    bad = np.full((2, P.L, P.N), 2**63, dtype=np.uint64)
+    fails(lambda: fresh.load_public_key(bad), "out of range")
+    # one asynchronous leaf job at a time
+    fresh.leaf_digests_begin(fresh.new_set(3, 2).fill_random(4))
+    fails(lambda: fresh.leaf_digests_begin(fresh.new_set(3, 2).fill_random(5)), "already in flight")
+    assert fresh.leaf_digests_end().shape == (3, 32)
+    fresh.close()

@@ -116,16 +116,16 @@ template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *__restrict__ coef, const u64 *__restrict__ acc,
                                                     u64 *__restrict__ ext, const bx_t *__restrict__ bx,
                                                     uint32_t B, uint32_t L, uint32_t K, uint32_t beta,
-                                                    const uint16_t *__restrict__ pairs, lm_mods mods,
+                                                    const uint32_t *__restrict__ work, lm_mods mods,
                                                     const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
     constexpr uint32_t N = 1u << LOGN;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
-    // the grid only holds the (digit, target) pairs that need an extension (a digit's own limbs reuse
-    // the NTT-domain c1: a workgroup that merely exited would still have held a CU's LDS while it was
-    // dispatched), target-major: one twiddle table stays hot per XCD L2
-    const uint32_t b = blockIdx.x % B, pr = pairs[blockIdx.x / B];
-    const uint32_t d = pr & 0xFF, t = pr >> 8; // t: modulus index (Q limbs then P limbs)
+    // The grid only holds the (column, digit, target) triples that need an extension (a digit's own
+    // limbs reuse the NTT-domain c1), in the order of a host-built work list (modup_work_list): XCD-
+    // aware, so that the targets of one digit run back to back on one XCD and share its L2.
+    const uint32_t wk = work[blockIdx.x];
+    const uint32_t b = wk & 0xFFFF, d = (wk >> 16) & 0xFF, t = wk >> 24; // t: modulus index (Q limbs then P limbs)
     const bx_t c = bx[d * LK + t];
     u64 *o = ext + (((size_t)b * beta + d) * LK + t) * N;
     const lm_qc qc = lm_make_qc(mods.m[t]);
@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
         slice = blockIdx.x / G;
     }
     const uint32_t i = ((slice % per_limb) * 256 + threadIdx.x) * LM_MAC_VEC; // first coefficient
-    const uint32_t t = slice / per_limb;                                      // modulus index
+    // limbs in descending order: the extension kernel wrote the highest target group last, so those
+    // digits are the likeliest to still sit in the Infinity Cache
+    const uint32_t t = LK - 1 - slice / per_limb;                             // modulus index
     const uint32_t b0 = z * LM_MAC_COLS;
     if (i >= N) return;
     const mod_t md = mods.m[t];
@@ -310,15 +312,18 @@ template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 *__restrict__ u, const u64 *__restrict__ acc_in,
                                                      u64 *__restrict__ acc_out, const bx_t *__restrict__ bxp,
                                                      const tw_t *__restrict__ pinv,
-                                                     const uint32_t *__restrict__ index, uint32_t B,
+                                                     const uint32_t *__restrict__ index,
+                                                     const uint32_t *__restrict__ work, uint32_t B,
                                                      uint32_t L, uint32_t K, lm_mods mods,
                                                      const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
     constexpr uint32_t N = 1u << LOGN;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
-    uint32_t r = blockIdx.x;
-    const uint32_t pw = r % (B * 2); // b*2 + w
-    const uint32_t t = r / (B * 2);
+    // host-built, XCD-aware order (moddown_work_list): the Q limbs of one polynomial, which all lift the
+    // same two P-limb words, run back to back on one XCD
+    const uint32_t wk = work[blockIdx.x];
+    const uint32_t pw = wk & 0xFFFF; // b*2 + w
+    const uint32_t t = wk >> 16;
     const uint32_t w = pw & 1;
     const bx_t c = bxp[t];
     const lm_qc qc = lm_make_qc(mods.m[t]);
@@ -369,10 +374,12 @@ struct KsTables {
     tw_t *d_pinv = nullptr;  // [L]  P^-1 mod q_t
     uint32_t beta = 0;
     lm_ninv_t yscale; // per modulus: N^-1 * (M/m)^-1 mod m of the source group the modulus sits in
-    uint16_t *d_pairs = nullptr; // (digit | target << 8) of every extension the key switch needs, target-major
-    uint32_t npairs = 0;
+    std::vector<uint16_t> pairs; // (digit | target << 8) of every extension the key switch needs, target-major
+    std::map<uint32_t, uint32_t *> d_work; // per batch size: the workgroup order of the extension kernel
+    std::map<uint32_t, uint32_t *> d_work_down; // ... and of the ModDown kernel
     ~KsTables() {
-        hipFree(d_pairs);
+        for (auto &kv : d_work) hipFree(kv.second);
+        for (auto &kv : d_work_down) hipFree(kv.second);
         hipFree(d_bx);
         hipFree(d_bxp);
         hipFree(d_pinv);
@@ -442,9 +449,7 @@ int get_tables(lumen_ctx *ctx, KsTables **out) {
     for (uint32_t t = 0; t < LK; t++)
         for (uint32_t d = 0; d < tb.beta; d++)
             if (!bx[(size_t)d * LK + t].own) pairs.push_back((uint16_t)(d | (t << 8)));
-    tb.npairs = (uint32_t)pairs.size();
-    LM_HIP(ctx, hipMalloc((void **)&tb.d_pairs, pairs.size() * sizeof(uint16_t)));
-    LM_HIP(ctx, hipMemcpy(tb.d_pairs, pairs.data(), pairs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    tb.pairs = pairs;
     LM_HIP(ctx, hipMalloc((void **)&tb.d_bx, bx.size() * sizeof(bx_t)));
     LM_HIP(ctx, hipMalloc((void **)&tb.d_bxp, bxp.size() * sizeof(bx_t)));
     LM_HIP(ctx, hipMalloc((void **)&tb.d_pinv, pinv.size() * sizeof(tw_t)));
@@ -480,6 +485,87 @@ namespace {
 struct KsScratch {
     u64 *coef, *ext, *u, *acc2;
 };
+
+// Workgroup order of the extension kernel for a batch of B columns.  Workgroup k runs on XCD k % 8
+// (round-robin dispatch), each XCD has its own 4 MB L2, and a digit is read once per target limb:
+// XCD x takes the columns b == x (mod 8); inside it the targets come in groups of LM_MODUP_TGROUP, and
+// for each group the (column, digit) pairs are walked with the group's targets innermost -- the
+// workgroups that read the same digit are adjacent on one XCD (one fabric read, the rest L2 hits)
+// while only LM_MODUP_TGROUP twiddle tables (256 KB each at N = 2^14) are live in that L2.
+#ifndef LM_MODUP_TGROUP
+#define LM_MODUP_TGROUP 4
+#endif
+static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint32_t **out) {
+    auto it = tb->d_work.find(B);
+    if (it != tb->d_work.end()) {
+        *out = it->second;
+        return 0;
+    }
+    const uint32_t LK = ctx->L + ctx->K, beta = tb->beta;
+    std::vector<std::vector<uint8_t>> need(beta); // digit -> targets that need an extension
+    for (uint16_t pr : tb->pairs) need[pr & 0xFF].push_back((uint8_t)(pr >> 8));
+    std::vector<std::vector<uint32_t>> lists(8);
+    for (uint32_t x = 0; x < 8; x++)
+        for (uint32_t t0 = 0; t0 < LK; t0 += LM_MODUP_TGROUP)
+            for (uint32_t b = x; b < B; b += 8)
+                for (uint32_t d = 0; d < beta; d++)
+                    for (uint8_t t : need[d])
+                        if (t >= t0 && t < t0 + LM_MODUP_TGROUP) lists[x].push_back(b | (d << 16) | ((uint32_t)t << 24));
+    // interleave: entry k belongs to XCD k % 8; lists of unequal length (B not a multiple of 8) are
+    // drained in turn
+    std::vector<uint32_t> order;
+    order.reserve((size_t)B * tb->pairs.size());
+    std::vector<size_t> pos(8, 0);
+    for (bool any = true; any;) {
+        any = false;
+        for (uint32_t x = 0; x < 8; x++)
+            if (pos[x] < lists[x].size()) {
+                order.push_back(lists[x][pos[x]++]);
+                any = true;
+            }
+    }
+    LM_CHECK(ctx, order.size() == (size_t)B * tb->pairs.size(), "extension work list is inconsistent");
+    uint32_t *d = nullptr;
+    LM_HIP(ctx, hipMalloc((void **)&d, order.size() * sizeof(uint32_t)));
+    LM_HIP(ctx, hipMemcpy(d, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    tb->d_work[B] = d;
+    *out = d;
+    return 0;
+}
+
+// The same for ModDown: (polynomial pw = 2b + w, Q limb t); XCD x takes the polynomials pw == x (mod 8),
+// targets in groups of LM_MODUP_TGROUP, the group's targets innermost.
+static int moddown_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint32_t **out) {
+    auto it = tb->d_work_down.find(B);
+    if (it != tb->d_work_down.end()) {
+        *out = it->second;
+        return 0;
+    }
+    const uint32_t L = ctx->L;
+    std::vector<std::vector<uint32_t>> lists(8);
+    for (uint32_t x = 0; x < 8; x++)
+        for (uint32_t t0 = 0; t0 < L; t0 += LM_MODUP_TGROUP)
+            for (uint32_t pw = x; pw < 2 * B; pw += 8)
+                for (uint32_t t = t0; t < std::min<uint32_t>(t0 + LM_MODUP_TGROUP, L); t++) lists[x].push_back(pw | (t << 16));
+    std::vector<uint32_t> order;
+    order.reserve((size_t)2 * B * L);
+    std::vector<size_t> pos(8, 0);
+    for (bool any = true; any;) {
+        any = false;
+        for (uint32_t x = 0; x < 8; x++)
+            if (pos[x] < lists[x].size()) {
+                order.push_back(lists[x][pos[x]++]);
+                any = true;
+            }
+    }
+    LM_CHECK(ctx, order.size() == (size_t)2 * B * L, "ModDown work list is inconsistent");
+    uint32_t *d = nullptr;
+    LM_HIP(ctx, hipMalloc((void **)&d, order.size() * sizeof(uint32_t)));
+    LM_HIP(ctx, hipMemcpy(d, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    tb->d_work_down[B] = d;
+    *out = d;
+    return 0;
+}
 
 int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s, int lane = 0) {
     const size_t N = ctx->N, L = ctx->L, LK = ctx->L + ctx->K;
@@ -530,14 +616,16 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
     }
     // 2. digit extension + NTT
     {
-        const uint64_t nb = (uint64_t)B * tb->npairs;
+        const uint64_t nb = (uint64_t)B * tb->pairs.size();
+        const uint32_t *work = nullptr;
+        if (int rc = modup_work_list(ctx, tb, B, &work)) return rc;
         lm_prof_scope ps(ctx, "ks_modup_ntt", nb);
         switch (ctx->logN) {
 #define LM_CASE(n)                                                                                            \
     case n:                                                                                                   \
         LM_LDS_ATTR(ctx, k_modup_ntt<n>, lds);               \
         hipLaunchKernelGGL(k_modup_ntt<n>, dim3((uint32_t)nb), dim3(threads), lds, ctx->stream, s.coef, acc,  \
-                           s.ext, tb->d_bx, B, L, K, beta, tb->d_pairs, ctx->mods, ctx->d_tw_fwd);            \
+                           s.ext, tb->d_bx, B, L, K, beta, work, ctx->mods, ctx->d_tw_fwd);                   \
         break;
             LM_FOR_EACH_LOGN(LM_CASE)
 #undef LM_CASE
@@ -571,13 +659,15 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
     }
     // 4b + 5. lift to Q, NTT, combine, automorphism, accumulate
     {
+        const uint32_t *work_down = nullptr;
+        if (int rc = moddown_work_list(ctx, tb, B, &work_down)) return rc;
         lm_prof_scope ps(ctx, "ks_moddown_ntt", (uint64_t)B * 2 * L);
         switch (ctx->logN) {
 #define LM_CASE(n)                                                                                            \
     case n:                                                                                                   \
         LM_LDS_ATTR(ctx, k_moddown_ntt<n>, lds);               \
         hipLaunchKernelGGL(k_moddown_ntt<n>, dim3(B * 2 * L), dim3(threads), lds, ctx->stream, s.u, acc,      \
-                           acc_out, tb->d_bxp, tb->d_pinv, gk.d_index, B, L, K, ctx->mods,                \
+                           acc_out, tb->d_bxp, tb->d_pinv, gk.d_index, work_down, B, L, K, ctx->mods,     \
                            ctx->d_tw_fwd);                                                                    \
         break;
             LM_FOR_EACH_LOGN(LM_CASE)

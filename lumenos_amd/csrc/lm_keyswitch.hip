@@ -534,7 +534,10 @@ static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint3
 }
 
 // The same for ModDown: (polynomial pw = 2b + w, Q limb t); XCD x takes the polynomials pw == x (mod 8),
-// targets in groups of LM_MODUP_TGROUP, the group's targets innermost.
+// targets in groups of LM_MODDOWN_TGROUP, the group's targets innermost.
+#ifndef LM_MODDOWN_TGROUP
+#define LM_MODDOWN_TGROUP 4
+#endif
 static int moddown_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint32_t **out) {
     auto it = tb->d_work_down.find(B);
     if (it != tb->d_work_down.end()) {
@@ -544,9 +547,9 @@ static int moddown_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uin
     const uint32_t L = ctx->L;
     std::vector<std::vector<uint32_t>> lists(8);
     for (uint32_t x = 0; x < 8; x++)
-        for (uint32_t t0 = 0; t0 < L; t0 += LM_MODUP_TGROUP)
+        for (uint32_t t0 = 0; t0 < L; t0 += LM_MODDOWN_TGROUP)
             for (uint32_t pw = x; pw < 2 * B; pw += 8)
-                for (uint32_t t = t0; t < std::min<uint32_t>(t0 + LM_MODUP_TGROUP, L); t++) lists[x].push_back(pw | (t << 16));
+                for (uint32_t t = t0; t < std::min<uint32_t>(t0 + LM_MODDOWN_TGROUP, L); t++) lists[x].push_back(pw | (t << 16));
     std::vector<uint32_t> order;
     order.reserve((size_t)2 * B * L);
     std::vector<size_t> pos(8, 0);

@@ -12,14 +12,18 @@
 //   4. ModDown: INTT the P limbs, extend P -> Q, NTT, (u_Q - lift) * P^-1  (P^-1 pre-folded into the key)
 //   5. add c0, permute both polynomials by the automorphism table, accumulate.
 // Everything but the correction term v is exact modular arithmetic; v is
-// computed in IEEE double exactly as the oracle does (this file is compiled
-// with -ffp-contract=off).
+// decided in 128-bit integers and falls back to the literal IEEE double
+// expression of the reference near a tie (this file is compiled with
+// -ffp-contract=off).
 //
 // Kernel shapes: the NTT-bearing steps reuse the LDS-resident limb transform
 // with the basis extension fused into its load phase (k_modup_ntt,
-// k_moddown_ntt: the extended limb never exists in HBM in coefficient form);
-// the gadget product keeps key material in Montgomery form and accumulates
-// the beta products of a coefficient in 128 bits, one reduction per output.
+// k_moddown_ntt: the extended limb never exists in HBM in coefficient form;
+// k_pack_v first turns a digit's two source words into the two words of its exact
+// integer reconstruction, so that the extension is one multiplication per target);
+// both kernels are dealt by XCD-aware work lists so that the targets of one digit
+// share an L2; the gadget product keeps key material in Montgomery form and
+// accumulates the beta products of a coefficient in 128 bits, one reduction per output.
 #include <cstdlib>
 #include <cstring>
 

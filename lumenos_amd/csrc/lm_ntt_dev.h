@@ -286,12 +286,24 @@ __device__ __forceinline__ void lm_fwd_stages(u64 *e, uint32_t s0, uint32_t blk,
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int span = (1 << R) >> st, half = span >> 1;
+        // all sums x + w*y of the stage first (x rides in the multiplication's addend slot), then all
+        // differences (2x + 3q) - sum: measured 1-2 % faster than butterfly by butterfly
+        u64 sum[(1 << R) / 2];
 #pragma unroll
         for (int g = 0; g < (1 << st); g++) {
             const tw_t W = lm_tw_load<UW>(tw, ((1u << s0) << st) + (blk << st) + g);
 #pragma unroll
-            for (int k = 0; k < half; k++) lm_bfly_fwd<UW>(e[g * span + k], e[g * span + k + half], W, c);
+            for (int k = 0; k < half; k++)
+                sum[g * half + k] = lm_shoup3<UW>(e[g * span + k + half], W.w, W.wp, c.nq, e[g * span + k]);
         }
+#pragma unroll
+        for (int g = 0; g < (1 << st); g++)
+#pragma unroll
+            for (int k = 0; k < half; k++) {
+                u64 &x = e[g * span + k];
+                e[g * span + k + half] = ((x << 1) + c.q3) - sum[g * half + k];
+                x = sum[g * half + k];
+            }
     }
 }
 

@@ -159,6 +159,8 @@ template <>
 struct mac_vec<1> {
     u64 v[1];
     static __device__ __forceinline__ mac_vec load(const u64 *p) { return mac_vec{{*p}}; }
+    // read-once streams (the extended digits): do not displace what later kernels will re-read
+    static __device__ __forceinline__ mac_vec load_once(const u64 *p) { return mac_vec{{__builtin_nontemporal_load(p)}}; }
     __device__ __forceinline__ void store(u64 *p) const { *p = v[0]; }
 };
 template <>
@@ -167,6 +169,9 @@ struct mac_vec<2> {
     static __device__ __forceinline__ mac_vec load(const u64 *p) {
         const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p);
         return mac_vec{{a.x, a.y}};
+    }
+    static __device__ __forceinline__ mac_vec load_once(const u64 *p) {
+        return mac_vec{{__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1)}};
     }
     __device__ __forceinline__ void store(u64 *p) const {
         ulonglong2 a;
@@ -273,8 +278,8 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
 #pragma unroll
         for (int c = 0; c < LM_MAC_COLS; c++) {
             const uint32_t bc = b0 + c < B ? b0 + c : B - 1;
-            g.x[c] = vec::load(d == own ? acc + ((size_t)(bc * 2 + 1) * L + t) * N + i
-                                        : ext + (((size_t)bc * beta + d) * LK + t) * N + i);
+            g.x[c] = d == own ? vec::load(acc + ((size_t)(bc * 2 + 1) * L + t) * N + i)
+                              : vec::load_once(ext + (((size_t)bc * beta + d) * LK + t) * N + i);
         }
         return g;
     };

@@ -35,7 +35,9 @@
 #ifndef LM_CT_W
 #define LM_CT_W 32      // lanes per tile
 #endif
+#ifndef LM_CT_THREADS
 #define LM_CT_THREADS 512
+#endif
 #define LM_NOSLOT 0xFFFFFFFFu
 
 // ------------------------------------------------------------ schedule compiler

@@ -321,11 +321,22 @@ __device__ __forceinline__ void lm_inv_stages(u64 *e, uint32_t logN, uint32_t lo
         const int half = 1 << st, span = half << 1;
         const uint32_t m = 1u << (logN - log_t0 - st - 1);
         const u64 C = c.q3 << st;
+        // all sums and differences of the stage first, then the multiplications (as in the forward stages)
+        u64 dif[(1 << R) / 2];
+#pragma unroll
+        for (int g = 0; g < ((1 << R) / span); g++)
+#pragma unroll
+            for (int k = 0; k < half; k++) {
+                u64 &x = e[g * span + k], &y = e[g * span + k + half];
+                dif[g * half + k] = x + C - y;
+                x = x + y;
+            }
 #pragma unroll
         for (int g = 0; g < ((1 << R) / span); g++) {
             const tw_t W = lm_tw_load<UW>(tw, m + (blk << (R - st - 1)) + g);
 #pragma unroll
-            for (int k = 0; k < half; k++) lm_bfly_inv<UW>(e[g * span + k], e[g * span + k + half], W, c, C);
+            for (int k = 0; k < half; k++)
+                e[g * span + k + half] = lm_shoup3<UW>(dif[g * half + k], W.w, W.wp, c.nq);
         }
     }
     if (!LAST) {

@@ -255,23 +255,13 @@ __device__ __forceinline__ lm_qc lm_make_qc(const mod_t &m) {
     return c;
 }
 
-// forward (Cooley-Tukey) butterfly, fully lazy: both outputs grow by < 3q
-template <bool UW>
-__device__ __forceinline__ void lm_bfly_fwd(u64 &x, u64 &y, const tw_t W, const lm_qc &c) {
-    const u64 s = lm_shoup3<UW>(y, W.w, W.wp, c.nq, x); // x + v
-    y = ((x << 1) + c.q3) - s;                          // x + 3q - v as one shift-add and one subtract
-    x = s;
-}
-// inverse (Gentleman-Sande) butterfly, lazy inside a pass: in stage st of a pass both inputs are
-// below C = 3q * 2^st; the sum is left to grow (x < 2C), the difference goes through the Shoup
-// multiplication (any input below 2^64) and lands in [0, 3q).  lm_inv_stages brings the sums back
-// under 3q once per pass instead of once per butterfly.
-template <bool UW>
-__device__ __forceinline__ void lm_bfly_inv(u64 &x, u64 &y, const tw_t W, const lm_qc &c, u64 C) {
-    const u64 u = x, v = y;
-    x = u + v;
-    y = lm_shoup3<UW>(u + C - v, W.w, W.wp, c.nq);
-}
+// Butterflies (written out stage by stage in lm_fwd_stages / lm_inv_stages):
+//   forward (Cooley-Tukey), fully lazy:   s = x + w*y (x rides in the multiplication's addend slot),
+//       y' = (2x + 3q) - s, x' = s: both outputs grow by < 3q per stage;
+//   inverse (Gentleman-Sande), lazy inside a pass: in stage st of a pass both inputs are below
+//       C = 3q * 2^st; x' = x + y is left to grow (< 2C), y' = w * (x + C - y) goes through the Shoup
+//       multiplication (any input below 2^64) and lands in [0, 3q); lm_inv_stages brings the sums
+//       back under 3q once per pass instead of once per butterfly.
 
 template <bool UW>
 __device__ __forceinline__ tw_t lm_tw_load(const tw_t *__restrict__ tw, uint32_t idx) {

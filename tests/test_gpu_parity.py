@@ -619,3 +619,24 @@ def test_error_paths_report_status_and_message(oracle, small):
     fails(lambda: fresh.leaf_digests_begin(fresh.new_set(3, 2).fill_random(5)), "already in flight")
     assert fresh.leaf_digests_end().shape == (3, 32)
     fresh.close()
+
+
+def test_full_size_encrypt_rescale_decrypt_round_trip(full_d):
+    """At the headline parameters (N = 2^14, 12 + 2 limbs): witness columns -> lumen_encrypt_values ->
+    Rescale to level 1 -> lumen_decrypt returns the columns (a size-independent property: no oracle
+    arithmetic on the path), and one ciphertext is spot-checked against the oracle's encryption."""
+    from lumenos_amd import params as lp
+    P, ctx = full_d
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    ctx.load_public_key(pk)
+    ctx.load_secret_key(sk)
+    ctx.encoder_set(lp.encoder_psi(T_REF, 14))
+    rng = np.random.default_rng(140)
+    vals = rng.integers(0, T_REF, size=(6, P.N), dtype=np.uint64)
+    seed = np.frombuffer(bytes(range(1, 33)), dtype=np.uint8)
+    cts = ctx.encrypt_values(vals, seed, 1000)
+    assert np.array_equal(cts.download(2, 1)[0], P.encrypt_det(pk, P.encode(vals[2]), seed, 1002))
+    lvl1 = ctx.rescale(cts, 2)
+    got = ctx.decrypt(lvl1, P.N, P.rescale_scale(P.L, 2))
+    assert np.array_equal(got, vals)

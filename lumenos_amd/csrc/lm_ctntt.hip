@@ -418,15 +418,18 @@ __global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mo
         const uint32_t slot = slots[s];
         if (slot == LM_NOSLOT) continue;
         const uint32_t pos = a.out_pos ? a.out_pos[slot] : slot;
+        if (pos == LM_NOSLOT) continue; // a slot this rank's share of the next pass never reads
         a.dst[(size_t)pos * a.ctw + lane] = lm_csub(buf[s * LM_CT_W + l], q);
     }
 }
 
 // final_g0/final_ng: groups of the final pass to run (all when final_ng == 0); final_pos: device
 // table slot -> output position for that pass (the plan's own permutation when NULL)
+// keep_pos: for a sharded run, device table slot -> slot (or LM_NOSLOT) applied to the stores of the
+// pass BEFORE the final one: the slots the rank's final groups do not read are not written
 static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, const u64 *srcA,
                     uint32_t splitA, const u64 *srcB, u64 *tmp, u64 *out, uint32_t final_g0 = 0,
-                    uint32_t final_ng = 0, const uint32_t *final_pos = nullptr) {
+                    uint32_t final_ng = 0, const uint32_t *final_pos = nullptr, const uint32_t *keep_pos = nullptr) {
     const size_t ctw = (size_t)2 * nl * ctx->N;
     const uint32_t P = (uint32_t)plan->dev.size();
     LM_CHECK(ctx, ctw % LM_CT_W == 0, "ciphertext width not a multiple of the lane tile");
@@ -441,7 +444,7 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
         a.srcA = cur, a.srcB = curB, a.splitA = split;
         a.dst = final_pass ? out : tmp;
         a.slots = d.d_slots, a.ops = d.d_ops, a.layer = d.d_layer;
-        a.out_pos = final_pass ? (final_pos ? final_pos : plan->d_out_pos) : nullptr;
+        a.out_pos = final_pass ? (final_pos ? final_pos : plan->d_out_pos) : (p + 2 == P ? keep_pos : nullptr);
         a.group0 = final_pass && final_ng ? final_g0 : 0;
         a.scal = ctx->d_scal;
         a.gsize = d.gsize, a.total = d.total, a.nlayers = d.nlayers;
@@ -598,9 +601,14 @@ extern "C" int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const
     const size_t ctw = (size_t)2 * nl * ctx->N;
     u64 *dzero = (u64 *)lm_scratch(ctx, "zero_ct", ctw * sizeof(u64));
     uint32_t *dpos = (uint32_t *)lm_scratch(ctx, "shard_pos", (size_t)S * 4);
-    if (!dzero || !dpos) return 1;
+    uint32_t *dkeep = (uint32_t *)lm_scratch(ctx, "shard_keep", (size_t)S * 4);
+    if (!dzero || !dpos || !dkeep) return 1;
+    // the pass before the final one only stores the slots this rank's final groups read
+    std::vector<uint32_t> keep(S);
+    for (uint32_t sl = 0; sl < S; sl++) keep[sl] = pos[sl] == LM_NOSLOT ? LM_NOSLOT : sl;
     LM_HIP(ctx, hipMemcpyAsync(dzero, zero_ct, ctw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     LM_HIP(ctx, hipMemcpyAsync(dpos, pos.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(ctx, hipMemcpyAsync(dkeep, keep.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
     LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     lumen_set *out = nullptr;
     if (int rc = lumen_set_create(ctx, (uint32_t)own.size(), nl, &out)) return rc;
@@ -610,7 +618,7 @@ extern "C" int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const
         tmp = (u64 *)lm_scratch(ctx, "ct_tmp", (size_t)S * ctw * sizeof(u64));
         if (!tmp) rc = 1;
     }
-    if (!rc && g1 > g0) rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d, g0, g1 - g0, dpos);
+    if (!rc && g1 > g0) rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d, g0, g1 - g0, dpos, dkeep);
     if (rc) {
         lumen_set_destroy(ctx, out);
         return rc;

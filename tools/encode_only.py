@@ -33,6 +33,13 @@ def main():
     ms = ctx.timer_stop() / reps
     gb = (cols + S) * 2 * L * P.N * 8 / 1e9
     print(f"Encode {cfg}: {ms:.2f} ms per call ({cols} -> {S} ciphertexts, {gb:.1f} GB in+out)")
+    for world in (2, 8):  # one rank's share of a multi-GPU Encode (non-final passes replicated)
+        ctx.encode_shard(m, zero, 2, 0, world)[0].free()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            ctx.encode_shard(m, zero, 2, world - 1, world)[0].free()
+        print(f"Encode shard {world - 1}/{world}: {ctx.timer_stop() / reps:.2f} ms per call")
     ctx.close()
 
 

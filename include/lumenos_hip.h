@@ -15,10 +15,20 @@
  *   - a ciphertext is [poly(2)][limb(nl)][N] u64; a "set" is an HBM-resident
  *     array [ct][poly][limb][N].  Host buffers passed in/out use the same
  *     layout (the Go shim stages Lattigo's per-limb slices into it).
- *   - all calls on one context are serialised on the context's HIP stream;
- *     distinct contexts are independent (one per goroutine-pool, or one per
- *     GPU).  Calls return after the work is enqueued unless they hand back
- *     host data; lumen_sync() waits.
+ *   - threading: every entry point that takes a context locks it, so
+ *     concurrent calls on ONE context are safe and run one after the other
+ *     (host side and on the context's HIP stream).  To run concurrently -- the
+ *     reference evaluates the R and Z inner products on two goroutines
+ *     (fhe/ligero.go:231-242), each with its own backend.CopyNew() -- give each
+ *     goroutine pool a lumen_ctx_clone(): clones share parameters, twiddles,
+ *     field table and keys (read-only, like Evaluator.ShallowCopy) and own their
+ *     streams, scratch and storage pool.  A set may be read by any context of
+ *     the same device (lumen_sync the producer first); it is destroyed through
+ *     the context that created it.  Configuration calls (lumen_field_set,
+ *     lumen_load_*_key, lumen_encoder_set, lumen_leaf_format_set) must not race
+ *     with compute calls on a clone of the same context.
+ *   - calls return after the work is enqueued unless they hand back host data;
+ *     lumen_sync() waits.
  */
 #ifndef LUMENOS_HIP_H
 #define LUMENOS_HIP_H
@@ -30,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LUMEN_ABI_VERSION 1
+#define LUMEN_ABI_VERSION 2
 #define LUMEN_MAX_LIMBS 24
 
 typedef struct lumen_ctx lumen_ctx;
@@ -54,6 +64,10 @@ typedef struct lumen_params_desc {
 /* ---- context: replaces fhe.ServerBFV / NewBackendBFV / CopyNew (fhe/bfv.go:13-58) */
 int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out);
 void lumen_ctx_destroy(lumen_ctx *ctx);
+/* ServerBFV.CopyNew (fhe/bfv.go:56-58: Evaluator.ShallowCopy per goroutine, fhe/ligero.go:142,315):
+ * a context on the same device that shares src's tables and keys and owns its streams and scratch.
+ * Destroy clones and source in any order; the shared tables go with the last one. */
+int lumen_ctx_clone(lumen_ctx *src, lumen_ctx **out);
 const char *lumen_last_error(const lumen_ctx *ctx); /* ctx may be NULL */
 int lumen_sync(lumen_ctx *ctx);
 /* number of ct x scalar multiplications issued: ServerBFV.MulCounter (bfv.go:44-46) */
@@ -70,6 +84,13 @@ int lumen_set_slice(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32
                     lumen_set **view);
 /* device pointer of the set's storage (for callers that own HIP interop) */
 void *lumen_set_device_ptr(const lumen_set *set);
+/* Host <-> device staging.  The Go shim's stage() copies Lattigo's per-limb slices
+ * (ct.Value[k].Coeffs[i]) into ONE flat buffer anyway: allocate that buffer with
+ * lumen_host_alloc (page-locked) and upload/download move it by DMA with no further copy.  Ordinary
+ * (pageable) host pointers are accepted too and are pipelined through two pinned bounce buffers of the
+ * context.  Both calls return when the host buffer may be reused / holds the data. */
+void *lumen_host_alloc(size_t bytes);
+void lumen_host_free(void *p);
 int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, uint32_t n,
                      const uint64_t *host);
 int lumen_set_download(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,

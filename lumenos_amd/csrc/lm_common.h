@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -48,7 +49,32 @@ struct lumen_set {
     lumen_ctx *home = nullptr; // context whose pool the storage returns to
 };
 
+// Device tables that never change once loaded: shared by a context and its clones
+// (lumen_ctx_clone = ServerBFV.CopyNew / Evaluator.ShallowCopy, fhe/bfv.go:56-58: the copies share
+// parameters and keys and own their scratch).  `mu` guards the maps (a clone may build a cached plan or
+// table while another one looks one up); the tables themselves are read-only on the device.
+struct lm_shared {
+    std::recursive_mutex mu;
+    // twiddle tables, device: [L+K][N] tw_t
+    tw_t *d_tw_fwd = nullptr;
+    tw_t *d_tw_inv = nullptr;
+    // plaintext field table (core.PrimeField)
+    std::vector<uint64_t> roots;
+    uint32_t fieldN = 0;
+    tw_t *d_scal = nullptr; // [L][fieldN+1] centred twiddle scalars per limb
+    std::map<uint64_t, lm_galois_key> gkeys;
+    // derived tables owned by other translation units (key-switch constants, ciphertext-transform
+    // plans, public/secret/ring-switch keys)
+    std::map<std::string, std::shared_ptr<void>> ext;
+    ~lm_shared();
+};
+
 struct lumen_ctx {
+    // every entry point locks the context (LM_ENTER): concurrent calls on ONE context are serialised
+    // here, not left to the caller (the reference runs the R and Z inner products on two goroutines,
+    // fhe/ligero.go:231-242); recursive because entry points call one another
+    std::recursive_mutex mu;
+    std::shared_ptr<lm_shared> sh;
     int device = 0;
     hipStream_t stream = nullptr;  // where every entry point enqueues (may be swapped to stream2 internally)
     hipStream_t stream2 = nullptr; // second lane for independent column batches (key-switch pipeline)
@@ -56,24 +82,31 @@ struct lumen_ctx {
     hipStream_t stream_aux = nullptr; // side jobs that overlap the main stream (leaf hashing)
     hipEvent_t ev_aux = nullptr;
     uint32_t aux_digests = 0;         // leaves of the lumen_leaf_digests_begin job in flight
+    const u64 *aux_lo = nullptr, *aux_hi = nullptr; // storage that job is reading
     uint8_t *aux_host = nullptr;      // pinned staging of its digests
     size_t aux_host_cap = 0;
+    // pinned staging for small host tables handed to asynchronous copies (plaintexts, index lists)
+    void *stage_host = nullptr;
+    size_t stage_cap = 0;
+    hipEvent_t ev_stage = nullptr; // the last copy out of stage_host
+    // two pinned bounce buffers for uploads / downloads of pageable host memory (lumen_set_upload)
+    void *io_host[2] = {nullptr, nullptr};
+    hipEvent_t ev_io[2] = {nullptr, nullptr};
     uint32_t logN = 0, N = 0, L = 0, K = 0;
     uint64_t T = 0;
     uint64_t mod[LM_MAX_LIMBS] = {0};
     uint64_t psi[LM_MAX_LIMBS] = {0};
     lm_mods mods; // device-side constants by value
-    // twiddle tables, device: [L+K][N] tw_t
-    tw_t *d_tw_fwd = nullptr;
-    tw_t *d_tw_inv = nullptr;
     tw_t ninv[LM_MAX_LIMBS]; // N^-1 mod q_i
-    // plaintext field table (core.PrimeField)
-    std::vector<uint64_t> roots;
-    uint32_t fieldN = 0;
-    tw_t *d_scal = nullptr; // [L][fieldN+1] centred twiddle scalars per limb
+    // views of the shared tables (same names as before the split)
+    tw_t *&d_tw_fwd;
+    tw_t *&d_tw_inv;
+    std::vector<uint64_t> &roots;
+    uint32_t &fieldN;
+    tw_t *&d_scal;
+    std::map<uint64_t, lm_galois_key> &gkeys;
+    std::map<std::string, std::shared_ptr<void>> &ext;
     uint64_t mul_counter = 0;
-    // galois keys
-    std::map<uint64_t, lm_galois_key> gkeys;
     // scratch
     std::map<std::string, std::pair<void *, size_t>> scratch;
     // freed set storage kept for reuse: a prover run allocates the same set sizes every time, and
@@ -82,9 +115,6 @@ struct lumen_ctx {
     size_t pool_bytes = 0;
     // kernels whose dynamic-LDS limit has already been raised on this device
     std::set<const void *> lds_attr_done;
-    // per-context derived tables owned by other translation units (key-switch constants,
-    // ciphertext-transform plans); released with the context
-    std::map<std::string, std::shared_ptr<void>> ext;
     // profiling
     bool prof = false;
     std::map<std::string, lm_prof_entry> prof_tab;
@@ -99,7 +129,38 @@ struct lumen_ctx {
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t tm0 = nullptr, tm1 = nullptr;
     std::string err;
+    explicit lumen_ctx(std::shared_ptr<lm_shared> s)
+        : sh(std::move(s)), d_tw_fwd(sh->d_tw_fwd), d_tw_inv(sh->d_tw_inv), roots(sh->roots), fieldN(sh->fieldN),
+          d_scal(sh->d_scal), gkeys(sh->gkeys), ext(sh->ext) {}
 };
+
+// first statement of every entry point that takes a context: serialise callers and select the
+// context's device for the calling thread (a fresh OS thread -- every cgo call may be one -- starts
+// on device 0)
+#define LM_ENTER(ctx)                                             \
+    std::lock_guard<std::recursive_mutex> lm_lock_((ctx)->mu);    \
+    (void)hipSetDevice((ctx)->device)
+// lookups and insertions in the shared maps (ext, gkeys, cached work lists)
+#define LM_SHARED_LOCK(ctx) std::lock_guard<std::recursive_mutex> lm_shlock_((ctx)->sh->mu)
+
+// shared derived tables by name: the returned handle keeps the table alive for the caller's scope even if
+// another clone replaces the entry meanwhile
+template <class T>
+static inline std::shared_ptr<T> lm_ext_get(lumen_ctx *ctx, const std::string &key) {
+    LM_SHARED_LOCK(ctx);
+    auto it = ctx->ext.find(key);
+    return it == ctx->ext.end() ? std::shared_ptr<T>() : std::static_pointer_cast<T>(it->second);
+}
+static inline void lm_ext_put(lumen_ctx *ctx, const std::string &key, std::shared_ptr<void> v) {
+    LM_SHARED_LOCK(ctx);
+    ctx->ext[key] = std::move(v);
+}
+
+// waits for every stream of the context (main, second lane, side jobs)
+void lm_sync_all(lumen_ctx *ctx);
+// pinned host staging of at least `bytes`, safe to overwrite (the previous asynchronous copy out of it
+// has completed); record ctx->ev_stage on the stream after enqueuing the next copy
+void *lm_stage(lumen_ctx *ctx, size_t bytes);
 
 int lm_fail(lumen_ctx *ctx, const char *fmt, ...);
 extern thread_local std::string lm_global_err;
@@ -126,6 +187,24 @@ extern thread_local std::string lm_global_err;
             (ctx)->lds_attr_done.insert(fp_);                                                             \
         }                                                                                                 \
     } while (0)
+
+// owns a freshly created set until the entry point hands it to the caller: every early return
+// (LM_HIP / LM_CHECK) gives the storage back instead of leaking it
+struct lm_set_guard {
+    lumen_ctx *ctx;
+    lumen_set *s;
+    lm_set_guard(lumen_ctx *c, lumen_set *x) : ctx(c), s(x) {}
+    ~lm_set_guard() {
+        if (s) lumen_set_destroy(ctx, s);
+    }
+    lumen_set *release() {
+        lumen_set *r = s;
+        s = nullptr;
+        return r;
+    }
+    lm_set_guard(const lm_set_guard &) = delete;
+    lm_set_guard &operator=(const lm_set_guard &) = delete;
+};
 
 // scratch buffer that persists in the context and only grows
 void *lm_scratch(lumen_ctx *ctx, const char *name, size_t bytes);

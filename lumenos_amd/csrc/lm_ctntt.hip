@@ -328,6 +328,7 @@ int upload_plan(lumen_ctx *ctx, Plan *plan, uint32_t count) {
 int get_plan(lumen_ctx *ctx, uint32_t count, uint32_t size, Plan **out) {
     char key[96];
     snprintf(key, sizeof(key), "ct_plan:%u:%u:%u", count, size, ctx->fieldN);
+    LM_SHARED_LOCK(ctx);
     auto it = ctx->ext.find(key);
     if (it != ctx->ext.end()) {
         *out = static_cast<Plan *>(it->second.get());
@@ -475,6 +476,7 @@ static int check_field(lumen_ctx *ctx, uint32_t size) {
 
 extern "C" int lumen_field_set(lumen_ctx *ctx, const uint64_t *roots_forward, uint32_t field_n) {
     LM_CHECK(nullptr, ctx && roots_forward, "lumen_field_set: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, field_n >= 2 && (field_n & (field_n - 1)) == 0, "field_n %u is not a power of two >= 2", field_n);
     LM_CHECK(ctx, field_n < (1u << 24), "field_n too large");
     const uint64_t T = ctx->T;
@@ -496,8 +498,9 @@ extern "C" int lumen_field_set(lumen_ctx *ctx, const uint64_t *roots_forward, ui
             tab[(size_t)i * (field_n + 1) + k] = h_tw(s, q);
         }
     }
+    LM_SHARED_LOCK(ctx);
     if (ctx->d_scal) {
-        LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        lm_sync_all(ctx);
         LM_HIP(ctx, hipFree(ctx->d_scal));
         ctx->d_scal = nullptr;
     }
@@ -508,6 +511,7 @@ extern "C" int lumen_field_set(lumen_ctx *ctx, const uint64_t *roots_forward, ui
 
 extern "C" int lumen_ct_ntt(lumen_ctx *ctx, lumen_set *values, uint32_t size) {
     LM_CHECK(nullptr, ctx && values, "lumen_ct_ntt: NULL argument");
+    LM_ENTER(ctx);
     if (size <= 1 || values->count == 0) return 0; // ntt.go:22-23
     if (int rc = check_field(ctx, size)) return rc;
     LM_CHECK(ctx, values->count % size == 0, "len(values)=%u is not a multiple of size=%u", values->count, size);
@@ -532,6 +536,7 @@ extern "C" int lumen_ct_ntt(lumen_ctx *ctx, lumen_set *values, uint32_t size) {
 extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *zero_ct,
                             uint32_t rho_inv, lumen_set **encoded) {
     LM_CHECK(nullptr, ctx && matrix && zero_ct && encoded, "lumen_encode: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, rho_inv >= 1, "rho_inv must be >= 1");
     const uint32_t cols = matrix->count, S = cols * rho_inv, nl = matrix->nl;
     LM_CHECK(ctx, cols > 0, "matrix is empty"); // core/code.go:4-6 panics on an empty row
@@ -541,31 +546,24 @@ extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint6
     u64 *dzero = (u64 *)lm_scratch(ctx, "zero_ct", ctw * sizeof(u64));
     if (!dzero) return 1;
     LM_HIP(ctx, hipMemcpyAsync(dzero, zero_ct, ctw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // zero_ct is caller memory
     lumen_set *out = nullptr;
     if (int rc = lumen_set_create(ctx, S, nl, &out)) return rc;
+    lm_set_guard og(ctx, out);
     Plan *plan = nullptr;
-    if (int rc = get_plan(ctx, S, S, &plan)) {
-        lumen_set_destroy(ctx, out);
-        return rc;
-    }
+    if (int rc = get_plan(ctx, S, S, &plan)) return rc;
     const uint32_t P = (uint32_t)plan->dev.size();
-    int rc = 0;
     if (P == 0) { // S == 1
         LM_HIP(ctx, hipMemcpyAsync(out->d, matrix->d, (size_t)cols * ctw * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
     } else {
         u64 *tmp = nullptr;
         if (P >= 2) {
             tmp = (u64 *)lm_scratch(ctx, "ct_tmp", out->words * sizeof(u64));
-            if (!tmp) rc = 1;
+            if (!tmp) return 1;
         }
-        if (!rc) rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d);
+        if (int rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d)) return rc;
     }
-    if (rc) {
-        lumen_set_destroy(ctx, out);
-        return rc;
-    }
-    *encoded = out;
+    *encoded = og.release();
     return 0;
 }
 
@@ -576,6 +574,7 @@ extern "C" int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const
                                   uint32_t rho_inv, uint32_t rank, uint32_t world, lumen_set **encoded,
                                   uint32_t *col_index, uint32_t *n_cols) {
     LM_CHECK(nullptr, ctx && matrix && zero_ct && encoded && col_index && n_cols, "lumen_encode_shard: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, world >= 1 && rank < world, "rank %u out of range for world %u", rank, world);
     LM_CHECK(ctx, rho_inv >= 1, "rho_inv must be >= 1");
     const uint32_t cols = matrix->count, S = cols * rho_inv, nl = matrix->nl;
@@ -612,17 +611,14 @@ extern "C" int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const
     LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     lumen_set *out = nullptr;
     if (int rc = lumen_set_create(ctx, (uint32_t)own.size(), nl, &out)) return rc;
-    int rc = 0;
+    lm_set_guard og(ctx, out);
     u64 *tmp = nullptr;
     if (P >= 2) {
         tmp = (u64 *)lm_scratch(ctx, "ct_tmp", (size_t)S * ctw * sizeof(u64));
-        if (!tmp) rc = 1;
+        if (!tmp) return 1;
     }
-    if (!rc && g1 > g0) rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d, g0, g1 - g0, dpos, dkeep);
-    if (rc) {
-        lumen_set_destroy(ctx, out);
-        return rc;
-    }
-    *encoded = out;
+    if (g1 > g0)
+        if (int rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d, g0, g1 - g0, dpos, dkeep)) return rc;
+    *encoded = og.release();
     return 0;
 }

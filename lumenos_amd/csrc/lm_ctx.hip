@@ -5,6 +5,7 @@
 // primitive 2N-th root the host passes, with Shoup companions instead of
 // Montgomery form).
 #include <cstring>
+#include <thread>
 
 #include "lm_ntt_dev.h"
 
@@ -26,7 +27,7 @@ void *lm_scratch(lumen_ctx *ctx, const char *name, size_t bytes) {
     auto &e = ctx->scratch[name];
     if (e.second >= bytes && e.first) return e.first;
     if (e.first) {
-        hipStreamSynchronize(ctx->stream);
+        lm_sync_all(ctx); // the old block may still be read on any of the context's streams
         hipFree(e.first);
         e.first = nullptr;
         e.second = 0;
@@ -39,6 +40,42 @@ void *lm_scratch(lumen_ctx *ctx, const char *name, size_t bytes) {
     e.first = p;
     e.second = bytes;
     return p;
+}
+
+lm_shared::~lm_shared() {
+    hipFree(d_tw_fwd);
+    hipFree(d_tw_inv);
+    hipFree(d_scal);
+    for (auto &kv : gkeys) {
+        hipFree(kv.second.d_key);
+        hipFree(kv.second.d_index);
+        hipFree(kv.second.d_inv_index);
+    }
+    ext.clear();
+}
+
+void lm_sync_all(lumen_ctx *ctx) {
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream_aux) hipStreamSynchronize(ctx->stream_aux);
+}
+
+void *lm_stage(lumen_ctx *ctx, size_t bytes) {
+    if (ctx->ev_stage) hipEventSynchronize(ctx->ev_stage); // the previous copy out of the buffer
+    if (ctx->stage_cap < bytes) {
+        if (ctx->stage_host) hipHostFree(ctx->stage_host);
+        for (int i = 0; i < 2; i++) {
+            if (ctx->io_host[i]) hipHostFree(ctx->io_host[i]);
+            if (ctx->ev_io[i]) hipEventDestroy(ctx->ev_io[i]);
+        }
+        ctx->stage_host = nullptr, ctx->stage_cap = 0;
+        if (hipHostMalloc(&ctx->stage_host, bytes, hipHostMallocDefault) != hipSuccess) {
+            lm_fail(ctx, "hipHostMalloc(%zu) for host staging failed", bytes);
+            return nullptr;
+        }
+        ctx->stage_cap = bytes;
+    }
+    return ctx->stage_host;
 }
 
 static hipEvent_t ev_get(lumen_ctx *ctx) {
@@ -66,14 +103,18 @@ lm_prof_scope::~lm_prof_scope() {
 
 void lm_prof_resolve(lumen_ctx *ctx) {
     if (ctx->prof_pending.empty()) return;
-    hipStreamSynchronize(ctx->stream);
     for (auto &p : ctx->prof_pending) {
+        // a pair may sit on the main stream, the second lane or the side stream: wait for the pair
+        // itself, and drop a measurement that cannot be read rather than log it as 0 ms
         float ms = 0;
-        hipEventElapsedTime(&ms, p.a, p.b);
-        auto &e = ctx->prof_tab[p.name];
-        e.total_ms += ms;
-        e.launches += 1;
-        e.units += p.units;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &e = ctx->prof_tab[p.name];
+            e.total_ms += ms;
+            e.launches += 1;
+            e.units += p.units;
+        } else {
+            (void)hipGetLastError();
+        }
         ctx->ev_pool.push_back(p.a);
         ctx->ev_pool.push_back(p.b);
     }
@@ -114,22 +155,8 @@ void lm_build_tw(uint64_t q, uint64_t psi, uint32_t logN, std::vector<tw_t> &fwd
     }
 }
 
-extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) {
-    if (!desc || !out) return lm_fail(nullptr, "lumen_ctx_create: NULL argument");
-    *out = nullptr;
-    LM_CHECK(nullptr, desc->abi_version == LUMEN_ABI_VERSION, "ABI version mismatch: got %u want %u",
-             desc->abi_version, LUMEN_ABI_VERSION);
-    LM_CHECK(nullptr, lm_logn_supported(desc->log_n),
-             "log_n %u unsupported: kernels are instantiated for N = 2^8 and 2^10..2^16", desc->log_n);
-    LM_CHECK(nullptr, desc->num_q >= 1 && desc->num_q + desc->num_p <= LM_MAX_LIMBS,
-             "bad limb counts L=%u K=%u", desc->num_q, desc->num_p);
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return lm_fail(nullptr, "no HIP device visible: the lumenos HIP path has no CPU fallback");
-    LM_CHECK(nullptr, desc->device >= 0 && desc->device < ndev, "device %d out of range (have %d)",
-             desc->device, ndev);
-    lumen_ctx *ctx = new lumen_ctx();
-    ctx->device = desc->device;
+// streams, events and timers: what every context owns, a clone included
+static int ctx_private_init(lumen_ctx *ctx) {
     LM_HIP(ctx, hipSetDevice(ctx->device));
     LM_HIP(ctx, hipStreamCreate(&ctx->stream));
     LM_HIP(ctx, hipStreamCreate(&ctx->stream2));
@@ -137,6 +164,30 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
     LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     LM_HIP(ctx, hipStreamCreate(&ctx->stream_aux));
     LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+    LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming));
+    LM_HIP(ctx, hipEventCreate(&ctx->tm0));
+    LM_HIP(ctx, hipEventCreate(&ctx->tm1));
+    return 0;
+}
+
+extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) {
+    if (!desc || !out) return lm_fail(nullptr, "lumen_ctx_create: NULL argument");
+    *out = nullptr;
+    LM_CHECK(nullptr, desc->abi_version == LUMEN_ABI_VERSION, "ABI version mismatch: got %u want %u",
+             desc->abi_version, LUMEN_ABI_VERSION);
+    LM_CHECK(nullptr, lm_logn_supported(desc->log_n),
+             "log_n %u unsupported: kernels are instantiated for N = 2^8 and 2^10..2^14", desc->log_n);
+    LM_CHECK(nullptr, desc->num_q >= 1 && desc->num_q + desc->num_p <= LM_MAX_LIMBS,
+             "bad limb counts L=%u K=%u", desc->num_q, desc->num_p);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return lm_fail(nullptr, "no HIP device visible: the lumenos HIP path has no CPU fallback");
+    LM_CHECK(nullptr, desc->device >= 0 && desc->device < ndev, "device %d out of range (have %d)",
+             desc->device, ndev);
+    std::unique_ptr<lumen_ctx, void (*)(lumen_ctx *)> guard(new lumen_ctx(std::make_shared<lm_shared>()),
+                                                            lumen_ctx_destroy);
+    lumen_ctx *ctx = guard.get();
+    ctx->device = desc->device;
     ctx->logN = desc->log_n;
     ctx->N = 1u << desc->log_n;
     ctx->L = desc->num_q;
@@ -149,22 +200,19 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
         // the lazy forward NTT takes inputs below 7q (fused basis extension) and lets values grow
         // by 3q per stage before its one reduction
         const uint64_t qmax = UINT64_MAX / (3ull * desc->log_n + 8);
-        if (q < (1ull << 20) || q > qmax || (q & (two_n - 1)) != 1) {
-            delete ctx;
+        if (q < (1ull << 20) || q > qmax || (q & (two_n - 1)) != 1)
             return lm_fail(nullptr, "modulus %u (%llu) must be == 1 mod 2N and below %llu", i,
                            (unsigned long long)q, (unsigned long long)qmax);
-        }
         // psi must be a primitive 2N-th root: psi^N == -1
-        if (h_powmod(psi, N, q) != q - 1) {
-            delete ctx;
+        if (h_powmod(psi, N, q) != q - 1)
             return lm_fail(nullptr, "psi[%u] is not a primitive 2N-th root of unity", i);
-        }
         ctx->mod[i] = q;
         ctx->psi[i] = psi;
         ctx->mods.m[i] = lm_make_mod(q);
         ctx->ninv[i] = h_tw(h_invmod(N % q, q), q);
     }
     for (uint32_t i = LK; i < LM_MAX_LIMBS; i++) ctx->mods.m[i] = ctx->mods.m[0];
+    if (int rc = ctx_private_init(ctx)) return rc;
     LM_HIP(ctx, hipMalloc((void **)&ctx->d_tw_fwd, (size_t)LK * N * sizeof(tw_t)));
     LM_HIP(ctx, hipMalloc((void **)&ctx->d_tw_inv, (size_t)LK * N * sizeof(tw_t)));
     std::vector<tw_t> f, b;
@@ -173,39 +221,59 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
         LM_HIP(ctx, hipMemcpy(ctx->d_tw_fwd + (size_t)i * N, f.data(), N * sizeof(tw_t), hipMemcpyHostToDevice));
         LM_HIP(ctx, hipMemcpy(ctx->d_tw_inv + (size_t)i * N, b.data(), N * sizeof(tw_t), hipMemcpyHostToDevice));
     }
-    LM_HIP(ctx, hipEventCreate(&ctx->tm0));
-    LM_HIP(ctx, hipEventCreate(&ctx->tm1));
-    *out = ctx;
+    *out = guard.release();
+    return 0;
+}
+
+// ServerBFV.CopyNew (fhe/bfv.go:56-58): what Evaluator.ShallowCopy gives a goroutine -- the same
+// parameters, twiddles, field table and keys (shared, read-only), its own streams, scratch, storage
+// pool, counters and error text.  Calls on the clone run concurrently with calls on the source.
+extern "C" int lumen_ctx_clone(lumen_ctx *src, lumen_ctx **out) {
+    if (!src || !out) return lm_fail(nullptr, "lumen_ctx_clone: NULL argument");
+    *out = nullptr;
+    LM_ENTER(src);
+    std::unique_ptr<lumen_ctx, void (*)(lumen_ctx *)> guard(new lumen_ctx(src->sh), lumen_ctx_destroy);
+    lumen_ctx *ctx = guard.get();
+    ctx->device = src->device;
+    ctx->logN = src->logN, ctx->N = src->N, ctx->L = src->L, ctx->K = src->K, ctx->T = src->T;
+    memcpy(ctx->mod, src->mod, sizeof(ctx->mod));
+    memcpy(ctx->psi, src->psi, sizeof(ctx->psi));
+    ctx->mods = src->mods;
+    memcpy(ctx->ninv, src->ninv, sizeof(ctx->ninv));
+    if (int rc = ctx_private_init(ctx)) {
+        src->err = ctx->err;
+        return rc;
+    }
+    *out = guard.release();
     return 0;
 }
 
 extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    hipFree(ctx->d_tw_fwd);
-    hipFree(ctx->d_tw_inv);
-    hipFree(ctx->d_scal);
-    for (auto &kv : ctx->gkeys) {
-        hipFree(kv.second.d_key);
-        hipFree(kv.second.d_index);
-        hipFree(kv.second.d_inv_index);
+    {
+        LM_ENTER(ctx);
+        lm_sync_all(ctx);
+        for (auto &kv : ctx->scratch) hipFree(kv.second.first);
+        for (auto &kv : ctx->pool) hipFree(kv.second);
+        lm_prof_resolve(ctx);
+        for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
+        if (ctx->tm0) hipEventDestroy(ctx->tm0);
+        if (ctx->tm1) hipEventDestroy(ctx->tm1);
+        if (ctx->aux_host) hipHostFree(ctx->aux_host);
+        if (ctx->stage_host) hipHostFree(ctx->stage_host);
+        for (int i = 0; i < 2; i++) {
+            if (ctx->io_host[i]) hipHostFree(ctx->io_host[i]);
+            if (ctx->ev_io[i]) hipEventDestroy(ctx->ev_io[i]);
+        }
+        if (ctx->ev_stage) hipEventDestroy(ctx->ev_stage);
+        if (ctx->ev_aux) hipEventDestroy(ctx->ev_aux);
+        if (ctx->stream_aux) hipStreamDestroy(ctx->stream_aux);
+        if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+        if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+        if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+        if (ctx->stream) hipStreamDestroy(ctx->stream);
+        ctx->sh.reset(); // the shared tables go with their last user
     }
-    for (auto &kv : ctx->scratch) hipFree(kv.second.first);
-    for (auto &kv : ctx->pool) hipFree(kv.second);
-    ctx->ext.clear();
-    lm_prof_resolve(ctx);
-    for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
-    hipEventDestroy(ctx->tm0);
-    hipEventDestroy(ctx->tm1);
-    if (ctx->stream_aux) hipStreamSynchronize(ctx->stream_aux);
-    if (ctx->aux_host) hipHostFree(ctx->aux_host);
-    hipEventDestroy(ctx->ev_aux);
-    hipStreamDestroy(ctx->stream_aux);
-    hipEventDestroy(ctx->ev_fork);
-    hipEventDestroy(ctx->ev_join);
-    hipStreamDestroy(ctx->stream2);
-    hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -215,6 +283,7 @@ extern "C" const char *lumen_last_error(const lumen_ctx *ctx) {
 
 extern "C" int lumen_sync(lumen_ctx *ctx) {
     LM_CHECK(nullptr, ctx, "lumen_sync: NULL ctx");
+    LM_ENTER(ctx);
     LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -224,6 +293,7 @@ extern "C" uint64_t lumen_mul_counter(const lumen_ctx *ctx) { return ctx ? ctx->
 // ------------------------------------------------------------------ sets
 extern "C" int lumen_set_create(lumen_ctx *ctx, uint32_t count, uint32_t num_limbs, lumen_set **out) {
     LM_CHECK(nullptr, ctx && out, "lumen_set_create: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, num_limbs >= 1 && num_limbs <= ctx->L, "num_limbs %u out of range [1,%u]", num_limbs, ctx->L);
     lumen_set *s = new lumen_set();
     s->count = count;
@@ -240,13 +310,15 @@ extern "C" int lumen_set_create(lumen_ctx *ctx, uint32_t count, uint32_t num_lim
         } else {
             hipError_t e = hipMalloc((void **)&s->d, bytes);
             if (e != hipSuccess && !ctx->pool.empty()) { // give the pool back and retry once
-                hipStreamSynchronize(ctx->stream);
+                (void)hipGetLastError();
+                lm_sync_all(ctx);
                 for (auto &kv : ctx->pool) hipFree(kv.second);
                 ctx->pool.clear();
                 ctx->pool_bytes = 0;
                 e = hipMalloc((void **)&s->d, bytes);
             }
             if (e != hipSuccess) {
+                (void)hipGetLastError();
                 delete s;
                 return lm_fail(ctx, "hipMalloc(%zu bytes) for a %u x %u-limb set failed: %s", bytes, count,
                                num_limbs, hipGetErrorString(e));
@@ -259,16 +331,26 @@ extern "C" int lumen_set_create(lumen_ctx *ctx, uint32_t count, uint32_t num_lim
 
 extern "C" void lumen_set_destroy(lumen_ctx *ctx, lumen_set *set) {
     if (!set) return;
-    if (ctx) hipStreamSynchronize(ctx->stream);
-    if (set->owner && set->d) {
-        lumen_ctx *home = (ctx && ctx == set->home) ? ctx : nullptr; // never touch a context the caller did not pass
-        const size_t bytes = set->words * sizeof(u64);
-        if (home && home->pool_bytes + bytes <= ((size_t)96 << 30)) {
-            home->pool.emplace(bytes, set->d);
-            home->pool_bytes += bytes;
-        } else {
-            hipFree(set->d);
+    if (ctx) {
+        LM_ENTER(ctx);
+        // nothing enqueued may still touch the storage once it is back in the pool: the main stream and
+        // the second lane always, the side stream when its hashing job reads this very storage (a set
+        // destroyed between lumen_leaf_digests_begin and _end) -- any other destroy leaves that job alone
+        hipStreamSynchronize(ctx->stream);
+        hipStreamSynchronize(ctx->stream2);
+        if (ctx->aux_digests && set->d && set->d < ctx->aux_hi && set->d + set->words > ctx->aux_lo)
+            hipStreamSynchronize(ctx->stream_aux);
+        if (set->owner && set->d) {
+            const size_t bytes = set->words * sizeof(u64);
+            if (ctx == set->home && ctx->pool_bytes + bytes <= ((size_t)96 << 30)) {
+                ctx->pool.emplace(bytes, set->d);
+                ctx->pool_bytes += bytes;
+            } else {
+                hipFree(set->d); // never touch a context the caller did not pass
+            }
         }
+    } else if (set->owner && set->d) {
+        hipFree(set->d); // hipFree waits for the device
     }
     delete set;
 }
@@ -276,6 +358,7 @@ extern "C" void lumen_set_destroy(lumen_ctx *ctx, lumen_set *set) {
 extern "C" int lumen_set_slice(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,
                                lumen_set **view) {
     LM_CHECK(nullptr, ctx && set && view, "lumen_set_slice: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, (uint64_t)first + n <= set->count, "slice [%u,%u) exceeds set of %u", first, first + n, set->count);
     lumen_set *v = new lumen_set();
     const size_t ctw = (size_t)2 * set->nl * ctx->N;
@@ -292,25 +375,110 @@ extern "C" uint32_t lumen_set_count(const lumen_set *set) { return set ? set->co
 extern "C" uint32_t lumen_set_limbs(const lumen_set *set) { return set ? set->nl : 0; }
 extern "C" void *lumen_set_device_ptr(const lumen_set *set) { return set ? set->d : nullptr; }
 
+// ---- host <-> device staging.  A pinned host buffer (lumen_host_alloc: what the Go
+// shim's stage() should fill) is handed to the DMA engine as it is.  A pageable one goes through two
+// pinned bounce buffers: the CPU copies chunk k+1 (a few threads: one core moves ~10 GB/s, the link
+// ~55) while the engine moves chunk k.
+extern "C" void *lumen_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        lm_fail(nullptr, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void lumen_host_free(void *p) {
+    if (p) hipHostFree(p);
+}
+
+static bool host_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); // an ordinary malloc'd pointer is "invalid value" here
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+#define LM_IO_CHUNK ((size_t)64 << 20)
+static void par_memcpy(void *dst, const void *src, size_t bytes) {
+    const size_t nthr = bytes >= ((size_t)8 << 20) ? 4 : 1;
+    if (nthr == 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::thread th[4];
+    const size_t part = (bytes / nthr + 63) & ~(size_t)63;
+    for (size_t t = 0; t < nthr; t++) {
+        const size_t lo = std::min(bytes, t * part), hi = std::min(bytes, lo + part);
+        th[t] = std::thread([=] { memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+    }
+    for (size_t t = 0; t < nthr; t++) th[t].join();
+}
+
+static int io_buffers(lumen_ctx *ctx) {
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->io_host[i]) LM_HIP(ctx, hipHostMalloc(&ctx->io_host[i], LM_IO_CHUNK, hipHostMallocDefault));
+        if (!ctx->ev_io[i]) LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_io[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
 extern "C" int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, uint32_t n,
                                 const uint64_t *host) {
     LM_CHECK(nullptr, ctx && set && host, "lumen_set_upload: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, (uint64_t)first + n <= set->count, "upload range [%u,%u) exceeds set of %u", first, first + n, set->count);
-    size_t ctw = (size_t)2 * set->nl * ctx->N;
-    LM_HIP(ctx, hipMemcpyAsync(set->d + (size_t)first * ctw, host, (size_t)n * ctw * sizeof(u64),
-                               hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t ctw = (size_t)2 * set->nl * ctx->N, bytes = (size_t)n * ctw * sizeof(u64);
+    char *dst = (char *)(set->d + (size_t)first * ctw);
+    if (bytes <= ((size_t)1 << 20) || host_is_pinned(host)) {
+        LM_HIP(ctx, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        if (int rc = io_buffers(ctx)) return rc;
+        int i = 0;
+        for (size_t off = 0; off < bytes; off += LM_IO_CHUNK, i ^= 1) {
+            const size_t len = std::min(LM_IO_CHUNK, bytes - off);
+            LM_HIP(ctx, hipEventSynchronize(ctx->ev_io[i])); // the copy that last read this bounce buffer
+            par_memcpy(ctx->io_host[i], (const char *)host + off, len);
+            LM_HIP(ctx, hipMemcpyAsync(dst + off, ctx->io_host[i], len, hipMemcpyHostToDevice, ctx->stream));
+            LM_HIP(ctx, hipEventRecord(ctx->ev_io[i], ctx->stream));
+        }
+    }
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `host` is caller memory
     return 0;
 }
 
 extern "C" int lumen_set_download(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,
                                   uint64_t *host) {
     LM_CHECK(nullptr, ctx && set && host, "lumen_set_download: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, (uint64_t)first + n <= set->count, "download range [%u,%u) exceeds set of %u", first, first + n, set->count);
-    size_t ctw = (size_t)2 * set->nl * ctx->N;
-    LM_HIP(ctx, hipMemcpyAsync(host, set->d + (size_t)first * ctw, (size_t)n * ctw * sizeof(u64),
-                               hipMemcpyDeviceToHost, ctx->stream));
-    LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t ctw = (size_t)2 * set->nl * ctx->N, bytes = (size_t)n * ctw * sizeof(u64);
+    const char *src = (const char *)(set->d + (size_t)first * ctw);
+    if (bytes <= ((size_t)1 << 20) || host_is_pinned(host)) {
+        LM_HIP(ctx, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
+    if (int rc = io_buffers(ctx)) return rc;
+    // chunk k+1 crosses the link while the CPU copies chunk k out of its bounce buffer
+    const size_t nchunks = (bytes + LM_IO_CHUNK - 1) / LM_IO_CHUNK;
+    auto issue = [&](size_t k) -> int {
+        const size_t off = k * LM_IO_CHUNK, len = std::min(LM_IO_CHUNK, bytes - off);
+        LM_HIP(ctx, hipMemcpyAsync(ctx->io_host[k & 1], src + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP(ctx, hipEventRecord(ctx->ev_io[k & 1], ctx->stream));
+        return 0;
+    };
+    if (nchunks)
+        if (int rc = issue(0)) return rc;
+    for (size_t k = 0; k < nchunks; k++) {
+        if (k + 1 < nchunks)
+            if (int rc = issue(k + 1)) return rc;
+        const size_t off = k * LM_IO_CHUNK, len = std::min(LM_IO_CHUNK, bytes - off);
+        LM_HIP(ctx, hipEventSynchronize(ctx->ev_io[k & 1]));
+        par_memcpy((char *)host + off, ctx->io_host[k & 1], len);
+    }
     return 0;
 }
 
@@ -329,6 +497,7 @@ __global__ void k_fill_random(u64 *d, size_t words, uint32_t N, uint32_t nl, lm_
 
 extern "C" int lumen_set_fill_random(lumen_ctx *ctx, lumen_set *set, uint64_t seed) {
     LM_CHECK(nullptr, ctx && set, "lumen_set_fill_random: NULL argument");
+    LM_ENTER(ctx);
     if (!set->words) return 0;
     hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, ctx->stream, set->d, set->words,
                        ctx->N, set->nl, ctx->mods, (u64)seed);
@@ -339,12 +508,14 @@ extern "C" int lumen_set_fill_random(lumen_ctx *ctx, lumen_set *set, uint64_t se
 // ------------------------------------------------------------------ timing
 extern "C" int lumen_timer_start(lumen_ctx *ctx) {
     LM_CHECK(nullptr, ctx, "NULL ctx");
+    LM_ENTER(ctx);
     LM_HIP(ctx, hipEventRecord(ctx->tm0, ctx->stream));
     return 0;
 }
 
 extern "C" int lumen_timer_stop(lumen_ctx *ctx, float *elapsed_ms) {
     LM_CHECK(nullptr, ctx && elapsed_ms, "NULL argument");
+    LM_ENTER(ctx);
     LM_HIP(ctx, hipEventRecord(ctx->tm1, ctx->stream));
     LM_HIP(ctx, hipEventSynchronize(ctx->tm1));
     LM_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->tm0, ctx->tm1));
@@ -353,6 +524,7 @@ extern "C" int lumen_timer_stop(lumen_ctx *ctx, float *elapsed_ms) {
 
 extern "C" int lumen_prof_enable(lumen_ctx *ctx, int on) {
     LM_CHECK(nullptr, ctx, "NULL ctx");
+    LM_ENTER(ctx);
     if (!on) lm_prof_resolve(ctx);
     ctx->prof = on != 0;
     return 0;
@@ -360,6 +532,7 @@ extern "C" int lumen_prof_enable(lumen_ctx *ctx, int on) {
 
 extern "C" int lumen_prof_reset(lumen_ctx *ctx) {
     LM_CHECK(nullptr, ctx, "NULL ctx");
+    LM_ENTER(ctx);
     lm_prof_resolve(ctx);
     ctx->prof_tab.clear();
     return 0;
@@ -367,6 +540,7 @@ extern "C" int lumen_prof_reset(lumen_ctx *ctx) {
 
 extern "C" size_t lumen_prof_names(lumen_ctx *ctx, char *buf, size_t cap) {
     if (!ctx) return 0;
+    LM_ENTER(ctx);
     lm_prof_resolve(ctx);
     std::string all;
     for (auto &kv : ctx->prof_tab) {
@@ -384,6 +558,7 @@ extern "C" size_t lumen_prof_names(lumen_ctx *ctx, char *buf, size_t cap) {
 extern "C" int lumen_prof_read(lumen_ctx *ctx, const char *kernel, double *total_ms,
                                uint64_t *launches, uint64_t *units) {
     LM_CHECK(nullptr, ctx && kernel, "NULL argument");
+    LM_ENTER(ctx);
     lm_prof_resolve(ctx);
     auto it = ctx->prof_tab.find(kernel);
     lm_prof_entry e;

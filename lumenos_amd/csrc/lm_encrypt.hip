@@ -195,6 +195,7 @@ struct PkTable {
 
 extern "C" int lumen_load_public_key(lumen_ctx *ctx, const uint64_t *pk) {
     LM_CHECK(nullptr, ctx && pk, "lumen_load_public_key: NULL argument");
+    LM_ENTER(ctx);
     const uint32_t N = ctx->N, L = ctx->L;
     std::vector<tw_t> tab((size_t)2 * L * N);
     for (uint32_t w = 0; w < 2; w++)
@@ -209,7 +210,7 @@ extern "C" int lumen_load_public_key(lumen_ctx *ctx, const uint64_t *pk) {
     auto sp = std::make_shared<PkTable>();
     LM_HIP(ctx, hipMalloc((void **)&sp->d_pk, tab.size() * sizeof(tw_t)));
     LM_HIP(ctx, hipMemcpy(sp->d_pk, tab.data(), tab.size() * sizeof(tw_t), hipMemcpyHostToDevice));
-    ctx->ext["public_key"] = sp;
+    lm_ext_put(ctx, "public_key", sp);
     return 0;
 }
 
@@ -231,6 +232,7 @@ struct EncoderTables {
 
 extern "C" int lumen_encoder_set(lumen_ctx *ctx, uint64_t psi_t) {
     LM_CHECK(nullptr, ctx, "lumen_encoder_set: NULL ctx");
+    LM_ENTER(ctx);
     const uint64_t T = ctx->T;
     const uint32_t N = ctx->N, logN = ctx->logN;
     LM_CHECK(ctx, T > 2 && (T & (2ull * N - 1)) == 1, "plaintext modulus %llu is not 1 mod 2N", (unsigned long long)T);
@@ -259,7 +261,7 @@ extern "C" int lumen_encoder_set(lumen_ctx *ctx, uint64_t psi_t) {
     LM_HIP(ctx, hipMemcpy(sp->d_tw_inv, b.data(), (size_t)N * sizeof(tw_t), hipMemcpyHostToDevice));
     LM_HIP(ctx, hipMalloc((void **)&sp->d_tw_fwd, (size_t)N * sizeof(tw_t)));
     LM_HIP(ctx, hipMemcpy(sp->d_tw_fwd, f.data(), (size_t)N * sizeof(tw_t), hipMemcpyHostToDevice));
-    ctx->ext["encoder"] = sp;
+    lm_ext_put(ctx, "encoder", sp);
     return 0;
 }
 
@@ -288,21 +290,25 @@ static int encrypt_t(lumen_ctx *ctx, const int8_t *small, const tw_t *pk, const 
 // plaintexts (NTT-domain RNS, [count][L][N]) or values ([count][rows] slot values) or neither (zeros)
 static int encrypt_impl(lumen_ctx *ctx, const uint64_t *plaintexts, const uint64_t *values, uint32_t rows,
                         uint32_t count, const uint8_t seed[32], uint64_t first_index, lumen_set **out) {
-    auto it = ctx->ext.find("public_key");
-    LM_CHECK(ctx, it != ctx->ext.end(), "no public key loaded (lumen_load_public_key)");
-    const PkTable *pkt = static_cast<const PkTable *>(it->second.get());
+    const std::shared_ptr<PkTable> pk_hold = lm_ext_get<PkTable>(ctx, "public_key");
+    LM_CHECK(ctx, pk_hold, "no public key loaded (lumen_load_public_key)");
+    const PkTable *pkt = pk_hold.get();
+    std::shared_ptr<EncoderTables> enc_hold;
     const EncoderTables *enc = nullptr;
     if (values) {
-        auto ie = ctx->ext.find("encoder");
-        LM_CHECK(ctx, ie != ctx->ext.end(), "no encoder tables (lumen_encoder_set)");
-        enc = static_cast<const EncoderTables *>(ie->second.get());
+        enc_hold = lm_ext_get<EncoderTables>(ctx, "encoder");
+        LM_CHECK(ctx, enc_hold, "no encoder tables (lumen_encoder_set)");
+        enc = enc_hold.get();
         LM_CHECK(ctx, rows >= 1 && rows <= ctx->N, "rows=%u out of range [1, N]", rows);
     }
     const uint32_t N = ctx->N, L = ctx->L;
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, count, L, &o)) return rc;
-    *out = o;
-    if (!count) return 0;
+    lm_set_guard og(ctx, o); // given back on every early return below
+    if (!count) {
+        *out = og.release();
+        return 0;
+    }
     enc_seed_t key;
     memcpy(key.k, seed, 32); // little-endian words, as RFC 8439 reads the key
     enc_cdt_t cdt;
@@ -316,11 +322,7 @@ static int encrypt_impl(lumen_ctx *ctx, const uint64_t *plaintexts, const uint64
     u64 *dpt = plaintexts ? (u64 *)lm_scratch(ctx, "enc_pt", (size_t)chunk * L * N * sizeof(u64)) : nullptr;
     u64 *dval = values ? (u64 *)lm_scratch(ctx, "enc_val", (size_t)chunk * rows * sizeof(u64)) : nullptr;
     u64 *dm = values ? (u64 *)lm_scratch(ctx, "enc_m", (size_t)chunk * N * sizeof(u64)) : nullptr;
-    if (!small || (plaintexts && !dpt) || (values && (!dval || !dm))) {
-        lumen_set_destroy(ctx, o);
-        *out = nullptr;
-        return 1;
-    }
+    if (!small || (plaintexts && !dpt) || (values && (!dval || !dm))) return 1;
     int rc = 0;
     for (uint32_t first = 0; first < count && !rc; first += chunk) {
         const uint32_t n = std::min(chunk, count - first);
@@ -362,23 +364,23 @@ static int encrypt_impl(lumen_ctx *ctx, const uint64_t *plaintexts, const uint64
             rc = lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
         }
     }
-    if (!rc && (plaintexts || values)) LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // caller memory
-    if (rc) {
-        lumen_set_destroy(ctx, o);
-        *out = nullptr;
-    }
-    return rc;
+    if (rc) return rc;
+    if (plaintexts || values) LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // caller memory
+    *out = og.release();
+    return 0;
 }
 
 extern "C" int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint32_t count, const uint8_t seed[32],
                                 uint64_t first_index, lumen_set **out) {
     LM_CHECK(nullptr, ctx && seed && out, "lumen_encrypt_pk: NULL argument");
+    LM_ENTER(ctx);
     return encrypt_impl(ctx, plaintexts, nullptr, 0, count, seed, first_index, out);
 }
 
 extern "C" int lumen_encrypt_values(lumen_ctx *ctx, const uint64_t *values, uint32_t rows, uint32_t count,
                                     const uint8_t seed[32], uint64_t first_index, lumen_set **out) {
     LM_CHECK(nullptr, ctx && values && seed && out, "lumen_encrypt_values: NULL argument");
+    LM_ENTER(ctx);
     return encrypt_impl(ctx, nullptr, values, rows, count, seed, first_index, out);
 }
 
@@ -398,6 +400,7 @@ struct SkTable {
 
 extern "C" int lumen_load_secret_key(lumen_ctx *ctx, const uint64_t *sk) {
     LM_CHECK(nullptr, ctx && sk, "lumen_load_secret_key: NULL argument");
+    LM_ENTER(ctx);
     const uint32_t N = ctx->N, L = ctx->L;
     std::vector<tw_t> tab((size_t)L * N);
     for (uint32_t l = 0; l < L; l++) {
@@ -411,7 +414,7 @@ extern "C" int lumen_load_secret_key(lumen_ctx *ctx, const uint64_t *sk) {
     auto sp = std::make_shared<SkTable>();
     LM_HIP(ctx, hipMalloc((void **)&sp->d_sk, tab.size() * sizeof(tw_t)));
     LM_HIP(ctx, hipMemcpy(sp->d_sk, tab.data(), tab.size() * sizeof(tw_t), hipMemcpyHostToDevice));
-    ctx->ext["secret_key"] = sp;
+    lm_ext_put(ctx, "secret_key", sp);
     return 0;
 }
 
@@ -493,14 +496,15 @@ static int decrypt_phase_t(lumen_ctx *ctx, const u64 *ct, const tw_t *sk, u64 *p
 
 extern "C" int lumen_decrypt(lumen_ctx *ctx, const lumen_set *set, uint64_t scale, uint32_t nvalues, uint64_t *values) {
     LM_CHECK(nullptr, ctx && set && values, "lumen_decrypt: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, set->nl >= 1 && set->nl <= 2, "lumen_decrypt takes ciphertexts of one or two limbs (have %u)", set->nl);
     LM_CHECK(ctx, nvalues >= 1 && nvalues <= ctx->N, "nvalues=%u out of range [1, N]", nvalues);
-    auto is = ctx->ext.find("secret_key");
-    LM_CHECK(ctx, is != ctx->ext.end(), "no secret key loaded (lumen_load_secret_key)");
-    auto ie = ctx->ext.find("encoder");
-    LM_CHECK(ctx, ie != ctx->ext.end(), "no encoder tables (lumen_encoder_set)");
-    const SkTable *sk = static_cast<const SkTable *>(is->second.get());
-    const EncoderTables *enc = static_cast<const EncoderTables *>(ie->second.get());
+    const std::shared_ptr<SkTable> sk_hold = lm_ext_get<SkTable>(ctx, "secret_key");
+    LM_CHECK(ctx, sk_hold, "no secret key loaded (lumen_load_secret_key)");
+    const std::shared_ptr<EncoderTables> enc_hold = lm_ext_get<EncoderTables>(ctx, "encoder");
+    LM_CHECK(ctx, enc_hold, "no encoder tables (lumen_encoder_set)");
+    const SkTable *sk = sk_hold.get();
+    const EncoderTables *enc = enc_hold.get();
     const uint32_t N = ctx->N, nl = set->nl, count = set->count;
     const uint64_t T = ctx->T;
     LM_CHECK(ctx, scale % T != 0, "scale is 0 modulo T");

@@ -120,6 +120,7 @@ __global__ void k_leaf_sha256(const u64 *__restrict__ set, size_t words, uint32_
 
 extern "C" int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8_t *digests) {
     LM_CHECK(nullptr, ctx && level1 && digests, "lumen_leaf_digests: NULL argument");
+    LM_ENTER(ctx);
     if (!level1->count) return 0;
     const size_t words = (size_t)2 * level1->nl * ctx->N;
     LM_CHECK(ctx, words >= 6, "ciphertext too small to serialise");
@@ -138,6 +139,7 @@ extern "C" int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8
 
 extern "C" int lumen_leaf_digests_begin(lumen_ctx *ctx, const lumen_set *level1) {
     LM_CHECK(nullptr, ctx && level1, "lumen_leaf_digests_begin: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, !ctx->aux_digests, "a lumen_leaf_digests_begin job is already in flight");
     if (!level1->count) return 0;
     const size_t words = (size_t)2 * level1->nl * ctx->N, bytes = (size_t)level1->count * 32;
@@ -166,14 +168,17 @@ extern "C" int lumen_leaf_digests_begin(lumen_ctx *ctx, const lumen_set *level1)
     }
     LM_HIP(ctx, hipMemcpyAsync(ctx->aux_host, dd, bytes, hipMemcpyDeviceToHost, ctx->stream_aux));
     ctx->aux_digests = level1->count;
+    ctx->aux_lo = level1->d, ctx->aux_hi = level1->d + level1->words; // lumen_set_destroy waits for the job if it frees this
     return 0;
 }
 
 extern "C" int lumen_leaf_digests_end(lumen_ctx *ctx, uint8_t *digests) {
     LM_CHECK(nullptr, ctx && digests, "lumen_leaf_digests_end: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, ctx->aux_digests, "no lumen_leaf_digests_begin job in flight");
     const uint32_t n = ctx->aux_digests;
     ctx->aux_digests = 0;
+    ctx->aux_lo = ctx->aux_hi = nullptr;
     LM_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
     memcpy(digests, ctx->aux_host, (size_t)n * 32);
     return 0;
@@ -202,6 +207,7 @@ extern "C" int lumen_merkle_build(lumen_ctx *ctx, const uint8_t *leaf_digests, u
     // last node is hashed with itself (tree.go:127-131).  S*32 bytes of input
     // (256 KiB at S = 8192): host work.
     LM_CHECK(nullptr, ctx && leaf_digests && nodes && n_nodes && root, "lumen_merkle_build: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, n_leaves > 0, "cannot build a tree over zero leaves");
     size_t total = 0;
     for (uint32_t n = n_leaves;; n = (n + 1) / 2) {
@@ -242,23 +248,24 @@ __global__ void k_gather(const u64 *__restrict__ src, u64 *__restrict__ dst, con
 extern "C" int lumen_gather(lumen_ctx *ctx, const lumen_set *src, const uint32_t *idx, uint32_t n,
                             lumen_set **out) {
     LM_CHECK(nullptr, ctx && src && out && (idx || !n), "lumen_gather: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, n <= 65535, "gather of %u ciphertexts exceeds the grid", n);
     for (uint32_t i = 0; i < n; i++)
         LM_CHECK(ctx, idx[i] < src->count, "gather index %u out of range (%u ciphertexts)", idx[i], src->count);
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, n, src->nl, &o)) return rc;
+    lm_set_guard og(ctx, o);
     if (n) {
         uint32_t *didx = (uint32_t *)lm_scratch(ctx, "gather_idx", (size_t)n * 4);
-        if (!didx) {
-            lumen_set_destroy(ctx, o);
-            return 1;
-        }
-        LM_HIP(ctx, hipMemcpyAsync(didx, idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        uint32_t *hidx = (uint32_t *)lm_stage(ctx, (size_t)n * 4); // idx is caller memory: copy it before returning
+        if (!didx || !hidx) return 1;
+        memcpy(hidx, idx, (size_t)n * 4);
+        LM_HIP(ctx, hipMemcpyAsync(didx, hidx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        LM_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
         const size_t ctw2 = (size_t)src->nl * ctx->N; // 2*nl*N u64 = nl*N ulonglong2
-        LM_CHECK(ctx, n <= 65535, "gather of %u ciphertexts exceeds the grid", n);
         hipLaunchKernelGGL(k_gather, dim3(32, n), dim3(256), 0, ctx->stream, src->d, o->d, didx, ctw2);
         LM_HIP(ctx, hipGetLastError());
-        LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // idx is caller memory
     }
-    *out = o;
+    *out = og.release();
     return 0;
 }

@@ -103,14 +103,33 @@ __global__ __launch_bounds__(256) void k_pack_v(u64 *__restrict__ y, size_t poly
 }
 
 // ---- step 0: MulNew(ct, pt): out = ct (.) (pt * T)
-__global__ void k_mul_plain(const u64 *__restrict__ ct, u64 *__restrict__ out, const tw_t *__restrict__ ptT,
+// The plaintext arrives once per call as raw residues; k_pt_prepare turns it into the multiplier in
+// Montgomery form, ptM = pt * T * 2^64 mod q_l (one Montgomery product with c_l = T * 2^128 mod q_l),
+// so that the product over the matrix is one 64x64 multiplication and one Montgomery reduction per
+// residue, canonical result.
+struct pt_consts_t {
+    u64 c[LM_MAX_LIMBS]; // T * 2^128 mod q_l
+};
+__global__ void k_pt_prepare(const u64 *__restrict__ pt, u64 *__restrict__ ptM, uint32_t logN, uint32_t nl,
+                             lm_mods mods, pt_consts_t pc) {
+    const size_t total = (size_t)nl << logN;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t limb = (uint32_t)(i >> logN);
+        u64 lo, hi;
+        mul128(pt[i], pc.c[limb], lo, hi);
+        ptM[i] = lm_mont_reduce(lo, hi, mods.m[limb].q, mods.m[limb].qneg);
+    }
+}
+__global__ void k_mul_plain(const u64 *__restrict__ ct, u64 *__restrict__ out, const u64 *__restrict__ ptM,
                             size_t words, uint32_t logN, uint32_t nl, lm_mods mods) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t N = (size_t)1 << logN;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
         const uint32_t limb = (uint32_t)((i >> logN) % nl);
         const size_t k = i & (N - 1);
-        out[i] = lm_shoup(ct[i], ptT[(size_t)limb * N + k], mods.m[limb].q);
+        u64 lo, hi;
+        mul128(ct[i], ptM[(size_t)limb * N + k], lo, hi);
+        out[i] = lm_mont_reduce(lo, hi, mods.m[limb].q, mods.m[limb].qneg);
     }
 }
 
@@ -199,24 +218,24 @@ __device__ __forceinline__ void mac2(mac_acc &p, mac_acc &q, u64 x, u64 k0, u64 
     const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
 #if LM_ASM_SHOUP
     asm("v_mad_u64_u32 %[pa0], s[98:99], %[x0], %[k00], %[pa0]\n\t"
-        "v_mad_u64_u32 %[qa0], s[100:101], %[x0], %[k10], %[qa0]\n\t"
+        "v_mad_u64_u32 %[qa0], s[90:91], %[x0], %[k10], %[qa0]\n\t"
         "v_mad_u64_u32 %[pa1], s[94:95], %[x0], %[k01], %[pa1]\n\t"
         "v_addc_co_u32_e64 %[pc0], s[96:97], %[pc0], 0, s[98:99]\n\t"
         "v_mad_u64_u32 %[qa1], s[92:93], %[x0], %[k11], %[qa1]\n\t"
-        "v_addc_co_u32_e64 %[qc0], s[96:97], %[qc0], 0, s[100:101]\n\t"
+        "v_addc_co_u32_e64 %[qc0], s[96:97], %[qc0], 0, s[90:91]\n\t"
         "v_mad_u64_u32 %[pa3], s[96:97], %[x1], %[k01], %[pa3]\n\t"
         "v_addc_co_u32_e64 %[pc1], s[96:97], %[pc1], 0, s[94:95]\n\t"
         "v_mad_u64_u32 %[pa1], s[98:99], %[x1], %[k00], %[pa1]\n\t"
         "v_addc_co_u32_e64 %[qc1], s[96:97], %[qc1], 0, s[92:93]\n\t"
-        "v_mad_u64_u32 %[qa1], s[100:101], %[x1], %[k10], %[qa1]\n\t"
+        "v_mad_u64_u32 %[qa1], s[90:91], %[x1], %[k10], %[qa1]\n\t"
         "v_mad_u64_u32 %[qa3], s[96:97], %[x1], %[k11], %[qa3]\n\t"
         "v_addc_co_u32_e64 %[pc1], s[96:97], %[pc1], 0, s[98:99]\n\t"
-        "v_addc_co_u32_e64 %[qc1], s[96:97], %[qc1], 0, s[100:101]"
+        "v_addc_co_u32_e64 %[qc1], s[96:97], %[qc1], 0, s[90:91]"
         : [pa0] "+v"(p.a0), [pa1] "+v"(p.a1), [pa3] "+v"(p.a3), [pc0] "+v"(p.c0), [pc1] "+v"(p.c1),
           [qa0] "+v"(q.a0), [qa1] "+v"(q.a1), [qa3] "+v"(q.a3), [qc0] "+v"(q.c0), [qc1] "+v"(q.c1)
         : [x0] "v"(x0), [x1] "v"(x1), [k00] "v"((u32)k0), [k01] "v"((u32)(k0 >> 32)), [k10] "v"((u32)k1),
           [k11] "v"((u32)(k1 >> 32))
-        : "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101");
+        : "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s90", "s91");
 #else
     auto one = [&](mac_acc &r, u64 k) {
         const u32 k0w = (u32)k, k1w = (u32)(k >> 32);
@@ -415,6 +434,7 @@ uint64_t hat_inv(const uint64_t *src, uint32_t ns, uint32_t a) {
 }
 
 int get_tables(lumen_ctx *ctx, KsTables **out) {
+    LM_SHARED_LOCK(ctx);
     auto it = ctx->ext.find("ks_tables");
     if (it != ctx->ext.end()) {
         *out = static_cast<KsTables *>(it->second.get());
@@ -505,6 +525,10 @@ struct KsScratch {
 #define LM_MODUP_TGROUP 4
 #endif
 static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint32_t **out) {
+    LM_SHARED_LOCK(ctx); // the cached lists are shared with the context's clones
+    // packed as column (16 bits) | digit (8) | target modulus (8): refuse what does not fit
+    LM_CHECK(ctx, B >= 1 && B <= 65535 && tb->beta <= 255 && ctx->L + ctx->K <= 255,
+             "key-switch batch of %u columns (beta %u) does not fit the packed work list", B, tb->beta);
     auto it = tb->d_work.find(B);
     if (it != tb->d_work.end()) {
         *out = it->second;
@@ -548,6 +572,9 @@ static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint3
 #define LM_MODDOWN_TGROUP 4
 #endif
 static int moddown_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint32_t **out) {
+    LM_SHARED_LOCK(ctx);
+    // packed as polynomial 2b + w (16 bits) | target limb (16)
+    LM_CHECK(ctx, B >= 1 && 2 * (uint64_t)B <= 65535, "key-switch batch of %u columns does not fit the packed work list", B);
     auto it = tb->d_work_down.find(B);
     if (it != tb->d_work_down.end()) {
         *out = it->second;
@@ -696,12 +723,17 @@ int inner_sum_batch(lumen_ctx *ctx, u64 *acc, uint32_t B, uint32_t n, KsTables *
     uint64_t gal[64];
     const uint32_t cnt = lumen_inner_sum_galois_elements(ctx, n, gal);
     for (uint32_t r = 0; r < cnt; r++) {
-        auto it = ctx->gkeys.find(gal[r]);
-        LM_CHECK(ctx, it != ctx->gkeys.end(), "Galois key for element %llu not loaded",
-                 (unsigned long long)gal[r]);
+        lm_galois_key gk;
+        {
+            LM_SHARED_LOCK(ctx);
+            auto it = ctx->gkeys.find(gal[r]);
+            LM_CHECK(ctx, it != ctx->gkeys.end(), "Galois key for element %llu not loaded",
+                     (unsigned long long)gal[r]);
+            gk = it->second;
+        }
         // ping-pong: the automorphism reads two positions of the old accumulator per output
         u64 *src = (r & 1) ? s.acc2 : acc, *dst = (r & 1) ? acc : s.acc2;
-        if (int rc = rotate_accumulate(ctx, src, dst, B, it->second, tb, s)) return rc;
+        if (int rc = rotate_accumulate(ctx, src, dst, B, gk, tb, s)) return rc;
     }
     if (cnt & 1)
         LM_HIP(ctx, hipMemcpyAsync(acc, s.acc2, (size_t)B * 2 * ctx->L * ctx->N * 8, hipMemcpyDeviceToDevice,
@@ -709,28 +741,38 @@ int inner_sum_batch(lumen_ctx *ctx, u64 *acc, uint32_t B, uint32_t n, KsTables *
     return 0;
 }
 
-int upload_ptT(lumen_ctx *ctx, const uint64_t *pt, uint32_t nl, tw_t **out) {
-    // pt * T with Shoup companion: the multiplier MulNew(ct, pt) applies
-    // ([LATTIGO-RECALL] bgv tensorStandard, ciphertext x plaintext branch)
+int upload_ptT(lumen_ctx *ctx, const uint64_t *pt, uint32_t nl, u64 **out) {
+    // pt * T in Montgomery form: the multiplier MulNew(ct, pt) applies
+    // ([LATTIGO-RECALL] bgv tensorStandard, ciphertext x plaintext branch).  The host only checks the
+    // range and stages the residues in pinned memory; the products are formed on the device, and the
+    // call does not wait for the copy.
     const uint32_t N = ctx->N;
-    std::vector<tw_t> tab((size_t)nl * N);
+    const size_t words = (size_t)nl * N;
+    u64 *h = (u64 *)lm_stage(ctx, words * sizeof(u64));
+    u64 *draw = (u64 *)lm_scratch(ctx, "pt_raw", words * sizeof(u64));
+    u64 *d = (u64 *)lm_scratch(ctx, "ptT", words * sizeof(u64));
+    if (!h || !draw || !d) return 1;
+    pt_consts_t pc;
+    memset(&pc, 0, sizeof(pc));
     for (uint32_t l = 0; l < nl; l++) {
-        const uint64_t q = ctx->mod[l], t = ctx->T % q;
-        for (uint32_t k = 0; k < N; k++) {
-            const uint64_t x = pt[(size_t)l * N + k];
-            if (x >= q) return lm_fail(ctx, "plaintext residue out of range at limb %u coeff %u", l, k);
-            tab[(size_t)l * N + k] = h_tw(h_mulmod(x, t, q), q);
-        }
+        const uint64_t q = ctx->mod[l];
+        const uint64_t *src = pt + (size_t)l * N;
+        uint64_t bad = 0;
+        for (uint32_t k = 0; k < N; k++) bad |= (uint64_t)(src[k] >= q);
+        if (bad) return lm_fail(ctx, "plaintext residue out of range at limb %u", l);
+        memcpy(h + (size_t)l * N, src, (size_t)N * sizeof(u64));
+        const uint64_t r = (uint64_t)((((u128)1) << 64) % q);
+        pc.c[l] = h_mulmod(ctx->T % q, h_mulmod(r, r, q), q);
     }
-    tw_t *d = (tw_t *)lm_scratch(ctx, "ptT", tab.size() * sizeof(tw_t));
-    if (!d) return 1;
-    LM_HIP(ctx, hipMemcpyAsync(d, tab.data(), tab.size() * sizeof(tw_t), hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // tab is a local
+    LM_HIP(ctx, hipMemcpyAsync(draw, h, words * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+    hipLaunchKernelGGL(k_pt_prepare, dim3(256), dim3(256), 0, ctx->stream, draw, d, ctx->logN, nl, ctx->mods, pc);
+    LM_HIP(ctx, hipGetLastError());
     *out = d;
     return 0;
 }
 
-int launch_mul_plain(lumen_ctx *ctx, const u64 *ct, u64 *out, const tw_t *ptT, size_t words, uint32_t nl,
+int launch_mul_plain(lumen_ctx *ctx, const u64 *ct, u64 *out, const u64 *ptT, size_t words, uint32_t nl,
                      uint32_t ncts) {
     lm_prof_scope ps(ctx, "mul_plain", ncts);
     hipLaunchKernelGGL(k_mul_plain, dim3(4096), dim3(256), 0, ctx->stream, ct, out, ptT, words, ctx->logN, nl,
@@ -761,6 +803,7 @@ extern "C" uint32_t lumen_inner_sum_galois_elements(const lumen_ctx *ctx, uint32
 
 extern "C" int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint64_t *evk) {
     LM_CHECK(nullptr, ctx && evk, "lumen_load_galois_key: NULL argument");
+    LM_ENTER(ctx);
     const uint32_t N = ctx->N, L = ctx->L, K = ctx->K, LK = L + K;
     LM_CHECK(ctx, K >= 1, "parameters have no special primes: key switching unavailable");
     LM_CHECK(ctx, (gal_el & 1) && gal_el < 2ull * N, "Galois element %llu is not an odd residue mod 2N",
@@ -795,6 +838,7 @@ extern "C" int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint
         const uint64_t t2 = ((gal_el * t1 & mask) - 1) >> 1;
         index[i] = h_bitrev((uint32_t)t2, (int)ctx->logN);
     }
+    LM_SHARED_LOCK(ctx);
     lm_galois_key &gk = ctx->gkeys[gal_el];
     if (!gk.d_key) LM_HIP(ctx, hipMalloc((void **)&gk.d_key, words * 8));
     if (!gk.d_index) LM_HIP(ctx, hipMalloc((void **)&gk.d_index, (size_t)N * 4));
@@ -809,61 +853,66 @@ extern "C" int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint
 
 extern "C" int lumen_mul_plain(lumen_ctx *ctx, const lumen_set *in, const uint64_t *pt, lumen_set **out) {
     LM_CHECK(nullptr, ctx && in && pt && out, "lumen_mul_plain: NULL argument");
-    tw_t *ptT = nullptr;
+    LM_ENTER(ctx);
+    u64 *ptT = nullptr;
     if (int rc = upload_ptT(ctx, pt, in->nl, &ptT)) return rc;
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, in->count, in->nl, &o)) return rc;
+    lm_set_guard og(ctx, o);
     if (in->words)
-        if (int rc = launch_mul_plain(ctx, in->d, o->d, ptT, in->words, in->nl, in->count)) {
-            lumen_set_destroy(ctx, o);
-            return rc;
-        }
-    *out = o;
+        if (int rc = launch_mul_plain(ctx, in->d, o->d, ptT, in->words, in->nl, in->count)) return rc;
+    *out = og.release();
+    return 0;
+}
+
+static int check_inner_sum_level(lumen_ctx *ctx, const lumen_set *in, const char *what) {
+    // the hybrid key switch is tabulated for the top level (digits of K limbs over all L limbs): the
+    // path only ever calls InnerSum there (fhe/ligero.go:319-325 -- MulNew and InnerSum precede the
+    // rescale).  A lower-level set is refused, never silently mis-evaluated.
+    LM_CHECK(ctx, in->nl == ctx->L, "%s is implemented at the top level only (set has %u of %u limbs)", what,
+             in->nl, ctx->L);
     return 0;
 }
 
 extern "C" int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, lumen_set **out) {
     LM_CHECK(nullptr, ctx && in && out, "lumen_inner_sum: NULL argument");
-    LM_CHECK(ctx, in->nl == ctx->L, "InnerSum is implemented at the top level only (set has %u of %u limbs)",
-             in->nl, ctx->L);
+    LM_ENTER(ctx);
+    if (int rc = check_inner_sum_level(ctx, in, "InnerSum")) return rc;
     LM_CHECK(ctx, n && !(n & (n - 1)) && n <= ctx->N, "InnerSum length %u is not a power of two <= N", n);
     KsTables *tb = nullptr;
     if (int rc = get_tables(ctx, &tb)) return rc;
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, in->count, in->nl, &o)) return rc;
+    lm_set_guard og(ctx, o);
     if (in->words)
         LM_HIP(ctx, hipMemcpyAsync(o->d, in->d, in->words * 8, hipMemcpyDeviceToDevice, ctx->stream));
     const uint32_t Bmax = std::min<uint32_t>(ks_batch(), std::max(in->count, 1u));
     KsScratch s;
-    if (get_scratch(ctx, Bmax, tb->beta, &s)) {
-        lumen_set_destroy(ctx, o);
-        return 1;
-    }
+    if (get_scratch(ctx, Bmax, tb->beta, &s)) return 1;
     const size_t ctw = (size_t)2 * in->nl * ctx->N;
     for (uint32_t first = 0; first < in->count; first += Bmax) {
         const uint32_t B = std::min(Bmax, in->count - first);
-        if (int rc = inner_sum_batch(ctx, o->d + (size_t)first * ctw, B, n, tb, s)) {
-            lumen_set_destroy(ctx, o);
-            return rc;
-        }
+        if (int rc = inner_sum_batch(ctx, o->d + (size_t)first * ctw, B, n, tb, s)) return rc;
     }
-    *out = o;
+    *out = og.release();
     return 0;
 }
 
 extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *pt,
                                       uint32_t rows, lumen_set **out) {
     LM_CHECK(nullptr, ctx && matrix && pt && out, "lumen_matrix_inner_sum: NULL argument");
-    LM_CHECK(ctx, matrix->nl == ctx->L, "matrix must be at the top level (%u of %u limbs)", matrix->nl, ctx->L);
+    LM_ENTER(ctx);
+    if (int rc = check_inner_sum_level(ctx, matrix, "matrixInnerSumEval")) return rc;
     LM_CHECK(ctx, rows && !(rows & (rows - 1)) && rows <= ctx->N, "rows=%u is not a power of two <= N", rows);
     KsTables *tb = nullptr;
     if (int rc = get_tables(ctx, &tb)) return rc;
-    tw_t *ptT = nullptr;
+    u64 *ptT = nullptr;
     if (int rc = upload_ptT(ctx, pt, matrix->nl, &ptT)) return rc;
     const uint32_t N = ctx->N, L = ctx->L;
     const uint32_t target = std::min<uint32_t>(2, L);
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, matrix->count, target, &o)) return rc;
+    lm_set_guard og(ctx, o);
     const uint32_t Bmax = std::min<uint32_t>(ks_batch(), std::max(matrix->count, 1u));
     // the rescale to level 1 runs on groups of batches: one batch alone (2*B polynomials) does not
     // fill the 256 CUs in the kernels that take one workgroup per polynomial
@@ -873,40 +922,38 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
     u64 *acc = (u64 *)lm_scratch(ctx, "ks_acc", (size_t)group * ctw * 8);
     u64 *work = (u64 *)lm_scratch(ctx, "rescale_work", (size_t)group * ctw * 8);
     u64 *tbuf = (u64 *)lm_scratch(ctx, "rescale_t", (size_t)group * 2 * N * 8);
-    if (get_scratch(ctx, Bmax, tb->beta, &s[0], 0) || get_scratch(ctx, Bmax, tb->beta, &s[1], 1) || !acc || !work ||
-        !tbuf) {
-        lumen_set_destroy(ctx, o);
+    if (get_scratch(ctx, Bmax, tb->beta, &s[0], 0) || (ks_lanes() > 1 && get_scratch(ctx, Bmax, tb->beta, &s[1], 1)) ||
+        !acc || !work || !tbuf)
         return 1;
-    }
-    int rc = 0;
-    for (uint32_t g0 = 0; g0 < matrix->count && !rc; g0 += group) {
+    for (uint32_t g0 = 0; g0 < matrix->count; g0 += group) {
         const uint32_t gn = std::min(group, matrix->count - g0);
         // fork: the second lane starts after everything already enqueued on the main stream
-        LM_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        LM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        if (ks_lanes() > 1) {
+            LM_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            LM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        }
         uint32_t lane = 0;
-        for (uint32_t first = 0; first < gn && !rc; first += Bmax, lane = (lane + 1) % ks_lanes()) {
+        for (uint32_t first = 0; first < gn; first += Bmax, lane = (lane + 1) % ks_lanes()) {
             const uint32_t B = std::min(Bmax, gn - first);
             u64 *a = acc + (size_t)first * ctw;
             LaneGuard guard(ctx, (int)lane);
-            rc = launch_mul_plain(ctx, matrix->d + (size_t)(g0 + first) * ctw, a, ptT, (size_t)B * ctw, L, B); // ligero.go:319
-            if (!rc) rc = inner_sum_batch(ctx, a, B, rows, tb, s[lane]);                                        // ligero.go:325
+            if (int rc = launch_mul_plain(ctx, matrix->d + (size_t)(g0 + first) * ctw, a, ptT, (size_t)B * ctw, L, B)) // ligero.go:319
+                return rc;
+            if (int rc = inner_sum_batch(ctx, a, B, rows, tb, s[lane])) return rc; // ligero.go:325
         }
         // join: the rescale of the group needs both lanes
-        LM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-        LM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        if (!rc) { // ligero.go:331-333
-            if (L > target)
-                rc = lm_rescale_polys(ctx, acc, L, o->d + (size_t)g0 * octw, target, gn * 2, work, tbuf);
-            else
-                rc = hipMemcpyAsync(o->d + (size_t)g0 * octw, acc, (size_t)gn * ctw * 8, hipMemcpyDeviceToDevice,
-                                    ctx->stream) != hipSuccess;
+        if (ks_lanes() > 1) {
+            LM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            LM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
+        // ligero.go:331-333
+        if (L > target) {
+            if (int rc = lm_rescale_polys(ctx, acc, L, o->d + (size_t)g0 * octw, target, gn * 2, work, tbuf)) return rc;
+        } else {
+            LM_HIP(ctx, hipMemcpyAsync(o->d + (size_t)g0 * octw, acc, (size_t)gn * ctw * 8, hipMemcpyDeviceToDevice,
+                                       ctx->stream));
         }
     }
-    if (rc) {
-        lumen_set_destroy(ctx, o);
-        return rc;
-    }
-    *out = o;
+    *out = og.release();
     return 0;
 }

@@ -91,6 +91,7 @@ struct RescaleTables {
 };
 
 static int get_rescale_tables(lumen_ctx *ctx, RescaleTables **out) {
+    LM_SHARED_LOCK(ctx);
     auto it = ctx->ext.find("rescale_tables");
     if (it != ctx->ext.end()) {
         *out = static_cast<RescaleTables *>(it->second.get());
@@ -240,16 +241,18 @@ int lm_rescale_polys(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint
 
 extern "C" int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t target_limbs, lumen_set **out) {
     LM_CHECK(nullptr, ctx && in && out, "lumen_rescale: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, target_limbs >= 1 && target_limbs <= in->nl, "target_limbs %u out of range [1,%u]",
              target_limbs, in->nl);
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, in->count, target_limbs, &o)) return rc;
+    lm_set_guard og(ctx, o);
     const uint32_t N = ctx->N, nl = in->nl;
     const size_t in_ctw = (size_t)2 * nl * N, out_ctw = (size_t)2 * target_limbs * N;
     if (target_limbs == nl) { // already there: `for ct.Level() > 1` does nothing
         if (in->words)
             LM_HIP(ctx, hipMemcpyAsync(o->d, in->d, in->words * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
-        *out = o;
+        *out = og.release();
         return 0;
     }
     // chunk so that the full-stride work buffer stays <= ~2 GiB
@@ -259,24 +262,16 @@ extern "C" int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t targe
     u64 *work = nullptr;
     if (nl - target_limbs > 1) {
         work = (u64 *)lm_scratch(ctx, "rescale_work", (size_t)chunk * in_ctw * sizeof(u64));
-        if (!work) {
-            lumen_set_destroy(ctx, o);
-            return 1;
-        }
+        if (!work) return 1;
     }
     u64 *tbuf = (u64 *)lm_scratch(ctx, "rescale_t", (size_t)chunk * 2 * N * sizeof(u64));
-    if (!tbuf) {
-        lumen_set_destroy(ctx, o);
-        return 1;
-    }
+    if (!tbuf) return 1;
     for (uint32_t first = 0; first < in->count; first += chunk) {
         const uint32_t n = std::min(chunk, in->count - first);
         if (int rc = lm_rescale_polys(ctx, in->d + (size_t)first * in_ctw, nl, o->d + (size_t)first * out_ctw,
-                                      target_limbs, n * 2, work, tbuf)) {
-            lumen_set_destroy(ctx, o);
+                                      target_limbs, n * 2, work, tbuf))
             return rc;
-        }
     }
-    *out = o;
+    *out = og.release();
     return 0;
 }

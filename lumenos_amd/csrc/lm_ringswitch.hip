@@ -138,6 +138,7 @@ extern "C" uint32_t lumen_ringswitch_digits(const lumen_ctx *ctx, uint32_t base_
 extern "C" int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, uint32_t base_two_w,
                                          const uint64_t *key) {
     LM_CHECK(nullptr, ctx && key, "lumen_load_ringswitch_key: NULL argument");
+    LM_ENTER(ctx);
     LM_CHECK(ctx, ctx->K >= 1 && ctx->K <= 2, "ring switch needs 1 or 2 special primes");
     LM_CHECK(ctx, log_n_small <= ctx->logN && lm_logn_supported(log_n_small),
              "target ring degree 2^%u is not supported (need <= 2^%u and one of the instantiated sizes)",
@@ -177,7 +178,7 @@ extern "C" int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, u
     LM_HIP(ctx, hipMemcpy(sp->d_tw_small, f.data(), n * sizeof(tw_t), hipMemcpyHostToDevice));
     LM_HIP(ctx, hipMemcpy(sp->d_tw_small_inv, b.data(), n * sizeof(tw_t), hipMemcpyHostToDevice));
     sp->ninv_small = h_tw(h_invmod(n % q0, q0), q0);
-    ctx->ext["ringswitch_key"] = sp;
+    lm_ext_put(ctx, "ringswitch_key", sp);
     return 0;
 }
 
@@ -234,9 +235,10 @@ static int ring_switch_batch(lumen_ctx *ctx, RsKey *rk, const lm_ks_view &kv, co
 
 extern "C" int lumen_ring_switch(lumen_ctx *ctx, const lumen_set *in, uint64_t *out) {
     LM_CHECK(nullptr, ctx && in && out, "lumen_ring_switch: NULL argument");
-    auto it = ctx->ext.find("ringswitch_key");
-    LM_CHECK(ctx, it != ctx->ext.end(), "no ring-switch key loaded (lumen_load_ringswitch_key)");
-    RsKey *rk = static_cast<RsKey *>(it->second.get());
+    LM_ENTER(ctx);
+    const std::shared_ptr<RsKey> rk_hold = lm_ext_get<RsKey>(ctx, "ringswitch_key");
+    LM_CHECK(ctx, rk_hold, "no ring-switch key loaded (lumen_load_ringswitch_key)");
+    RsKey *rk = rk_hold.get();
     lm_ks_view kv;
     if (int rc = lm_ks_tables_view(ctx, &kv)) return rc;
     const uint32_t N = ctx->N, K = ctx->K, nt = 1 + K, nd = rk->nd, nl = in->nl;

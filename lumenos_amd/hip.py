@@ -15,7 +15,7 @@ _u64p = C.POINTER(C.c_uint64)
 _u32p = C.POINTER(C.c_uint32)
 _u8p = C.POINTER(C.c_uint8)
 LUMEN_MAX_LIMBS = 24
-LUMEN_ABI_VERSION = 1
+LUMEN_ABI_VERSION = 2
 
 
 class LumenError(RuntimeError):
@@ -41,6 +41,9 @@ _vpp = C.POINTER(C.c_void_p)
 SYMBOLS = {
     "lumen_ctx_create": (C.c_int, [C.POINTER(ParamsDesc), _vpp]),
     "lumen_ctx_destroy": (None, [_vp]),
+    "lumen_ctx_clone": (C.c_int, [_vp, _vpp]),
+    "lumen_host_alloc": (_vp, [C.c_size_t]),
+    "lumen_host_free": (None, [_vp]),
     "lumen_last_error": (C.c_char_p, [_vp]),
     "lumen_sync": (C.c_int, [_vp]),
     "lumen_mul_counter": (C.c_uint64, [_vp]),
@@ -109,6 +112,28 @@ def load(build=True):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def pinned_empty(shape):
+    """uint64 array in page-locked host memory (lumen_host_alloc): uploads/downloads of it are plain DMA."""
+    lib = load()
+    n = int(np.prod(shape))
+    p = lib.lumen_host_alloc(max(n, 1) * 8)
+    if not p:
+        raise LumenError(lib.lumen_last_error(None).decode())
+    buf = (C.c_uint64 * max(n, 1)).from_address(p)
+    arr = np.frombuffer(buf, dtype=np.uint64, count=n).reshape(shape)
+    _pinned_keep[arr.ctypes.data] = p
+    return arr
+
+
+def pinned_free(arr):
+    p = _pinned_keep.pop(arr.ctypes.data, None)
+    if p:
+        load().lumen_host_free(p)
+
+
+_pinned_keep = {}
 
 
 def _p64(a):
@@ -194,6 +219,18 @@ class Context:
         self.q, self.p, self.T = list(q), list(p), plaintext_modulus
 
     _pending_leaves = 0
+
+    def clone(self):
+        """ServerBFV.CopyNew: a context sharing this one's tables and keys, with its own streams and scratch."""
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_ctx_clone(self.h, C.byref(h)))
+        c = object.__new__(Context)
+        c.lib, c.h = self.lib, h
+        c.log_n, c.N, c.L, c.K = self.log_n, self.N, self.L, self.K
+        c.q, c.p, c.T = self.q, self.p, self.T
+        if hasattr(self, "_rs_logn"):
+            c._rs_logn = self._rs_logn
+        return c
 
     def _ck(self, rc):
         if rc:

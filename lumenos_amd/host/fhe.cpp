@@ -1,9 +1,13 @@
 // Host-side mirror of the reference's `fhe` package, server half (see fhe.hpp).
 #include "fhe.hpp"
 
+#include <cerrno>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
+
+#include <sys/random.h>
 
 namespace lumenos {
 namespace fhe {
@@ -160,13 +164,25 @@ static void host_ntt(std::vector<uint64_t> &a, uint64_t q, uint64_t psi, int log
 }
 
 // ------------------------------------------------------------------ ServerBFV
+void OsRandom(uint8_t *out, size_t n) {
+    size_t got = 0;
+    while (got < n) {
+        const ssize_t r = getrandom(out + got, n - got, 0);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            throw std::runtime_error("getrandom failed: no OS entropy for the encryption seed");
+        }
+        got += (size_t)r;
+    }
+}
+
 void ServerBFV::check(int rc, const char *what) const {
     if (rc) throw std::runtime_error(std::string(what) + ": " + lumen_last_error(ctx_));
 }
 
 ServerBFV::ServerBFV(core::PrimeField *plaintextField, const Parameters &params, std::vector<uint64_t> pk,
                      const std::map<uint64_t, std::vector<uint64_t>> &evk, int device)
-    : ptField_(plaintextField), params_(params), pk_(std::move(pk)), rng_(std::random_device{}()) {
+    : ptField_(plaintextField), params_(params), pk_(std::move(pk)) {
     lumen_params_desc d;
     memset(&d, 0, sizeof(d));
     d.abi_version = LUMEN_ABI_VERSION;
@@ -186,7 +202,10 @@ ServerBFV::ServerBFV(core::PrimeField *plaintextField, const Parameters &params,
     check(lumen_load_public_key(ctx_, pk_.data()), "lumen_load_public_key");
     check(lumen_encoder_set(ctx_, PowMod(core::PrimitiveRoot(params.T), (params.T - 1) / (2ull << params.LogN), params.T)),
           "lumen_encoder_set");
-    for (auto &b : enc_seed_) b = (uint8_t)rng_(); // the reference keys its PRNG from crypto/rand
+    // the reference keys Lattigo's sampler from crypto/rand: all encryption randomness (u, e0, e1 of every
+    // ciphertext this server makes) is the ChaCha20 stream under this key, so the key comes from the
+    // kernel's CSPRNG and from nowhere else -- no user-space generator in between
+    OsRandom(enc_seed_, sizeof(enc_seed_));
     // encoder tables ([LATTIGO-RECALL] bgv.Encoder: slot i of row 0 sits at 5^i, row 1 at -5^i)
     const uint64_t T = params.T, two_n = 2ull << params.LogN;
     psiT_ = PowMod(core::PrimitiveRoot(T), (T - 1) / two_n, T);
@@ -229,33 +248,19 @@ Plaintext ServerBFV::Encode(const std::vector<uint64_t> &values) const {
 }
 
 std::vector<uint64_t> ServerBFV::EncryptNew(const Plaintext &pt) {
-    // rlwe.Encryptor with a public key: (u*pk0 + e0 + pt, u*pk1 + e1), ternary u, Gaussian e (sigma 3.2)
-    const int N = params_.N(), L = (int)params_.Q.size(), nl = pt.Level + 1;
-    std::normal_distribution<double> gauss(0.0, 3.2);
-    std::vector<int64_t> u(N), e0(N), e1(N);
-    for (int k = 0; k < N; k++) {
-        u[k] = (int64_t)(rng_() % 3) - 1;
-        do e0[k] = (int64_t)std::llround(gauss(rng_)); while (std::llabs(e0[k]) > 19);
-        do e1[k] = (int64_t)std::llround(gauss(rng_)); while (std::llabs(e1[k]) > 19);
-    }
-    std::vector<uint64_t> ct((size_t)2 * nl * N);
-    auto lift = [&](const std::vector<int64_t> &c, int l) {
-        const uint64_t q = params_.Q[l];
-        std::vector<uint64_t> v(N);
-        for (int k = 0; k < N; k++) v[k] = c[k] >= 0 ? (uint64_t)c[k] : q - (uint64_t)(-c[k]);
-        host_ntt(v, q, params_.Psi[l], params_.LogN, false);
-        return v;
-    };
-    for (int l = 0; l < nl; l++) {
-        const uint64_t q = params_.Q[l];
-        const std::vector<uint64_t> un = lift(u, l), a = lift(e0, l), b = lift(e1, l);
-        for (int k = 0; k < N; k++) {
-            uint64_t c0 = (MulMod(un[k], pk_[(size_t)l * N + k], q) + a[k]) % q;
-            c0 = (c0 + pt.Value[(size_t)l * N + k]) % q;
-            ct[(size_t)l * N + k] = c0;
-            ct[(size_t)(nl + l) * N + k] = (MulMod(un[k], pk_[(size_t)(L + l) * N + k], q) + b[k]) % q;
-        }
-    }
+    // rlwe.Encryptor with a public key: (u*pk0 + e0 + pt, u*pk1 + e1), ternary u, Gaussian e (sigma 3.2).
+    // One ciphertext of the device encryptor: its samples are ChaCha20(enc_seed_, index), the same
+    // stream EncryptNewBatch / EncryptColumnsNew draw from, never a host-side generator.  The path only
+    // encrypts at MaxLevel (fhe/code.go:15-19: NewPlaintext(params, MaxLevel)).
+    const size_t N = (size_t)params_.N(), L = params_.Q.size();
+    if ((size_t)pt.Level + 1 != L) throw std::invalid_argument("EncryptNew: plaintext must be at MaxLevel");
+    lumen_set *set = nullptr;
+    check(lumen_encrypt_pk(ctx_, pt.Value.data(), 1, enc_seed_, enc_next_, &set), "lumen_encrypt_pk");
+    enc_next_ += 1;
+    std::vector<uint64_t> ct(2 * L * N);
+    const int rc = lumen_set_download(ctx_, set, 0, 1, ct.data());
+    lumen_set_destroy(ctx_, set);
+    check(rc, "lumen_set_download");
     return ct;
 }
 

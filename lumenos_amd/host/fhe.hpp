@@ -6,7 +6,6 @@
 #pragma once
 #include <map>
 #include <memory>
-#include <random>
 #include <string>
 #include <vector>
 
@@ -103,13 +102,19 @@ class ServerBFV {
     Parameters params_;
     std::vector<uint64_t> pk_;
     lumen_ctx *ctx_ = nullptr;
-    std::mt19937_64 rng_;
     uint64_t psiT_ = 0;
     std::vector<uint32_t> slot_index_;
     RingSwitchServer *rs_ = nullptr;
-    uint8_t enc_seed_[32] = {0};
+    uint8_t enc_seed_[32] = {0}; // ChaCha20 key of every sample this server draws: OsRandom, never a PRNG
     uint64_t enc_next_ = 0;
+
+  public:
+    // test hook: the seed must differ between instances (it is the only secret of the encryptor)
+    const uint8_t *EncSeedForTest() const { return enc_seed_; }
 };
+
+// n bytes from the kernel CSPRNG (getrandom(2)); throws if unavailable
+void OsRandom(uint8_t *out, size_t n);
 
 // fhe.RingSwitchServer (fhe/ring_switch.go:93-113)
 class RingSwitchServer {

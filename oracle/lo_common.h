@@ -253,6 +253,13 @@ int lo_calculate_queries(double security_bits, int rho_inv);
  * u32 limbs, u32 N} then raw little-endian limbs [poly][limb][N]. */
 size_t lo_ct_serialized_size(uint32_t nl, uint32_t N);
 void lo_ct_serialize(const uint64_t *ct, uint32_t nl, uint32_t N, uint8_t *out);
+/* processLeafParallel (fhe/ligero.go:126-183): rescale every encoded column to level 1, serialise, SHA-256.
+ * level1: [count][2][2][N]; digests: [count][32] */
+void lo_commit_leaves(const lo_params *p, const uint64_t *encoded, uint32_t count, uint32_t nl,
+                      uint64_t *level1, uint8_t *digests);
+/* matrixInnerSumEval (fhe/ligero.go:299-370) without the ring switch: out [cols][2][min(nl,2)][N] */
+void lo_matrix_inner_sum(const lo_params *p, const uint64_t *matrix, uint32_t cols, uint32_t nl,
+                         const uint64_t *pt, uint32_t rows, const uint64_t *const *evks, uint64_t *out);
 
 #ifdef __cplusplus
 }

@@ -76,3 +76,32 @@ def test_c_consumer_runs_on_the_gpu():
                            "-L" + os.path.dirname(lib), "-llumenos_hip", "-Wl,-rpath," + os.path.dirname(lib)])
     out = subprocess.check_output([exe]).decode()
     assert "abi_smoke OK" in out
+
+
+def _build_threads_rz():
+    import subprocess
+    from lumenos_amd import _build
+    from oracle import loader
+    lib = _build.build()
+    loader.build()
+    exe = os.path.join(ROOT, "tests", "cpp", "threads_rz")
+    cd, od = os.path.dirname(lib), os.path.join(ROOT, "oracle")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "threads_rz.c"), "-o", exe, "-L" + cd, "-llumenos_hip",
+                           "-L" + od, "-llumen_oracle", "-lpthread", f"-Wl,-rpath,{cd}:{od}"])
+    return exe
+
+
+def test_threads_program_builds():
+    assert os.path.exists(_build_threads_rz())
+
+
+@pytest.mark.gpu
+def test_two_threads_r_and_z():
+    """fhe/ligero.go:231-242 runs the R and Z inner products on two goroutines.  Two pthreads on ONE
+    context (serialised by the per-context lock) and on a context + its lumen_ctx_clone (concurrent,
+    shared keys) must both reproduce the serial results bit for bit; the clone survives its source."""
+    import subprocess
+    out = subprocess.run([_build_threads_rz()], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "threads_rz OK" in out.stdout

@@ -149,12 +149,16 @@ int lumen_merkle_build(lumen_ctx *ctx, const uint8_t *leaf_digests, uint32_t n_l
 
 /* ---- server-side witness encryption: server.EncryptNew per column
  * (cmd/server/main.go:199-208; fhe/bfv.go:13-58 holds the rlwe.Encryptor with the public key).
- * pk: [2][L][N], NTT domain.  plaintexts: host, [count][L][N] NTT-domain RNS plaintexts as
- * Encoder.Encode leaves them (m * T^-1 form), or NULL for encryptions of zero (fhe/code.go:21-25).
+ * pk: [2][L+K][N], NTT domain, over the whole basis QP -- rlwe.PublicKey.Value[0..1] are ringqp.Poly
+ * {Q, P}: flatten the Q limbs then the P limbs of each.  Encryption follows rlwe.Encryptor.encryptZeroPk
+ * [LATTIGO-RECALL]: u*pk_w + e_w is formed over QP and divided by P (ModDownQPtoQ), which leaves a
+ * fresh noise of a few units; fhe.Encode's unrescaled scalar multiplications need that.
+ * plaintexts: host, [count][L][N] NTT-domain RNS plaintexts as Encoder.Encode leaves them
+ * (m * T^-1 form), or NULL for encryptions of zero (fhe/code.go:21-25).
  * The reference's encryption is randomised; this one is deterministic in (seed, first_index + i):
  * ciphertext i draws its ternary u and Gaussian e0, e1 from ChaCha20(seed, first_index + i), so a
- * column encrypts to the same bits on whichever GPU it lands.  out: new set of `count` ciphertexts
- * at the top level. */
+ * column encrypts to the same bits on whichever GPU it lands.  The seed is key material: take it from
+ * the OS CSPRNG (crypto/rand).  out: new set of `count` ciphertexts at the top level. */
 int lumen_load_public_key(lumen_ctx *ctx, const uint64_t *pk);
 /* The same from the raw witness: Encoder.Encode + EncryptNew for `count` columns of `rows` slot
  * values each (cmd/server/main.go:188-208), host [count][rows]; 8*rows bytes cross PCIe per column

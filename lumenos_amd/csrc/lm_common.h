@@ -137,9 +137,12 @@ struct lumen_ctx {
 // first statement of every entry point that takes a context: serialise callers and select the
 // context's device for the calling thread (a fresh OS thread -- every cgo call may be one -- starts
 // on device 0)
+// ... and drop whatever error an earlier HIP call of this thread left behind (the host program's own
+// calls, a clean-up path): hipGetLastError() after a launch must speak about that launch
 #define LM_ENTER(ctx)                                             \
     std::lock_guard<std::recursive_mutex> lm_lock_((ctx)->mu);    \
-    (void)hipSetDevice((ctx)->device)
+    (void)hipSetDevice((ctx)->device);                            \
+    (void)hipGetLastError()
 // lookups and insertions in the shared maps (ext, gkeys, cached work lists)
 #define LM_SHARED_LOCK(ctx) std::lock_guard<std::recursive_mutex> lm_shlock_((ctx)->sh->mu)
 

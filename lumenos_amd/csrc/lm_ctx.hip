@@ -64,10 +64,6 @@ void *lm_stage(lumen_ctx *ctx, size_t bytes) {
     if (ctx->ev_stage) hipEventSynchronize(ctx->ev_stage); // the previous copy out of the buffer
     if (ctx->stage_cap < bytes) {
         if (ctx->stage_host) hipHostFree(ctx->stage_host);
-        for (int i = 0; i < 2; i++) {
-            if (ctx->io_host[i]) hipHostFree(ctx->io_host[i]);
-            if (ctx->ev_io[i]) hipEventDestroy(ctx->ev_io[i]);
-        }
         ctx->stage_host = nullptr, ctx->stage_cap = 0;
         if (hipHostMalloc(&ctx->stage_host, bytes, hipHostMallocDefault) != hipSuccess) {
             lm_fail(ctx, "hipHostMalloc(%zu) for host staging failed", bytes);

@@ -18,7 +18,7 @@
 // the LDS-resident limb transform, the pk products and the sums fused into the stores).
 #include <cstring>
 
-#include "lm_ntt_dev.h"
+#include "lm_ks_dev.h"
 
 struct enc_seed_t {
     u32 k[8];
@@ -105,89 +105,157 @@ __global__ __launch_bounds__(256) void k_sample_small(int8_t *__restrict__ small
     }
 }
 
-// One workgroup per (ciphertext c, limb l).  pk: [2][L][N] in Shoup form; pt: [count][L][N] or NULL;
-// out: [count][2][L][N].
-// mcoef/tinv: alternatively to `pt`, the plaintexts as coefficient vectors modulo T ([count][N],
-// the encoder's INTT output) with T^-1 mod q_l per limb: NTT is linear, so the scaled message rides in
-// the load of the e0 transform, NTT(e0 + m * T^-1), and costs no transform of its own.
+// rlwe.Encryptor.encryptZeroPk [LATTIGO-RECALL], for ciphertext c and polynomial w in {0, 1}:
+//     t_w   = u * pk_w + e_w                      over the whole basis QP (pk lives there)
+//     c_w   = ModDownQPtoQ(t_w) = (t_w,Q - [t_w]_P) * P^-1   (then + pt on c_0)
+// The division by P is what keeps fresh noise at a few units (delta_0 + delta_1 * s, delta in [0,1))
+// instead of |u*e_pk + e_0 + e_1*s| ~ 2^8; fhe.Encode multiplies noise by up to T/2 ten times without
+// a rescale, and the reference's 2048x1024 shape only fits its own LogQ heuristic with the small
+// noise (tools/noise_budget.py).
+// NTT is linear, so with U = NTT(u) the Q limbs never leave the NTT domain:
+//     c_w[l] = U*pk_w[l]*P^-1  -  NTT( lift_{P->q_l}([t_w]_P) - e_w ) * P^-1
+// Three kernels (per ciphertext (L+K) + 2K + 2L limb transforms instead of Lattigo's 3(L+K) + 2L):
+//   k_enc_u      one workgroup per (ciphertext, limb of QP): U = NTT(u); Q limbs store U*pk_w*P^-1
+//                into the output (P^-1 is folded into the key table), P limbs store U*pk_w into scratch
+//   (limb INTT with the y-scaling of the basis extension on the 2K scratch limbs, k_enc_add_e: + e_w,
+//    k_pack_v: the exact integer reconstruction, as in the key switch)
+//   k_enc_down   one workgroup per (ciphertext, w, Q limb): the lift fused into the load together with
+//                -e_w and, for w = 0, the message; NTT; combine with the product of k_enc_u in the store.
+// Without special primes (K = 0) there is nothing to divide by: c_w = U*pk_w + NTT(e_w).
 struct enc_tinv_t {
-    tw_t t[LM_MAX_LIMBS];
+    tw_t t[LM_MAX_LIMBS]; // message scale per Q limb: -P * T^-1 mod q_l (K > 0), T^-1 mod q_l (K = 0)
 };
+
+// pk: [2][LK][N] Shoup form (Q limbs times P^-1); out: [count][2][L][N]; upk: [count][2][K][N]
 template <int LOGN>
-__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_encrypt_ntt(const int8_t *__restrict__ small,
-                                                                     const tw_t *__restrict__ pk,
-                                                                     const u64 *__restrict__ pt,
-                                                                     const u64 *__restrict__ mcoef, enc_tinv_t tinv,
-                                                                     u64 *__restrict__ out, uint32_t count, uint32_t L,
-                                                                     lm_mods mods, const tw_t *__restrict__ tw_all) {
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_enc_u(const int8_t *__restrict__ small,
+                                                               const tw_t *__restrict__ pk, u64 *__restrict__ out,
+                                                               u64 *__restrict__ upk, uint32_t count, uint32_t L,
+                                                               uint32_t K, lm_mods mods,
+                                                               const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
     constexpr uint32_t N = 1u << LOGN;
-    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
-    const uint32_t l = blockIdx.x / count, c = blockIdx.x % count; // limb-major: one twiddle table hot per XCD
-    const lm_qc qc = lm_make_qc(mods.m[l]);
-    const tw_t *tw = tw_all + (size_t)l * N;
-    const int8_t *su = small + (size_t)c * 3 * N, *se0 = su + N, *se1 = su + 2 * N;
-    u64 *c0 = out + ((size_t)c * 2 * L + l) * N, *c1 = c0 + (size_t)L * N;
-    const u64 *p = pt ? pt + ((size_t)c * L + l) * N : nullptr;
-    const tw_t *pk0 = pk + (size_t)l * N, *pk1 = pk + (size_t)(L + l) * N;
-    auto lift = [&](int8_t v) { return v >= 0 ? (u64)v : qc.q - (u64)(-(int)v); };
-    { // c0 = NTT(e0 [+ m * T^-1]) [+ pt]
-        const u64 *mc = mcoef ? mcoef + (size_t)c * N : nullptr;
-        const tw_t ti = tinv.t[l];
-        auto ld = [&](uint32_t i) {
-            const u64 e = lift(se0[i]);
-            return mc ? lm_shoup3<true>(mc[i], ti.w, ti.wp, qc.nq, e) : e; // < 4q
-        };
-        auto st = [&](uint32_t i0, const u64 *v, int n) {
-            u64 r[8], pv[8];
-            if (p) lm_load_run(p, i0, pv, n);
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
+    const uint32_t t = blockIdx.x / count, c = blockIdx.x % count; // limb-major: one twiddle table hot per XCD
+    const lm_qc qc = lm_make_qc(mods.m[t]);
+    const int8_t *su = small + (size_t)c * 3 * N;
+    const tw_t *pk0 = pk + (size_t)t * N, *pk1 = pk + (size_t)(LK + t) * N;
+    u64 *o0, *o1;
+    if (t < L)
+        o0 = out + ((size_t)c * 2 * L + t) * N, o1 = o0 + (size_t)L * N;
+    else
+        o0 = upk + ((size_t)c * 2 * K + (t - L)) * N, o1 = o0 + (size_t)K * N;
+    auto ld = [&](uint32_t i) {
+        const int8_t v = su[i];
+        return v >= 0 ? (u64)v : qc.q - (u64)(-(int)v);
+    };
+    auto st = [&](uint32_t i0, const u64 *v, int n) {
+        u64 a[8], b[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (k < n) {
-                    r[k] = lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64);
-                    if (p) r[k] = lm_addmod(r[k], pv[k], qc.q);
-                }
-            lm_store_run(c0, i0, r, n);
-        };
-        lm_ntt_forward<LOGN>(sm, tw, qc, tid, nthreads, ld, st);
-    }
-    __syncthreads(); // LDS is reused by the next transform
-    {                // c1 = NTT(e1)
-        auto ld = [&](uint32_t i) { return lift(se1[i]); };
-        auto st = [&](uint32_t i0, const u64 *v, int n) {
-            u64 r[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (k < n) r[k] = lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64);
-            lm_store_run(c1, i0, r, n);
-        };
-        lm_ntt_forward<LOGN>(sm, tw, qc, tid, nthreads, ld, st);
-    }
-    __syncthreads();
-    { // c0 += NTT(u) * pk0, c1 += NTT(u) * pk1: a work item meets the coefficients it stored above
-        auto ld = [&](uint32_t i) { return lift(su[i]); };
-        auto st = [&](uint32_t i0, const u64 *v, int n) {
-            u64 a[8], b[8];
-            lm_load_run(c0, i0, a, n);
-            lm_load_run(c1, i0, b, n);
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (k < n) {
-                    const tw_t k0 = pk0[i0 + k], k1 = pk1[i0 + k];
-                    u64 x = lm_shoup3<false>(v[k], k0.w, k0.wp, qc.nq, a[k]); // a + u*pk0, lazily: < 4q
-                    u64 y = lm_shoup3<false>(v[k], k1.w, k1.wp, qc.nq, b[k]);
-                    a[k] = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
-                    b[k] = lm_csub(lm_csub(y, 2 * qc.q), qc.q);
-                }
-            lm_store_run(c0, i0, a, n);
-            lm_store_run(c1, i0, b, n);
-        };
-        lm_ntt_forward<LOGN>(sm, tw, qc, tid, nthreads, ld, st);
+        for (int k = 0; k < 8; k++)
+            if (k < n) {
+                const tw_t k0 = pk0[i0 + k], k1 = pk1[i0 + k];
+                const u64 x = lm_shoup3<false>(v[k], k0.w, k0.wp, qc.nq); // any v < 2^64 -> [0, 3q)
+                const u64 y = lm_shoup3<false>(v[k], k1.w, k1.wp, qc.nq);
+                a[k] = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
+                b[k] = lm_csub(lm_csub(y, 2 * qc.q), qc.q);
+            }
+        lm_store_run(o0, i0, a, n);
+        lm_store_run(o1, i0, b, n);
+    };
+    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);
+}
+
+// y[c][w][j][i] += e_w[c][i] * hat_j mod p_j  (the INTT before it scaled the products by hat_j =
+// (P/p_j)^-1 mod p_j, the source-side factor of the basis extension: the error has to follow)
+struct enc_hat_t {
+    tw_t t[4];
+};
+__global__ __launch_bounds__(256) void k_enc_add_e(u64 *__restrict__ upk, const int8_t *__restrict__ small,
+                                                   uint32_t count, uint32_t K, uint32_t L, uint32_t logN,
+                                                   lm_mods mods, enc_hat_t hat) {
+    const size_t total = ((size_t)count * 2 * K) << logN, N = (size_t)1 << logN;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = g & (N - 1), limb = g >> logN;
+        const uint32_t j = (uint32_t)(limb % K), w = (uint32_t)((limb / K) & 1);
+        const size_t c = limb / (2 * K);
+        const u64 p = mods.m[L + j].q;
+        const int8_t e = small[(c * 3 + 1 + w) * N + i];
+        const u64 el = e >= 0 ? (u64)e : p - (u64)(-(int)e);
+        upk[g] = lm_addmod(upk[g], lm_shoup(el, hat.t[j], p), p);
     }
 }
 
+// One workgroup per (ciphertext c, polynomial w, Q limb l).  HASP: the lift of the P limbs (packed by
+// k_pack_v) rides in the load with -e_w; otherwise the load is e_w itself.  mcoef: the plaintexts as
+// coefficient vectors modulo T ([count][N], the encoder's INTT output): NTT is linear, so the scaled
+// message rides in the load of the w = 0 transform and costs no transform of its own.  pt: the
+// plaintexts in the NTT domain ([count][L][N]), added in the store.  out holds U*pk_w(*P^-1) on entry.
+template <int LOGN, bool HASP>
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_enc_down(const int8_t *__restrict__ small,
+                                                                  const u64 *__restrict__ upk,
+                                                                  const bx_t *__restrict__ bxp,
+                                                                  const tw_t *__restrict__ pinv,
+                                                                  const u64 *__restrict__ pt,
+                                                                  const u64 *__restrict__ mcoef, enc_tinv_t tinv,
+                                                                  u64 *__restrict__ out, uint32_t count, uint32_t L,
+                                                                  uint32_t K, lm_mods mods,
+                                                                  const tw_t *__restrict__ tw_all) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm[];
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    const uint32_t l = blockIdx.x / (2 * count), cw = blockIdx.x % (2 * count), c = cw >> 1, w = cw & 1;
+    const lm_qc qc = lm_make_qc(mods.m[l]);
+    const int8_t *se = small + ((size_t)c * 3 + 1 + w) * N;
+    u64 *o = out + (((size_t)c * 2 + w) * L + l) * N;
+    const u64 *p = (pt && w == 0) ? pt + ((size_t)c * L + l) * N : nullptr;
+    const u64 *mc = (mcoef && w == 0) ? mcoef + (size_t)c * N : nullptr;
+    const tw_t ti = tinv.t[l];
+    bx_t bc;
+    const u64 *up0 = nullptr, *up1 = nullptr;
+    tw_t pi = ti;
+    if (HASP) {
+        bc = bxp[l];
+        up0 = upk + ((size_t)c * 2 + w) * K * N;
+        up1 = bc.ns == 2 ? up0 + N : up0;
+        pi = pinv[l];
+    }
+    auto ld = [&](uint32_t i) {
+        const int8_t e = se[i];
+        // HASP: -e - P*m*T^-1 (the store multiplies by -P^-1); else +e + m*T^-1.  Canonical: the lift
+        // below is already < 6q and the transform takes inputs below 7q.
+        u64 r = HASP ? (e > 0 ? qc.q - (u64)e : (u64)(-(int)e)) : (e >= 0 ? (u64)e : qc.q - (u64)(-(int)e));
+        if (mc) {
+            r = lm_shoup3<true>(mc[i], ti.w, ti.wp, qc.nq, r); // < 4q
+            r = lm_csub(lm_csub(r, 2 * qc.q), qc.q);
+            r = lm_csub(r, qc.q);
+        }
+        return HASP ? bx_apply(bc, up0[i], up1[i], qc) + r : r;
+    };
+    auto st = [&](uint32_t i0, const u64 *v, int n) {
+        u64 a[8], pv[8];
+        lm_load_run(o, i0, a, n);
+        if (p) lm_load_run(p, i0, pv, n);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < n) {
+                u64 x;
+                if (HASP) { // U*pk*P^-1 - NTT(lift - e) * P^-1
+                    x = a[k] + qc.q3 - lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq);
+                    x = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
+                } else { // U*pk + NTT(e)
+                    x = lm_addmod(a[k], lm_reduce_s(v[k], qc.q, qc.nq, qc.qinv64), qc.q);
+                }
+                if (p) x = lm_addmod(x, pv[k], qc.q);
+                a[k] = x;
+            }
+        lm_store_run(o, i0, a, n);
+    };
+    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)l * N, qc, tid, nthreads, ld, st);
+}
+
 struct PkTable {
-    tw_t *d_pk = nullptr; // [2][L][N] Shoup form
+    tw_t *d_pk = nullptr; // [2][L+K][N] Shoup form; Q limbs carry P^-1
     ~PkTable() {
         if (d_pk) hipFree(d_pk);
     }
@@ -196,15 +264,20 @@ struct PkTable {
 extern "C" int lumen_load_public_key(lumen_ctx *ctx, const uint64_t *pk) {
     LM_CHECK(nullptr, ctx && pk, "lumen_load_public_key: NULL argument");
     LM_ENTER(ctx);
-    const uint32_t N = ctx->N, L = ctx->L;
-    std::vector<tw_t> tab((size_t)2 * L * N);
+    const uint32_t N = ctx->N, L = ctx->L, K = ctx->K, LK = L + K;
+    std::vector<tw_t> tab((size_t)2 * LK * N);
     for (uint32_t w = 0; w < 2; w++)
-        for (uint32_t l = 0; l < L; l++) {
+        for (uint32_t l = 0; l < LK; l++) {
             const uint64_t q = ctx->mod[l];
+            uint64_t f = 1; // P^-1 mod q_l on the Q limbs: the products then leave k_enc_u already divided
+            if (l < L && K) {
+                for (uint32_t a = 0; a < K; a++) f = h_mulmod(f, ctx->mod[L + a] % q, q);
+                f = h_invmod(f, q);
+            }
             for (uint32_t k = 0; k < N; k++) {
-                const uint64_t x = pk[((size_t)w * L + l) * N + k];
+                const uint64_t x = pk[((size_t)w * LK + l) * N + k];
                 if (x >= q) return lm_fail(ctx, "public key residue out of range (poly %u limb %u)", w, l);
-                tab[((size_t)w * L + l) * N + k] = h_tw(x, q);
+                tab[((size_t)w * LK + l) * N + k] = h_tw(h_mulmod(x, f, q), q);
             }
         }
     auto sp = std::make_shared<PkTable>();
@@ -277,13 +350,56 @@ __global__ void k_scatter_slots(const u64 *__restrict__ values, u64 *__restrict_
 
 template <int LOGN>
 static int encrypt_t(lumen_ctx *ctx, const int8_t *small, const tw_t *pk, const u64 *pt, const u64 *mcoef,
-                     const enc_tinv_t &tinv, u64 *out, uint32_t count) {
+                     const enc_tinv_t &tinv, u64 *out, u64 *upk, uint32_t count) {
+    const uint32_t N = ctx->N, L = ctx->L, K = ctx->K, LK = L + K;
     const size_t lds = lm_fwd_lds(ctx->logN);
-    LM_LDS_ATTR(ctx, k_encrypt_ntt<LOGN>, lds);
-    lm_prof_scope ps(ctx, "encrypt_pk_ntt", (uint64_t)count * ctx->L * 3);
-    hipLaunchKernelGGL(k_encrypt_ntt<LOGN>, dim3(count * ctx->L), dim3(lm_fwd_threads(ctx->logN)), lds, ctx->stream,
-                       small, pk, pt, mcoef, tinv, out, count, ctx->L, ctx->mods, ctx->d_tw_fwd);
-    LM_HIP(ctx, hipGetLastError());
+    const uint32_t threads = lm_fwd_threads(ctx->logN);
+    {
+        LM_LDS_ATTR(ctx, k_enc_u<LOGN>, lds);
+        lm_prof_scope ps(ctx, "encrypt_u_ntt", (uint64_t)count * LK);
+        hipLaunchKernelGGL(k_enc_u<LOGN>, dim3(count * LK), dim3(threads), lds, ctx->stream, small, pk, out, upk, count,
+                           L, K, ctx->mods, ctx->d_tw_fwd);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    if (!K) {
+        LM_LDS_ATTR(ctx, (k_enc_down<LOGN, false>), lds);
+        lm_prof_scope ps(ctx, "encrypt_down_ntt", (uint64_t)count * 2 * L);
+        hipLaunchKernelGGL((k_enc_down<LOGN, false>), dim3(count * 2 * L), dim3(threads), lds, ctx->stream, small, upk,
+                           (const bx_t *)nullptr, (const tw_t *)nullptr, pt, mcoef, tinv, out, count, L, K, ctx->mods,
+                           ctx->d_tw_fwd);
+        LM_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+    lm_ks_view kv;
+    if (int rc = lm_ks_tables_view(ctx, &kv)) return rc;
+    // the P limbs of u*pk_w to the coefficient domain, scaled for the basis extension
+    lm_modmap mp;
+    mp.period = K;
+    for (uint32_t i = 0; i < LM_MAX_LIMBS; i++) mp.idx[i] = (uint8_t)(L + (i < K ? i : 0));
+    if (int rc = lm_launch_ntt_strided(ctx, upk, (size_t)K * N, upk, (size_t)K * N, count * 2, mp, true,
+                                       "encrypt_intt_p", kv.yscale))
+        return rc;
+    {
+        enc_hat_t hat;
+        memset(&hat, 0, sizeof(hat));
+        for (uint32_t j = 0; j < K; j++) { // yscale = N^-1 * hat_j: strip the N^-1
+            const uint64_t p = ctx->mod[L + j];
+            hat.t[j] = h_tw(h_mulmod(kv.yscale->t[L + j].w, N % p, p), p);
+        }
+        lm_prof_scope ps(ctx, "encrypt_add_e", count);
+        hipLaunchKernelGGL(k_enc_add_e, dim3(1024), dim3(256), 0, ctx->stream, upk, small, count, K, L, ctx->logN,
+                           ctx->mods, hat);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    if (K == 2)
+        if (int rc = lm_launch_pack_v(ctx, upk, (size_t)K * N, count * 2, 1u, K, L, K)) return rc;
+    {
+        LM_LDS_ATTR(ctx, (k_enc_down<LOGN, true>), lds);
+        lm_prof_scope ps(ctx, "encrypt_down_ntt", (uint64_t)count * 2 * L);
+        hipLaunchKernelGGL((k_enc_down<LOGN, true>), dim3(count * 2 * L), dim3(threads), lds, ctx->stream, small, upk,
+                           kv.d_bxp, kv.d_pinv, pt, mcoef, tinv, out, count, L, K, ctx->mods, ctx->d_tw_fwd);
+        LM_HIP(ctx, hipGetLastError());
+    }
     return 0;
 }
 
@@ -315,14 +431,26 @@ static int encrypt_impl(lumen_ctx *ctx, const uint64_t *plaintexts, const uint64
     memcpy(cdt.t, H_GAUSS_CDT, sizeof(cdt.t));
     enc_tinv_t tinv;
     memset(&tinv, 0, sizeof(tinv));
-    if (enc) tinv = enc->tinv;
+    if (enc) { // message scale riding in k_enc_down's load: T^-1, times -P when the store divides by -P
+        for (uint32_t l = 0; l < L; l++) {
+            const uint64_t q = ctx->mod[l];
+            uint64_t f = enc->tinv.t[l].w;
+            if (ctx->K) {
+                uint64_t P = 1;
+                for (uint32_t a = 0; a < ctx->K; a++) P = h_mulmod(P, ctx->mod[L + a] % q, q);
+                f = (q - h_mulmod(f, P, q)) % q;
+            }
+            tinv.t[l] = h_tw(f, q);
+        }
+    }
     // chunks bound the staging buffers (plaintexts: 8*L*N bytes per ciphertext)
     const uint32_t chunk = std::min<uint32_t>(count, 256);
     int8_t *small = (int8_t *)lm_scratch(ctx, "enc_small", (size_t)chunk * 3 * N);
     u64 *dpt = plaintexts ? (u64 *)lm_scratch(ctx, "enc_pt", (size_t)chunk * L * N * sizeof(u64)) : nullptr;
     u64 *dval = values ? (u64 *)lm_scratch(ctx, "enc_val", (size_t)chunk * rows * sizeof(u64)) : nullptr;
     u64 *dm = values ? (u64 *)lm_scratch(ctx, "enc_m", (size_t)chunk * N * sizeof(u64)) : nullptr;
-    if (!small || (plaintexts && !dpt) || (values && (!dval || !dm))) return 1;
+    u64 *upk = ctx->K ? (u64 *)lm_scratch(ctx, "enc_upk", (size_t)chunk * 2 * ctx->K * N * sizeof(u64)) : nullptr;
+    if (!small || (plaintexts && !dpt) || (values && (!dval || !dm)) || (ctx->K && !upk)) return 1;
     int rc = 0;
     for (uint32_t first = 0; first < count && !rc; first += chunk) {
         const uint32_t n = std::min(chunk, count - first);
@@ -356,7 +484,7 @@ static int encrypt_impl(lumen_ctx *ctx, const uint64_t *plaintexts, const uint64
         switch (ctx->logN) {
 #define LM_CASE(k) \
     case k:        \
-        rc = encrypt_t<k>(ctx, small, pkt->d_pk, dpt, dm, tinv, dst, n); \
+        rc = encrypt_t<k>(ctx, small, pkt->d_pk, dpt, dm, tinv, dst, upk, n); \
         break;
             LM_FOR_EACH_LOGN(LM_CASE)
 #undef LM_CASE

@@ -292,7 +292,7 @@ class Context:
 
     def load_public_key(self, pk):
         pk = np.ascontiguousarray(pk, dtype=np.uint64)
-        assert pk.shape == (2, self.L, self.N), pk.shape
+        assert pk.shape == (2, self.L + self.K, self.N), pk.shape  # over QP, as rlwe.PublicKey holds it
         self._ck(self.lib.lumen_load_public_key(self.h, _p64(pk)))
 
     def encrypt_pk(self, plaintexts, count, seed, first_index=0):

@@ -70,13 +70,16 @@ void lo_keygen_secret(const lo_params *p, lo_rng *r, uint64_t *sk) {
 }
 
 void lo_keygen_public(const lo_params *p, lo_rng *r, const uint64_t *sk, uint64_t *pk) {
-    uint32_t N = p->N, L = p->L;
+    /* [LATTIGO-RECALL] KeyGenerator.GenPublicKeyNew: an encryption of zero under sk over the WHOLE
+     * basis QP (rlwe.PublicKey.Value[0..1] are ringqp.Poly with a Q and a P part):
+     *     pk = (-a*s + e, a),   a uniform mod QP, e Gaussian.     pk: [2][L+K][N] */
+    uint32_t N = p->N, LK = p->L + p->K;
     int64_t *e = (int64_t *)malloc(N * sizeof(int64_t));
     uint64_t *en = (uint64_t *)malloc(N * sizeof(uint64_t));
     for (uint32_t k = 0; k < N; k++) e[k] = lo_sample_gaussian(r);
-    for (uint32_t i = 0; i < L; i++) {
+    for (uint32_t i = 0; i < LK; i++) {
         uint64_t q = p->mod[i];
-        uint64_t *b = pk + (size_t)i * N, *a = pk + (size_t)(L + i) * N;
+        uint64_t *b = pk + (size_t)i * N, *a = pk + (size_t)(LK + i) * N;
         small_to_limb(p, e, i, en);
         for (uint32_t k = 0; k < N; k++) {
             a[k] = rng_uniform(r, q);
@@ -153,33 +156,81 @@ void lo_encode(const lo_params *p, const uint64_t *values, uint32_t nvalues, uin
     free(m);
 }
 
+/* [LATTIGO-RECALL] rlwe.Encryptor.encryptZeroPk, the order of operations kept:
+ *   u <- Xs, extended to the limbs of Q_level and of P;  NTT on all of them
+ *   (c0, c1) = (u*pk0, u*pk1) over QP;  INTT on all limbs
+ *   c0 += e0, c1 += e1   (e <- Xe, extended to all limbs)
+ *   c_w = ModDownQPtoQ(c_w) = (c_w,Q - [c_w]_P) * P^-1   (floor convention, the float64-corrected
+ *                                                         basis extension of the key switch)
+ *   NTT on the Q limbs (BGV ciphertexts live in the NTT domain)
+ * The division by P leaves a fresh noise of delta0 + delta1*s, delta in [0, 1): a few units,
+ * not the |u*e_pk + e0 + e1*s| ~ 2^8 of an encryption in Q alone.  That difference decides whether
+ * fhe.Encode's unrescaled chain of scalar multiplications fits the reference's own Q heuristic
+ * (tools/noise_budget.py).  Without special primes (K = 0) there is nothing to
+ * divide by: c_w = u*pk_w + e_w in Q.
+ * u, e0, e1: N signed coefficients; pk: [2][L+K][N]; ct: [2][nl][N]. */
+void lo_encrypt_zero_pk(const lo_params *p, const int64_t *u, const int64_t *e0, const int64_t *e1,
+                        const uint64_t *pk, uint32_t nl, uint64_t *ct) {
+    const uint32_t N = p->N, L = p->L, K = p->K, LK = L + K, nt = nl + K;
+    uint64_t *un = (uint64_t *)malloc((size_t)N * 8);
+    uint64_t *c = (uint64_t *)malloc((size_t)2 * nt * N * 8); /* [2][nl + K][N], coefficient domain */
+    const int64_t *es[2] = {e0, e1};
+    for (uint32_t t = 0; t < nt; t++) {
+        const uint32_t mi = t < nl ? t : L + (t - nl);
+        const uint64_t q = p->mod[mi];
+        small_to_limb(p, u, mi, un);
+        for (uint32_t w = 0; w < 2; w++) {
+            uint64_t *o = c + ((size_t)w * nt + t) * N;
+            const uint64_t *k = pk + ((size_t)w * LK + mi) * N;
+            for (uint32_t i = 0; i < N; i++) o[i] = lo_mulmod(un[i], k[i], q);
+            lo_limb_intt(p, mi, o);
+            for (uint32_t i = 0; i < N; i++) {
+                const int64_t e = es[w][i];
+                o[i] = lo_addmod(o[i], e >= 0 ? (uint64_t)e % q : q - ((uint64_t)(-e) % q), q);
+            }
+        }
+    }
+    for (uint32_t w = 0; w < 2; w++) {
+        const uint64_t *srcs[LO_MAX_LIMBS];
+        for (uint32_t a = 0; a < K; a++) srcs[a] = c + ((size_t)w * nt + nl + a) * N;
+        for (uint32_t t = 0; t < nl; t++) {
+            const uint64_t q = p->mod[t];
+            uint64_t *o = ct + ((size_t)w * nl + t) * N;
+            const uint64_t *cq = c + ((size_t)w * nt + t) * N;
+            if (K) {
+                uint64_t pinv = 1;
+                for (uint32_t a = 0; a < K; a++) pinv = lo_mulmod(pinv, p->mod[L + a] % q, q);
+                pinv = lo_invmod(pinv, q);
+                lo_basis_extend(N, K, p->mod + L, srcs, q, un);
+                for (uint32_t i = 0; i < N; i++) o[i] = lo_mulmod(lo_submod(cq[i], un[i], q), pinv, q);
+            } else {
+                memcpy(o, cq, (size_t)N * 8);
+            }
+            lo_limb_ntt(p, t, o);
+        }
+    }
+    free(c);
+    free(un);
+}
+
 void lo_encrypt_pk(const lo_params *p, lo_rng *r, const uint64_t *pk, const uint64_t *pt,
                    uint32_t nl, uint64_t *ct) {
-    uint32_t N = p->N, L = p->L;
+    /* Encryptor.EncryptNew(pt): EncryptZero, then c0 += pt in the NTT domain */
+    uint32_t N = p->N;
     int64_t *u = (int64_t *)malloc(N * sizeof(int64_t));
     int64_t *e0 = (int64_t *)malloc(N * sizeof(int64_t));
     int64_t *e1 = (int64_t *)malloc(N * sizeof(int64_t));
-    uint64_t *un = (uint64_t *)malloc(N * sizeof(uint64_t));
-    uint64_t *en = (uint64_t *)malloc(N * sizeof(uint64_t));
     for (uint32_t k = 0; k < N; k++) {
         u[k] = (int64_t)(lo_rng_next(r) % 3) - 1;
         e0[k] = lo_sample_gaussian(r);
         e1[k] = lo_sample_gaussian(r);
     }
-    for (uint32_t l = 0; l < nl; l++) {
-        uint64_t q = p->mod[l];
-        small_to_limb(p, u, l, un);
-        uint64_t *c0 = ct + (size_t)l * N, *c1 = ct + (size_t)(nl + l) * N;
-        small_to_limb(p, e0, l, en);
-        for (uint32_t k = 0; k < N; k++) {
-            uint64_t v = lo_addmod(lo_mulmod(un[k], pk[(size_t)l * N + k], q), en[k], q);
-            c0[k] = pt ? lo_addmod(v, pt[(size_t)l * N + k], q) : v;
-        }
-        small_to_limb(p, e1, l, en);
-        for (uint32_t k = 0; k < N; k++)
-            c1[k] = lo_addmod(lo_mulmod(un[k], pk[(size_t)(L + l) * N + k], q), en[k], q);
-    }
-    free(en), free(un), free(e1), free(e0), free(u);
+    lo_encrypt_zero_pk(p, u, e0, e1, pk, nl, ct);
+    if (pt)
+        for (uint32_t l = 0; l < nl; l++)
+            for (uint32_t k = 0; k < N; k++)
+                ct[(size_t)l * N + k] = lo_addmod(ct[(size_t)l * N + k], pt[(size_t)l * N + k], p->mod[l]);
+    free(e1), free(e0), free(u);
 }
 
 /* T * (c0 + c1*s), coefficient domain, per limb: [nl][N] */

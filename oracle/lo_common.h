@@ -194,7 +194,7 @@ void lo_rng_seed(lo_rng *r, uint64_t seed);
 uint64_t lo_rng_next(lo_rng *r);
 /* sk: ternary, stored NTT-domain over all L+K limbs: [L+K][N] */
 void lo_keygen_secret(const lo_params *p, lo_rng *r, uint64_t *sk);
-/* pk: [2][L][N] */
+/* pk: [2][L+K][N] -- over the whole basis QP, as rlwe.PublicKey holds it */
 void lo_keygen_public(const lo_params *p, lo_rng *r, const uint64_t *sk, uint64_t *pk);
 /* key switching key from sk_in to sk_out */
 void lo_keygen_evk(const lo_params *p, lo_rng *r, const uint64_t *sk_in, const uint64_t *sk_out,

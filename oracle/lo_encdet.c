@@ -5,10 +5,9 @@
  * The reference encrypts the witness columns with server.EncryptNew (cmd/server/main.go:199-208):
  * Lattigo's rlwe.Encryptor under a public key, RANDOMISED (its PRNG is keyed from crypto/rand), so
  * there are no reference ciphertext bits to match.  What is restated here is the shape
- * [LATTIGO-RECALL: encryptZero with pk, no P-extension]
- *     c0 = u*pk0 + e0 + pt,  c1 = u*pk1 + e1,     u ternary (P(-1) = P(1) = 1/3), e0, e1 discrete
- *     Gaussians of sigma 3.2 truncated at 6 sigma (|e| <= 19), all three lifted to every limb and
- *     transformed,
+ * [LATTIGO-RECALL: encryptZeroPk -- encryption over QP, then division by P; lo_bgv.c lo_encrypt_zero_pk]
+ *     c_w = ModDown_P(u*pk_w + e_w),  c0 += pt,     u ternary (P(-1) = P(1) = 1/3), e0, e1 discrete
+ *     Gaussians of sigma 3.2 truncated at 6 sigma (|e| <= 19),
  * with a sampler of OUR OWN that the HIP path shares bit for bit, so that GPU and CPU ciphertexts can be
  * compared exactly and any sharding of the columns over GPUs yields the same ciphertexts:
  *     keystream(c, s) = ChaCha20(key = seed, nonce = LE64(c) || LE32(s), counter = 0, 1, ...)
@@ -21,6 +20,7 @@
 #include <string.h>
 
 #include "lo_common.h"
+#include "lo_internal.h"
 
 const uint64_t LO_GAUSS_CDT[19] = {
     0x0ff52b40a5917f1dull, 0x2e5a25d4bf0e400eull, 0x489ae26955b04bd6ull, 0x5d2bc20f621bf185ull,
@@ -54,33 +54,21 @@ void lo_det_small(const uint8_t seed[32], uint64_t index, uint32_t stream, uint3
     free(ks);
 }
 
-static void small8_to_limb(const lo_params *p, const int8_t *c, uint32_t mi, uint64_t *out) {
-    const uint64_t q = p->mod[mi];
-    for (uint32_t k = 0; k < p->N; k++) out[k] = c[k] >= 0 ? (uint64_t)c[k] : q - (uint64_t)(-c[k]);
-    lo_limb_ntt(p, mi, out);
-}
-
-/* ct: [2][nl][N]; pk: [2][L][N]; pt: [nl][N] or NULL */
+/* ct: [2][nl][N]; pk: [2][L+K][N]; pt: [nl][N] or NULL */
 void lo_encrypt_pk_det(const lo_params *p, const uint64_t *pk, const uint64_t *pt, uint32_t nl,
                        const uint8_t seed[32], uint64_t index, uint64_t *ct) {
-    const uint32_t N = p->N, L = p->L;
-    int8_t *u = (int8_t *)malloc(N), *e0 = (int8_t *)malloc(N), *e1 = (int8_t *)malloc(N);
-    uint64_t *un = (uint64_t *)malloc((size_t)N * 8), *en = (uint64_t *)malloc((size_t)N * 8);
-    lo_det_small(seed, index, 0, N, u);
-    lo_det_small(seed, index, 1, N, e0);
-    lo_det_small(seed, index, 2, N, e1);
-    for (uint32_t l = 0; l < nl; l++) {
-        const uint64_t q = p->mod[l];
-        uint64_t *c0 = ct + (size_t)l * N, *c1 = ct + (size_t)(nl + l) * N;
-        small8_to_limb(p, u, l, un);
-        small8_to_limb(p, e0, l, en);
-        for (uint32_t k = 0; k < N; k++) {
-            uint64_t v = lo_addmod(lo_mulmod(un[k], pk[(size_t)l * N + k], q), en[k], q);
-            c0[k] = pt ? lo_addmod(v, pt[(size_t)l * N + k], q) : v;
-        }
-        small8_to_limb(p, e1, l, en);
-        for (uint32_t k = 0; k < N; k++)
-            c1[k] = lo_addmod(lo_mulmod(un[k], pk[(size_t)(L + l) * N + k], q), en[k], q);
+    const uint32_t N = p->N;
+    int8_t *s8 = (int8_t *)malloc(N);
+    int64_t *v[3];
+    for (uint32_t st = 0; st < 3; st++) {
+        v[st] = (int64_t *)malloc((size_t)N * sizeof(int64_t));
+        lo_det_small(seed, index, st, N, s8);
+        for (uint32_t k = 0; k < N; k++) v[st][k] = s8[k];
     }
-    free(en), free(un), free(e1), free(e0), free(u);
+    lo_encrypt_zero_pk(p, v[0], v[1], v[2], pk, nl, ct);
+    if (pt)
+        for (uint32_t l = 0; l < nl; l++)
+            for (uint32_t k = 0; k < N; k++)
+                ct[(size_t)l * N + k] = lo_addmod(ct[(size_t)l * N + k], pt[(size_t)l * N + k], p->mod[l]);
+    free(v[2]), free(v[1]), free(v[0]), free(s8);
 }

@@ -114,8 +114,8 @@ void lo_automorphism_index(const lo_params *p, uint64_t gal_el, uint32_t *index)
 /* RNS basis extension of x (residues src[k][N] mod src_mod[k], coefficient
  * domain) to tgt_mod with the float64 correction of Lattigo's
  * reconstructRNS/multSum [LATTIGO-RECALL]. */
-static void basis_extend(uint32_t N, uint32_t ns, const uint64_t *src_mod,
-                         const uint64_t *const *src, uint64_t tgt_mod, uint64_t *out) {
+void lo_basis_extend(uint32_t N, uint32_t ns, const uint64_t *src_mod,
+                     const uint64_t *const *src, uint64_t tgt_mod, uint64_t *out) {
     if (ns == 1) { /* single-modulus digit: plain reduction */
         for (uint32_t k = 0; k < N; k++) out[k] = src[0][k] % tgt_mod;
         return;
@@ -169,7 +169,7 @@ static void key_switch(const lo_params *p, const uint64_t *c, uint32_t nl, const
             if (t >= lo && t < hi) {
                 dig = c + (size_t)t * N; /* own limb: original NTT values */
             } else {
-                basis_extend(N, ns, p->mod + lo, srcs, m, ext);
+                lo_basis_extend(N, ns, p->mod + lo, srcs, m, ext);
                 lo_limb_ntt(p, mi, ext);
                 dig = ext;
             }
@@ -196,7 +196,7 @@ static void key_switch(const lo_params *p, const uint64_t *c, uint32_t nl, const
             uint64_t q = p->mod[t], pinv = 1;
             for (uint32_t a = 0; a < K; a++) pinv = lo_mulmod(pinv, p->mod[L + a] % q, q);
             pinv = lo_invmod(pinv, q);
-            basis_extend(N, K, p->mod + L, srcs, q, ext);
+            lo_basis_extend(N, K, p->mod + L, srcs, q, ext);
             lo_limb_ntt(p, t, ext);
             const uint64_t *aq = accs[w] + (size_t)t * N;
             uint64_t *o = outs[w] + (size_t)t * N;

@@ -21,4 +21,12 @@ uint64_t lo_omega8_cubed(uint64_t T, const uint64_t *roots);
 /* gaussian / ternary samplers shared by the BGV harness */
 int64_t lo_sample_gaussian(lo_rng *r);
 
+/* RNS basis extension with Lattigo's float64 correction (lo_eval.c): residues src[a][N] mod
+ * src_mod[a], coefficient domain -> out[N] mod tgt_mod */
+void lo_basis_extend(uint32_t N, uint32_t ns, const uint64_t *src_mod, const uint64_t *const *src,
+                     uint64_t tgt_mod, uint64_t *out);
+/* rlwe.Encryptor.encryptZeroPk (lo_bgv.c): the one body behind lo_encrypt_pk and lo_encrypt_pk_det */
+void lo_encrypt_zero_pk(const lo_params *p, const int64_t *u, const int64_t *e0, const int64_t *e1,
+                        const uint64_t *pk, uint32_t nl, uint64_t *ct);
+
 #endif

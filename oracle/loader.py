@@ -338,7 +338,7 @@ class Params:
         return sk
 
     def keygen_public(self, sk):
-        pk = np.zeros((2, self.L, self.N), dtype=np.uint64)
+        pk = np.zeros((2, self.L + self.K, self.N), dtype=np.uint64)  # over QP, like rlwe.PublicKey
         self.o.lib.lo_keygen_public(self.h, self._r(), _p64(sk), _p64(pk))
         return pk
 

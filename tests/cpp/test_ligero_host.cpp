@@ -49,7 +49,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < L + K; i++) REQUIRE(lo_params_psi(op, i) == params.Psi[i], "psi mismatch at %d", i);
     lo_rng rng;
     lo_rng_seed(&rng, 42);
-    std::vector<uint64_t> sk((size_t)(L + K) * N), pk((size_t)2 * L * N);
+    std::vector<uint64_t> sk((size_t)(L + K) * N), pk((size_t)2 * (L + K) * N); // pk over QP
     lo_keygen_secret(op, &rng, sk.data());
     lo_keygen_public(op, &rng, sk.data(), pk.data());
     std::map<uint64_t, std::vector<uint64_t>> evk;

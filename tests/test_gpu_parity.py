@@ -605,7 +605,7 @@ def test_error_paths_report_status_and_message(oracle, small):
     from helpers import make_context
     fresh = make_context(P)
     fails(lambda: fresh.encrypt_pk(None, 1, seed, 0), "no public key")
-    fresh.load_public_key(np.zeros((2, P.L, P.N), dtype=np.uint64))
+    fresh.load_public_key(np.zeros((2, P.L + P.K, P.N), dtype=np.uint64))
     fails(lambda: fresh.encrypt_values(np.zeros((1, 8), dtype=np.uint64), seed, 0), "no encoder tables")
     fails(lambda: fresh.encoder_set(12345), "primitive 2N-th root")
     fresh.encoder_set(lp.encoder_psi(T_REF, P.logN))

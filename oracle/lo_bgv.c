@@ -261,31 +261,85 @@ void lo_decode_coeffs(const lo_params *p, const uint64_t *m, uint64_t scale, uin
     free(t);
 }
 
+/* centred reduction modulo T of the CRT lift of (y_0 .. y_{nl-1}), exact at any depth, in word
+ * arithmetic: Garner's mixed-radix digits  x = d_0 + d_1 q_0 + d_2 q_0 q_1 + ...  (0 <= d_i < q_i),
+ * x > Q/2 decided by comparing the digits with those of floor(Q/2) from the top, and
+ * x mod T = sum d_i * (q_0 ... q_{i-1} mod T).  [what Decryptor.DecryptNew + Encoder.Decode's
+ * RingQ -> RingT step computes with big integers] */
+typedef struct {
+    uint32_t nl;
+    uint64_t inv[LO_MAX_LIMBS][LO_MAX_LIMBS]; /* inv[i][j] = q_j^-1 mod q_i, j < i */
+    uint64_t radix_T[LO_MAX_LIMBS];           /* q_0 ... q_{i-1} mod T */
+    uint64_t q_mod_T;                         /* Q mod T */
+    uint64_t half[LO_MAX_LIMBS];              /* mixed-radix digits of floor(Q / 2) */
+} garner_t;
+
+static void garner_init(const lo_params *p, uint32_t nl, garner_t *g) {
+    const uint64_t T = p->T;
+    g->nl = nl;
+    uint64_t r = 1 % T;
+    for (uint32_t i = 0; i < nl; i++) {
+        g->radix_T[i] = r;
+        r = lo_mulmod(r, p->mod[i] % T, T);
+        for (uint32_t j = 0; j < i; j++) g->inv[i][j] = lo_invmod(p->mod[j] % p->mod[i], p->mod[i]);
+    }
+    g->q_mod_T = r;
+    /* floor(Q/2) = (Q - 1) / 2 (Q odd); Q - 1 has the digits (q_i - 1) in every position, and halving
+     * a mixed-radix number runs from the top digit down with the remainder carried as + q_i */
+    uint64_t carry = 0;
+    for (int i = (int)nl - 1; i >= 0; i--) {
+        lo_u128 v = (lo_u128)carry * p->mod[i] + (p->mod[i] - 1);
+        g->half[i] = (uint64_t)(v >> 1);
+        carry = (uint64_t)(v & 1);
+    }
+}
+
+static uint64_t garner_centred_mod_T(const lo_params *p, const garner_t *g, const uint64_t *y, size_t stride) {
+    uint64_t d[LO_MAX_LIMBS];
+    const uint32_t nl = g->nl;
+    const uint64_t T = p->T;
+    for (uint32_t i = 0; i < nl; i++) {
+        const uint64_t qi = p->mod[i];
+        uint64_t v = y[(size_t)i * stride] % qi;
+        for (uint32_t j = 0; j < i; j++) /* v = (v - d_j) / q_j mod q_i */
+            v = lo_mulmod(lo_submod(v, d[j] % qi, qi), g->inv[i][j], qi);
+        d[i] = v;
+    }
+    int above = 0; /* x > floor(Q/2) ? */
+    for (int i = (int)nl - 1; i >= 0; i--)
+        if (d[i] != g->half[i]) {
+            above = d[i] > g->half[i];
+            break;
+        }
+    uint64_t m = 0;
+    for (uint32_t i = 0; i < nl; i++) m = lo_addmod(m, lo_mulmod(d[i] % T, g->radix_T[i], T), T);
+    return above ? lo_submod(m, g->q_mod_T, T) : m;
+}
+
 int lo_decrypt_decode(const lo_params *p, const uint64_t *sk, const uint64_t *ct, uint32_t nl,
                       uint64_t scale, uint64_t *values, uint32_t nvalues) {
-    if (nl < 1 || nl > 2) return -1;
+    if (nl < 1 || nl > p->L) return -1;
     uint32_t N = p->N;
     uint64_t *ph = (uint64_t *)malloc((size_t)nl * N * sizeof(uint64_t));
     uint64_t *m = (uint64_t *)malloc(N * sizeof(uint64_t));
+    garner_t g;
+    garner_init(p, nl, &g);
     lo_decrypt_phase(p, sk, ct, nl, ph);
-    uint64_t q0 = p->mod[0], T = p->T;
-    if (nl == 1) {
-        for (uint32_t k = 0; k < N; k++) {
-            uint64_t y = ph[k];
-            m[k] = y > (q0 >> 1) ? (T - ((q0 - y) % T)) % T : y % T;
-        }
-    } else {
-        uint64_t q1 = p->mod[1], q0inv = lo_invmod(q0 % q1, q1);
-        lo_u128 Q = (lo_u128)q0 * q1;
-        for (uint32_t k = 0; k < N; k++) {
-            uint64_t y0 = ph[k], y1 = ph[N + k];
-            uint64_t h = lo_mulmod(lo_submod(y1, y0 % q1, q1), q0inv, q1);
-            lo_u128 y = (lo_u128)y0 + (lo_u128)q0 * h;
-            m[k] = y > (Q >> 1) ? (T - (uint64_t)((Q - y) % T)) % T : (uint64_t)(y % T);
-        }
-    }
+    for (uint32_t k = 0; k < N; k++) m[k] = garner_centred_mod_T(p, &g, ph + k, N);
     lo_decode_coeffs(p, m, scale, values, nvalues);
     free(m);
     free(ph);
     return 0;
+}
+
+/* the same for `count` ciphertexts ([count][2][nl][N] -> [count][nvalues]), columns in parallel */
+int lo_decrypt_decode_batch(const lo_params *p, const uint64_t *sk, const uint64_t *cts, uint32_t count,
+                            uint32_t nl, uint64_t scale, uint64_t *values, uint32_t nvalues) {
+    if (nl < 1 || nl > p->L) return -1;
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint32_t c = 0; c < count; c++)
+        if (lo_decrypt_decode(p, sk, cts + (size_t)c * 2 * nl * p->N, nl, scale, values + (size_t)c * nvalues, nvalues))
+            rc = -1;
+    return rc;
 }

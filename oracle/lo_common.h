@@ -219,6 +219,9 @@ void lo_encrypt_pk_det(const lo_params *p, const uint64_t *pk, const uint64_t *p
  * (mod T) to undo rescale scaling; pass 1 for none. */
 int lo_decrypt_decode(const lo_params *p, const uint64_t *sk, const uint64_t *ct, uint32_t nl,
                       uint64_t scale, uint64_t *values, uint32_t nvalues);
+/* `count` ciphertexts [count][2][nl][N] -> values [count][nvalues], any nl <= L (Garner mixed radix) */
+int lo_decrypt_decode_batch(const lo_params *p, const uint64_t *sk, const uint64_t *cts, uint32_t count,
+                            uint32_t nl, uint64_t scale, uint64_t *values, uint32_t nvalues);
 /* scale factor picked up by rescaling from nl_from limbs down to nl_to limbs:
  * prod q_dropped^-1 mod T */
 uint64_t lo_rescale_scale(const lo_params *p, uint32_t nl_from, uint32_t nl_to);

@@ -107,6 +107,7 @@ class Oracle:
             "lo_decrypt_phase": (None, [vp, u64p, u64p, C.c_uint32, u64p]),
             "lo_decode_coeffs": (None, [vp, u64p, C.c_uint64, u64p, C.c_uint32]),
             "lo_decrypt_decode": (C.c_int, [vp, u64p, u64p, C.c_uint32, C.c_uint64, u64p, C.c_uint32]),
+            "lo_decrypt_decode_batch": (C.c_int, [vp, u64p, u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, C.c_uint32]),
             "lo_rs_num_digits": (C.c_uint32, [vp, C.c_uint32]),
             "lo_rs_key_words": (C.c_size_t, [vp, C.c_uint32]),
             "lo_keygen_secret_small": (None, [vp, vp, C.c_uint32, C.POINTER(C.c_int64)]),
@@ -392,15 +393,26 @@ class Params:
         return out
 
     def decrypt(self, sk, ct, nvalues, scale=1):
-        """Decrypt at any level: levels <= 1 in C (128-bit CRT), deeper ones
-        by CRT in Python integers."""
+        """Decryptor.DecryptNew + Encoder.Decode at any level (exact CRT by Garner's mixed radix, in C)."""
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        out = np.zeros(nvalues, dtype=np.uint64)
+        rc = self.o.lib.lo_decrypt_decode(self.h, _p64(sk), _p64(ct), ct.shape[1], scale, _p64(out), nvalues)
+        assert rc == 0
+        return out
+
+    def decrypt_batch(self, sk, cts, nvalues, scale=1):
+        """[count][2][nl][N] -> [count][nvalues], columns in parallel (OpenMP)."""
+        cts = np.ascontiguousarray(cts, dtype=np.uint64)
+        out = np.zeros((cts.shape[0], nvalues), dtype=np.uint64)
+        rc = self.o.lib.lo_decrypt_decode_batch(self.h, _p64(sk), _p64(cts), cts.shape[0], cts.shape[2], scale,
+                                                _p64(out), nvalues)
+        assert rc == 0
+        return out
+
+    def decrypt_bigint(self, sk, ct, nvalues, scale=1):
+        """The same through Python integers (cross-check of the Garner path)."""
         ct = np.ascontiguousarray(ct, dtype=np.uint64)
         nl = ct.shape[1]
-        if nl <= 2:
-            out = np.zeros(nvalues, dtype=np.uint64)
-            rc = self.o.lib.lo_decrypt_decode(self.h, _p64(sk), _p64(ct), nl, scale, _p64(out), nvalues)
-            assert rc == 0
-            return out
         ph = self.decrypt_phase(sk, ct)
         mods = self.moduli[:nl]
         Q = 1

@@ -59,6 +59,14 @@ int main(int argc, char **argv) {
     }
     core::PrimeField ptField(params.PlaintextModulus(), cols * 2);
     fhe::ServerBFV server(&ptField, params, pk, evk);
+    {
+        // the encryptor's ChaCha20 key comes from the OS CSPRNG: two servers never share it, and it is
+        // not the all-zero default
+        fhe::ServerBFV other(&ptField, params, pk, {});
+        const uint8_t zero32[32] = {0};
+        REQUIRE(memcmp(server.EncSeedForTest(), other.EncSeedForTest(), 32) != 0, "two servers share an encryption seed");
+        REQUIRE(memcmp(server.EncSeedForTest(), zero32, 32) != 0, "encryption seed left at zero");
+    }
 
     // testLigeroE2E: witness, encryption of the batched columns by the server's own encoder/encryptor
     std::vector<uint64_t> matrix = core::RandomMatrixRowMajor(rows, cols, Modulus);
@@ -107,8 +115,9 @@ int main(int argc, char **argv) {
         return v;
     };
     std::vector<uint64_t> hR = proof.MatR.Download(), hZ = proof.MatZ.Download(), hQ = proof.QueriedCols.Download();
-    std::vector<uint64_t> MatR(cols), MatZ(cols);
-    for (int j = 0; j < cols; j++) MatR[j] = decrypt(hR, j, 1)[0], MatZ[j] = decrypt(hZ, j, 1)[0];
+    std::vector<uint64_t> MatR(cols), MatZ(cols); // slot 0 of every column (decodeSingleElement, ligero.go:428-434)
+    REQUIRE(!lo_decrypt_decode_batch(op, sk.data(), hR.data(), cols, 2, scale, MatR.data(), 1), "decrypt MatR");
+    REQUIRE(!lo_decrypt_decode_batch(op, sk.data(), hZ.data(), cols, 2, scale, MatZ.data(), 1), "decrypt MatZ");
 
     // ---- LigeroProveReference equality (ligero_test.go:164-174)
     core::Transcript refT("test");

@@ -46,12 +46,15 @@ def test_host_transcript_and_field_match_oracle(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(10, 512, 16, 6), (11, 2048, 64, 8), (12, 2048, 1024, 11)])
+@pytest.mark.parametrize("shape", [(10, 512, 16, 6), (11, 2048, 64, 8), (12, 2048, 1024, 10), (12, 4096, 2048, 11),
+                                   (13, 8192, 4096, 12)])
 def test_ligero_e2e_host_mirror(shape):
     """TestLigeroE2E twin: Commit + Prove through the C++ mirror on the GPU, decrypt + Verify with the
-    oracle.  rows == N on the middle shape (row-swap rotation); the last is the reference's own test
-    shape (2048x1024, LogN=12) with one limb more than the heuristic gives (4 of its 2048 encoded
-    columns overflow the noise budget otherwise -- see DESIGN.md)."""
-    res = subprocess.run([build_binary()] + [str(x) for x in shape], capture_output=True, text=True, timeout=900)
+    oracle.  The two small shapes take more limbs than the heuristic gives (a 16- or 64-column Encode is
+    as deep in scalar multiplications per limb as the heuristic assumes only from 1024 columns up); the
+    last three are the reference's own test shape (2048x1024, LogN=12: TestLigeroE2E / TestLigeroPPD,
+    BASELINE config 1) and BASELINE configs B and 3 (4096x2048, 8192x4096 with rows = N) on exactly the
+    chain fhe.GenerateBGVParamsForNTT derives: L = 10 / 11 / 12."""
+    res = subprocess.run([build_binary()] + [str(x) for x in shape], capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "PASS TestLigeroE2E" in res.stdout

@@ -1,0 +1,203 @@
+"""GPU: the reference's own test shapes and every BASELINE.json configuration AT THEIR OWN PARAMETERS
+(the Q chain is the one fhe.GenerateBGVParamsForNTT derives, fhe/bfv.go:121-188 -- no extra limb).
+
+* TestEncode (fhe/code_test.go:14-123): 2048 x 1024, LogN = 13, L = 10; every one of the 2048 encoded
+  columns is decrypted at the top level and compared with core.Encode of the plain rows.
+* Commit at TestLigeroE2E's shape (fhe/ligero_test.go:24, 2048 x 1024, LogN = 12, L = 10): every leaf
+  ciphertext (level 1) decrypts to the plain encoding.
+* BASELINE configs A (1024, 12), B (2048, 12), C (4096, 13), D (4096, 14): matrixInnerSumEval with
+  rows = N on real keys, rescale + leaf digests, witness encryption / decryption and the ring switch to
+  LogN = 10, bit for bit against the oracle.
+
+Fresh noise matters here: fhe.Encode never rescales, and the 1024-column shapes only fit the
+heuristic's chain because rlwe.Encryptor divides its encryptions of zero by P
+(tools/noise_budget.py).
+"""
+import numpy as np
+import pytest
+
+from helpers import T_REF, make_context, random_cts
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {  # name -> (cols, LogN, expected Q-chain length: results/baseline/server/bench_*.txt:16)
+    "A_2048x1024": (1024, 12, 10),
+    "B_4096x2048": (2048, 12, 11),
+    "C_8192x4096": (4096, 13, 12),
+    "D_16384x4096": (4096, 14, 12),
+}
+
+
+def reference_params(oracle, cols, log_n):
+    from lumenos_amd import params as lp
+    from oracle.loader import Params
+    B = lp.generate_bgv_params_for_ntt(cols, log_n)
+    P = Params.from_moduli(oracle, log_n, B.q, B.p, B.T)
+    assert P.psi == B.psi
+    return P
+
+
+def psi_T(log_n):
+    from lumenos_amd import params as lp
+    return pow(lp.primitive_root(T_REF), (T_REF - 1) // (2 << log_n), T_REF)
+
+
+def encrypt_witness(oracle, P, ctx, rows, cols, seed_byte):
+    """RandomMatrixRowMajor (core/utils.go:46-82) + Encoder.Encode + EncryptNew of every column, on the device."""
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    ctx.load_public_key(pk)
+    ctx.encoder_set(psi_T(P.logN))
+    matrix = oracle.witness(rows, cols, T_REF)  # [rows][cols]
+    columns = np.ascontiguousarray(matrix.T)    # column j = batched slots of ciphertext j
+    seed = np.full(32, seed_byte, dtype=np.uint8)
+    cts = ctx.encrypt_values(columns, seed, 0)
+    zero = ctx.encrypt_pk(None, 1, seed, cols).download()[0]  # the one Enc(0) of fhe/code.go:15-22
+    return sk, matrix, cts, zero
+
+
+def plain_encode_rows(oracle, matrix, rho, roots):
+    """core.Encode of every row (core/code.go:3-23): [rows][cols*rho]."""
+    return np.stack([oracle.plain_encode(matrix[i], rho, T_REF, roots) for i in range(matrix.shape[0])])
+
+
+def test_encode_reference_shape_every_column_decrypts(oracle):
+    """TestEncode at its real shape: 2048 x 1024, LogN = 13, the heuristic's L = 10, all 2048 columns."""
+    rows, cols, rho, log_n = 2048, 1024, 2, 13
+    P = reference_params(oracle, cols, log_n)
+    assert (P.L, P.K) == (10, 2)
+    P.seed(1313)
+    ctx = make_context(P)
+    sk, matrix, cts, zero = encrypt_witness(oracle, P, ctx, rows, cols, 0x13)
+    S = cols * rho
+    roots = oracle.field_roots(T_REF, S)
+    ctx.field_set(roots)
+    enc = ctx.encode(cts, zero, rho)
+    assert enc.count == S and enc.nl == P.L  # Encode does not rescale
+    assert ctx.mul_counter() == 9217         # ct x scalar multiplications of S = 2048
+    want = plain_encode_rows(oracle, matrix, rho, roots)  # [rows][S]
+    bad = []
+    for first in range(0, S, 256):
+        got = P.decrypt_batch(sk, enc.download(first, 256), rows)  # Decryptor + Encoder.Decode at level 9
+        for j in range(256):
+            if not np.array_equal(got[j], want[:, first + j]):
+                bad.append(first + j)
+    assert not bad, f"{len(bad)} of {S} encoded columns do not decrypt to core.Encode: {bad[:16]}"
+    ctx.close()
+
+
+def test_commit_reference_shape_every_leaf_decrypts(oracle):
+    """TestLigeroE2E's shape (2048 x 1024, LogN = 12) with the heuristic's L = 10: Encode, rescale to level 1
+    (processLeafParallel, fhe/ligero.go:145-155) and decrypt ALL 2048 leaf ciphertexts -- the verifier only
+    ever opens 309 of them.  GPU decrypt (lumen_decrypt) and the oracle's agree."""
+    rows, cols, rho, log_n = 2048, 1024, 2, 12
+    P = reference_params(oracle, cols, log_n)
+    assert (P.L, P.K) == (10, 2)
+    P.seed(1212)
+    ctx = make_context(P)
+    sk, matrix, cts, zero = encrypt_witness(oracle, P, ctx, rows, cols, 0x12)
+    S = cols * rho
+    roots = oracle.field_roots(T_REF, S)
+    ctx.field_set(roots)
+    lvl1 = ctx.rescale(ctx.encode(cts, zero, rho), 2)
+    scale = P.rescale_scale(P.L, 2)
+    ctx.load_secret_key(sk)
+    got = ctx.decrypt(lvl1, rows, scale)  # [S][rows]
+    want = plain_encode_rows(oracle, matrix, rho, roots)
+    bad = [j for j in range(S) if not np.array_equal(got[j], want[:, j])]
+    assert not bad, f"{len(bad)} of {S} leaves do not decrypt to core.Encode: {bad[:16]}"
+    sample = np.array([0, 1, 777, 1023, 1024, 2047])
+    assert np.array_equal(P.decrypt_batch(sk, lvl1.download()[sample], rows, scale), got[sample])
+    ctx.close()
+
+
+@pytest.fixture(scope="module", params=list(CONFIGS))
+def config(request, oracle):
+    cols, log_n, chain = CONFIGS[request.param]
+    P = reference_params(oracle, cols, log_n)
+    assert (P.L, P.K) == (chain, 2), (request.param, P.L)
+    P.seed(1000 + log_n * 10 + chain)
+    ctx = make_context(P)
+    sk = P.keygen_secret()
+    yield request.param, P, ctx, sk
+    ctx.close()
+
+
+def test_config_rescale_and_leaf_digests(oracle, config):
+    _, P, ctx, _ = config
+    cts = random_cts(P, 3, P.L, seed=3)
+    lvl1 = ctx.rescale(ctx.upload(cts), 2)
+    ref_l1, ref_dig = P.commit_leaves(cts)
+    assert np.array_equal(lvl1.download(), ref_l1)
+    assert np.array_equal(ctx.leaf_digests(lvl1), ref_dig)
+    for target in (1, P.L - 1):  # one step and all the way down
+        ref = cts[0]
+        while ref.shape[1] > target:
+            ref = P.rescale(ref)
+        assert np.array_equal(ctx.rescale(ctx.upload(cts[:1]), target).download()[0], ref), target
+
+
+def test_config_encrypt_values_and_decrypt(oracle, config):
+    """lumen_encrypt_values == the oracle's deterministic encryptor (QP + division by P), bit for bit,
+    at the configuration's ring degree and chain; the ciphertexts decrypt to the columns."""
+    _, P, ctx, sk = config
+    pk = P.keygen_public(sk)
+    ctx.load_public_key(pk)
+    ctx.encoder_set(psi_T(P.logN))
+    rng = np.random.default_rng(P.logN)
+    rows = P.N
+    vals = rng.integers(0, T_REF, size=(2, rows), dtype=np.uint64)
+    seed = rng.integers(0, 256, size=32, dtype=np.uint8)
+    got = ctx.encrypt_values(vals, seed, 5).download()
+    for i in range(2):
+        assert np.array_equal(got[i], P.encrypt_det(pk, P.encode(vals[i]), seed, 5 + i)), i
+        assert np.array_equal(P.decrypt(sk, got[i], rows), vals[i])
+    # fresh noise of an encryption over QP divided by P: delta0 + delta1*s, a few units
+    ph = P.decrypt_phase(sk, ctx.encrypt_pk(None, 1, seed, 99).download()[0][:, :1])  # limb 0 is enough
+    q0 = P.moduli[0]
+    e = ph[0].astype(object) * pow(T_REF % q0, -1, q0) % q0  # undo the *T of lo_decrypt_phase
+    e = np.array([int(x) if x < q0 // 2 else int(x) - q0 for x in e], dtype=np.float64)
+    assert np.abs(e).max() < 8 * np.sqrt((1 + 2 * P.N / 3) / 12) + 8, np.abs(e).max()
+
+
+def test_config_matrix_inner_sum_rows_eq_slots(oracle, config):
+    """matrixInnerSumEval with rows = N (configs B, C, D; A has rows = N/2): log2(N/2) column rotations and
+    the row swap on real keys, then Rescale to level 1 -- bit-exact, and slot 0 decrypts to <r, column>."""
+    name, P, ctx, sk = config
+    rows = P.N // 2 if name.startswith("A_") else P.N
+    pk = P.keygen_public(sk)
+    gl = P.inner_sum_galois_elements(rows)
+    assert len(gl) == P.logN - (1 if rows < P.N else 0)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    rng = np.random.default_rng(4)
+    col = rng.integers(0, T_REF, size=rows, dtype=np.uint64)
+    r = rng.integers(0, 2**63, size=rows, dtype=np.uint64)  # raw u64, as Prove samples it (ligero.go:202-203)
+    cts = P.encrypt(pk, P.encode(col))[None]
+    pt = P.encode(r)
+    out = ctx.matrix_inner_sum(ctx.upload(cts), pt, rows)
+    got = out.download()
+    assert np.array_equal(got, P.matrix_inner_sum(cts, pt, rows, evks))
+    want = int(np.sum(col.astype(object) * (r.astype(object) % T_REF)) % T_REF)
+    scale = P.rescale_scale(P.L, 2)
+    assert int(P.decrypt(sk, got[0], 1, scale)[0]) == want
+    ctx.load_secret_key(sk)
+    ctx.encoder_set(psi_T(P.logN))
+    assert int(ctx.decrypt(out, 1, scale)[0, 0]) == want
+
+
+def test_config_ring_switch_to_logn10(oracle, config):
+    """BASELINE config 5's tail at every configuration's ring degree: RingSwitchNew into LogN = 10 on level-1
+    ciphertexts, bit-exact vs the oracle, with the sub-ring decryption contract."""
+    _, P, ctx, sk = config
+    pk = P.keygen_public(sk)
+    rng = np.random.default_rng(9)
+    cts = np.stack([P.rescale_to_level1(P.encrypt(pk, P.encode(rng.integers(0, T_REF, size=P.N, dtype=np.uint64))))
+                    for _ in range(2)])
+    sk_small = P.keygen_secret_small(10)
+    key = P.keygen_ringswitch(sk, sk_small, 10)
+    ctx.load_ringswitch_key(10, key)
+    got = ctx.ring_switch(ctx.upload(cts))
+    for c in range(2):
+        assert np.array_equal(got[c], P.ring_switch(cts[c], key, 10)), c

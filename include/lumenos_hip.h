@@ -131,7 +131,24 @@ int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *
  * 271-273, 331-333).  out is a new set with target_limbs limbs. */
 int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t target_limbs, lumen_set **out);
 
-/* ---- leaves of the commitment: serialize every ciphertext of a level-1 set
+/* ---- rlwe.Ciphertext.WriteTo (fhe/ligero.go:156-157 for the leaves, 664-691 for the proof) as a layout
+ *     head | for each polynomial: poly_head | for each limb: limb_head | N little-endian u64
+ * The three byte strings are cut by the host out of ONE real ct.WriteTo of a ciphertext of the level
+ * being serialised (INTEGRATION.md section 4 shows the Go code): they hold Lattigo's MetaData block
+ * and the length words of structs.Vector / structs.Matrix, which this library does not hard-code.
+ * All three NULL: back to the default, the recalled framing with an empty MetaData block
+ * (head = LE64(2), poly_head = LE64(limbs), limb_head = LE64(N)) -- NOT byte-compatible with a
+ * Lattigo peer; a root computed under it verifies only against this library's own serialisation.
+ * lumen_ct_serialize writes ciphertexts [first, first+n) of a set in the current format into `out`
+ * (n * lumen_ct_serialized_size(ctx, limbs) bytes): the proof marshaller, and the shim's one-off
+ * byte comparison with Lattigo before it trusts device digests. */
+int lumen_leaf_format_set(lumen_ctx *ctx, const uint8_t *head, uint32_t head_len, const uint8_t *poly_head,
+                          uint32_t poly_head_len, const uint8_t *limb_head, uint32_t limb_head_len);
+size_t lumen_ct_serialized_size(lumen_ctx *ctx, uint32_t num_limbs);
+int lumen_ct_serialize(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n, uint8_t *out,
+                       size_t cap);
+
+/* ---- leaves of the commitment: serialize every ciphertext of a level-1 set in the current format
  * (ct.WriteTo, fhe/ligero.go:156-157) and SHA-256 it (core/tree.go:96-111).
  * digests: host buffer, count*32 bytes. */
 int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8_t *digests);

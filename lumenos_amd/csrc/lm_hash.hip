@@ -1,15 +1,18 @@
 // Commit tail: leaf serialisation + SHA-256 on the device, Merkle levels and
 // paths on the host (core/tree.go:39-163; fhe/ligero.go:156-157).
 //
-// Leaf bytes.  The reference hashes rlwe.Ciphertext.WriteTo output; that
-// format lives in the un-vendored Lattigo module and its header bytes are
-// unknown offline.  Until it is pinned
-// from a Go host the leaf layout is a documented stand-in: a 16-byte header
-// {u32 'LMCT', u32 polys = 2, u32 limbs, u32 N} followed by the raw
-// little-endian residues [poly][limb][N] -- i.e. exactly the ciphertext's HBM
-// image, so the hash streams straight from the rescaled set.  In drop-in use
-// the Go shim keeps hashing Lattigo's own bytes on the host until then
-// (INTEGRATION.md).
+// Leaf bytes.  The reference hashes rlwe.Ciphertext.WriteTo output.  Lattigo is not vendored
+// (SURVEY Appendix A.7), so the byte layout is a PARAMETER of the context, not a constant of the
+// kernel: a serialised ciphertext is
+//     head | for each polynomial: poly_head | for each limb: limb_head | N little-endian u64
+// with the three byte strings handed over by lumen_leaf_format_set.  Raw little-endian limbs are
+// what every Lattigo release has written; the strings in between (MetaData, the length words of
+// structs.Vector / structs.Matrix) are cut by the Go shim out of ONE real ct.WriteTo, and
+// lumen_ct_serialize lets it compare bytes before trusting a digest.
+// Without a format the recalled framing is used [LATTIGO-RECALL: Element.WriteTo = MetaData, then
+// structs.Vector[ring.Poly] (u64 count), each Poly a structs.Matrix[uint64] (u64 rows, per row u64
+// length + data)] with an EMPTY MetaData block: head = LE64(2), poly_head = LE64(limbs),
+// limb_head = LE64(N).
 #include <cstring>
 
 #include "lm_common.h"
@@ -62,59 +65,191 @@ __host__ __device__ __forceinline__ u32 bswap32(u32 x) {
     return (x >> 24) | ((x >> 8) & 0xff00) | ((x << 8) & 0xff0000) | (x << 24);
 }
 
-// one thread per leaf: the leaf is the 16-byte header followed by `words` u64
-__global__ void k_leaf_sha256(const u64 *__restrict__ set, size_t words, uint32_t count, uint32_t nl,
-                              uint32_t N, uint8_t *__restrict__ digests) {
-    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (leaf >= count) return;
-    const u64 *d = set + (size_t)leaf * words;
-    u32 h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-    u32 w[16];
-    // block 0: header + first 6 words
-    w[0] = bswap32(0x54434d4cu), w[1] = bswap32(2u), w[2] = bswap32(nl), w[3] = bswap32(N);
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const u64 x = d[k];
-        w[4 + 2 * k] = bswap32((u32)x);
-        w[5 + 2 * k] = bswap32((u32)(x >> 32));
+#define LM_FMT_HEAD_MAX 1024
+#define LM_FMT_SEG_MAX 64
+struct leaf_fmt_t { // device image of the serialisation format
+    u32 head_len, poly_len, limb_len, pad;
+    uint8_t head[LM_FMT_HEAD_MAX];
+    uint8_t poly[LM_FMT_SEG_MAX];
+    uint8_t limb[LM_FMT_SEG_MAX];
+};
+struct LeafFormat { // host copy, shared by a context and its clones (ext["leaf_format"])
+    std::vector<uint8_t> head, poly, limb;
+};
+
+static void put_le64(std::vector<uint8_t> &v, uint64_t x) {
+    for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i)));
+}
+// the format in force for ciphertexts of nl limbs
+static LeafFormat current_format(lumen_ctx *ctx, uint32_t nl) {
+    if (auto f = lm_ext_get<LeafFormat>(ctx, "leaf_format")) return *f;
+    LeafFormat d; // recalled framing, empty MetaData (see the header of this file)
+    put_le64(d.head, 2);
+    put_le64(d.poly, nl);
+    put_le64(d.limb, ctx->N);
+    return d;
+}
+static size_t serialized_size(const LeafFormat &f, uint32_t nl, uint32_t N) {
+    return f.head.size() + 2 * (f.poly.size() + (size_t)nl * (f.limb.size() + (size_t)N * 8));
+}
+static int upload_format(lumen_ctx *ctx, const LeafFormat &f, const char *slot, const leaf_fmt_t **out) {
+    leaf_fmt_t *h = (leaf_fmt_t *)lm_stage(ctx, sizeof(leaf_fmt_t));
+    leaf_fmt_t *d = (leaf_fmt_t *)lm_scratch(ctx, slot, sizeof(leaf_fmt_t));
+    if (!h || !d) return 1;
+    memset(h, 0, sizeof(*h));
+    h->head_len = (u32)f.head.size(), h->poly_len = (u32)f.poly.size(), h->limb_len = (u32)f.limb.size();
+    memcpy(h->head, f.head.data(), f.head.size());
+    memcpy(h->poly, f.poly.data(), f.poly.size());
+    memcpy(h->limb, f.limb.data(), f.limb.size());
+    LM_HIP(ctx, hipMemcpyAsync(d, h, sizeof(leaf_fmt_t), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+    *out = d;
+    return 0;
+}
+
+extern "C" int lumen_leaf_format_set(lumen_ctx *ctx, const uint8_t *head, uint32_t head_len, const uint8_t *poly_head,
+                                     uint32_t poly_head_len, const uint8_t *limb_head, uint32_t limb_head_len) {
+    LM_CHECK(nullptr, ctx, "lumen_leaf_format_set: NULL ctx");
+    LM_ENTER(ctx);
+    if (!head && !poly_head && !limb_head) { // back to the default framing
+        LM_SHARED_LOCK(ctx);
+        ctx->ext.erase("leaf_format");
+        return 0;
     }
-    sha256_compress(h, w, c_k256);
-    const size_t full = (words - 6) / 8; // whole 64-byte blocks after the first
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(d + 6);
-    for (size_t b = 0; b < full; b++) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const ulonglong2 v = p[b * 4 + k];
-            w[4 * k] = bswap32((u32)v.x), w[4 * k + 1] = bswap32((u32)(v.x >> 32));
-            w[4 * k + 2] = bswap32((u32)v.y), w[4 * k + 3] = bswap32((u32)(v.y >> 32));
+    LM_CHECK(ctx, (head || !head_len) && (poly_head || !poly_head_len) && (limb_head || !limb_head_len),
+             "lumen_leaf_format_set: NULL segment with a non-zero length");
+    LM_CHECK(ctx, head_len <= LM_FMT_HEAD_MAX && poly_head_len <= LM_FMT_SEG_MAX && limb_head_len <= LM_FMT_SEG_MAX,
+             "serialisation format too long: head %u (max %u), poly %u, limb %u (max %u)", head_len, LM_FMT_HEAD_MAX,
+             poly_head_len, limb_head_len, LM_FMT_SEG_MAX);
+    auto f = std::make_shared<LeafFormat>();
+    f->head.assign(head, head + head_len);
+    f->poly.assign(poly_head, poly_head + poly_head_len);
+    f->limb.assign(limb_head, limb_head + limb_head_len);
+    lm_ext_put(ctx, "leaf_format", f);
+    return 0;
+}
+
+extern "C" size_t lumen_ct_serialized_size(lumen_ctx *ctx, uint32_t num_limbs) {
+    if (!ctx) return 0;
+    LM_ENTER(ctx);
+    return serialized_size(current_format(ctx, num_limbs), num_limbs, ctx->N);
+}
+
+extern "C" int lumen_ct_serialize(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n, uint8_t *out,
+                                  size_t cap) {
+    LM_CHECK(nullptr, ctx && set && (out || !n), "lumen_ct_serialize: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, (uint64_t)first + n <= set->count, "range [%u,%u) exceeds set of %u", first, first + n, set->count);
+    const LeafFormat f = current_format(ctx, set->nl);
+    const uint32_t N = ctx->N, nl = set->nl;
+    const size_t each = serialized_size(f, nl, N), ctw = (size_t)2 * nl * N;
+    LM_CHECK(ctx, cap >= each * n, "output buffer too small: need %zu bytes", each * n);
+    std::vector<uint64_t> host(ctw);
+    for (uint32_t i = 0; i < n; i++) {
+        if (int rc = lumen_set_download(ctx, set, first + i, 1, host.data())) return rc;
+        uint8_t *o = out + (size_t)i * each;
+        memcpy(o, f.head.data(), f.head.size()), o += f.head.size();
+        for (uint32_t k = 0; k < 2; k++) {
+            memcpy(o, f.poly.data(), f.poly.size()), o += f.poly.size();
+            for (uint32_t l = 0; l < nl; l++) {
+                memcpy(o, f.limb.data(), f.limb.size()), o += f.limb.size();
+                memcpy(o, host.data() + ((size_t)k * nl + l) * N, (size_t)N * 8), o += (size_t)N * 8; // little-endian host
+            }
         }
+    }
+    return 0;
+}
+
+// One thread per leaf streams its ciphertext through SHA-256.  The format's byte strings have any
+// length, so the limb data sits at an arbitrary byte offset of the 64-byte blocks: words are
+// assembled with a byte shift (r bytes pending in `acc`) and staged in an LDS block buffer
+// ([word][thread]: conflict-free) whose fill index is dynamic but wave-uniform -- every leaf of a
+// launch has the same layout, so no branch diverges.
+struct sha_stream {
+    u32 h[8];
+    u32 *blk;  // this thread's column of the LDS block buffer, stride 64 words
+    u32 fillw; // whole words in the block
+    u32 acc, r; // r pending bytes, left-aligned in acc
+    u64 total;  // message bytes so far
+    __device__ __forceinline__ void flush() {
+        u32 w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = blk[i * 64];
         sha256_compress(h, w, c_k256);
+        fillw = 0;
     }
-    // tail: the remaining (words - 6) % 8 words (2 for every ring degree >= 8), padding, length
-    const size_t rem = (words - 6) % 8;
-    const u64 *tail = d + 6 + full * 8;
-#pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = 0;
-    for (size_t k = 0; k < rem; k++) {
-        const u64 x = tail[k];
-        w[2 * k] = bswap32((u32)x);
-        w[2 * k + 1] = bswap32((u32)(x >> 32));
+    __device__ __forceinline__ void word(u32 W) { // 4 message bytes, big-endian in W
+        if (r) {
+            const u32 sh = 8 * r;
+            blk[fillw * 64] = acc | (W >> sh);
+            acc = W << (32 - sh);
+        } else {
+            blk[fillw * 64] = W;
+        }
+        total += 4;
+        if (++fillw == 16) flush();
     }
-    w[2 * rem] = 0x80000000u;
-    const u64 bits = ((u64)words * 8 + 16) * 8;
-    if (rem > 6) { // no room for the length: one more block
-        sha256_compress(h, w, c_k256);
-#pragma unroll
-        for (int k = 0; k < 16; k++) w[k] = 0;
+    __device__ __forceinline__ void byte(u32 b) {
+        acc |= b << (24 - 8 * r);
+        total += 1;
+        if (++r == 4) {
+            blk[fillw * 64] = acc;
+            acc = 0, r = 0;
+            if (++fillw == 16) flush();
+        }
     }
-    w[14] = (u32)(bits >> 32);
-    w[15] = (u32)bits;
-    sha256_compress(h, w, c_k256);
-    uint8_t *o = digests + (size_t)leaf * 32;
+    __device__ __forceinline__ void bytes(const uint8_t *p, u32 n) {
+        for (u32 i = 0; i < n; i++) byte(p[i]);
+    }
+    __device__ __forceinline__ void finish(uint8_t *out) {
+        const u64 bits = total * 8;
+        byte(0x80);
+        while (r) byte(0);
+        while (fillw != 14) { // zero words up to the length field (wraps through a flush if needed)
+            blk[fillw * 64] = 0;
+            if (++fillw == 16) flush();
+        }
+        blk[14 * 64] = (u32)(bits >> 32), blk[15 * 64] = (u32)bits;
+        flush();
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        o[4 * k] = (uint8_t)(h[k] >> 24), o[4 * k + 1] = (uint8_t)(h[k] >> 16);
-        o[4 * k + 2] = (uint8_t)(h[k] >> 8), o[4 * k + 3] = (uint8_t)h[k];
+        for (int k = 0; k < 8; k++) {
+            out[4 * k] = (uint8_t)(h[k] >> 24), out[4 * k + 1] = (uint8_t)(h[k] >> 16);
+            out[4 * k + 2] = (uint8_t)(h[k] >> 8), out[4 * k + 3] = (uint8_t)h[k];
+        }
+    }
+};
+
+__global__ __launch_bounds__(64) void k_leaf_sha256(const u64 *__restrict__ set, uint32_t count, uint32_t nl,
+                                                    uint32_t N, const leaf_fmt_t *__restrict__ fmt,
+                                                    uint8_t *__restrict__ digests) {
+    __shared__ u32 lds[16 * 64];
+    const uint32_t leaf = blockIdx.x * 64 + threadIdx.x;
+    // threads past the end hash the last leaf again (never stored): the loops stay wave-uniform
+    const u64 *d = set + (size_t)(leaf < count ? leaf : count - 1) * 2 * nl * N;
+    sha_stream s;
+    const u32 iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.h[i] = iv[i];
+    s.blk = lds + threadIdx.x, s.fillw = 0, s.acc = 0, s.r = 0, s.total = 0;
+    s.bytes(fmt->head, fmt->head_len);
+    for (uint32_t k = 0; k < 2; k++) {
+        s.bytes(fmt->poly, fmt->poly_len);
+        for (uint32_t l = 0; l < nl; l++) {
+            s.bytes(fmt->limb, fmt->limb_len);
+            const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(d + ((size_t)k * nl + l) * N);
+            for (uint32_t i = 0; i < N / 2; i++) {
+                const ulonglong2 v = p[i];
+                s.word(bswap32((u32)v.x)), s.word(bswap32((u32)(v.x >> 32)));
+                s.word(bswap32((u32)v.y)), s.word(bswap32((u32)(v.y >> 32)));
+            }
+        }
+    }
+    uint8_t dg[32];
+    s.finish(dg);
+    if (leaf < count) {
+        uint8_t *o = digests + (size_t)leaf * 32;
+#pragma unroll
+        for (int k = 0; k < 32; k++) o[k] = dg[k];
     }
 }
 
@@ -122,14 +257,13 @@ extern "C" int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8
     LM_CHECK(nullptr, ctx && level1 && digests, "lumen_leaf_digests: NULL argument");
     LM_ENTER(ctx);
     if (!level1->count) return 0;
-    const size_t words = (size_t)2 * level1->nl * ctx->N;
-    LM_CHECK(ctx, words >= 6, "ciphertext too small to serialise");
     uint8_t *dd = (uint8_t *)lm_scratch(ctx, "digests", (size_t)level1->count * 32);
-    if (!dd) return 1;
+    const leaf_fmt_t *fmt = nullptr;
+    if (!dd || upload_format(ctx, current_format(ctx, level1->nl), "leaf_fmt", &fmt)) return 1;
     {
         lm_prof_scope ps(ctx, "leaf_sha256", level1->count);
-        hipLaunchKernelGGL(k_leaf_sha256, dim3((level1->count + 63) / 64), dim3(64), 0, ctx->stream,
-                           level1->d, words, level1->count, level1->nl, ctx->N, dd);
+        hipLaunchKernelGGL(k_leaf_sha256, dim3((level1->count + 63) / 64), dim3(64), 0, ctx->stream, level1->d,
+                           level1->count, level1->nl, ctx->N, fmt, dd);
         LM_HIP(ctx, hipGetLastError());
     }
     LM_HIP(ctx, hipMemcpyAsync(digests, dd, (size_t)level1->count * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -142,17 +276,17 @@ extern "C" int lumen_leaf_digests_begin(lumen_ctx *ctx, const lumen_set *level1)
     LM_ENTER(ctx);
     LM_CHECK(ctx, !ctx->aux_digests, "a lumen_leaf_digests_begin job is already in flight");
     if (!level1->count) return 0;
-    const size_t words = (size_t)2 * level1->nl * ctx->N, bytes = (size_t)level1->count * 32;
-    LM_CHECK(ctx, words >= 6, "ciphertext too small to serialise");
+    const size_t bytes = (size_t)level1->count * 32;
     uint8_t *dd = (uint8_t *)lm_scratch(ctx, "digests_async", bytes);
-    if (!dd) return 1;
+    const leaf_fmt_t *fmt = nullptr;
+    if (!dd || upload_format(ctx, current_format(ctx, level1->nl), "leaf_fmt_async", &fmt)) return 1;
     if (ctx->aux_host_cap < bytes) {
         if (ctx->aux_host) LM_HIP(ctx, hipHostFree(ctx->aux_host));
         ctx->aux_host = nullptr, ctx->aux_host_cap = 0;
         LM_HIP(ctx, hipHostMalloc((void **)&ctx->aux_host, bytes, hipHostMallocDefault));
         ctx->aux_host_cap = bytes;
     }
-    // the side stream starts behind the work that produces `level1`
+    // the side stream starts behind the work that produces `level1` (and the upload of the format)
     LM_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
     LM_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_aux, 0));
     {
@@ -161,7 +295,7 @@ extern "C" int lumen_leaf_digests_begin(lumen_ctx *ctx, const lumen_set *level1)
         {
             lm_prof_scope ps(ctx, "leaf_sha256", level1->count);
             hipLaunchKernelGGL(k_leaf_sha256, dim3((level1->count + 63) / 64), dim3(64), 0, ctx->stream_aux,
-                               level1->d, words, level1->count, level1->nl, ctx->N, dd);
+                               level1->d, level1->count, level1->nl, ctx->N, fmt, dd);
         }
         ctx->stream = main_stream;
         LM_HIP(ctx, hipGetLastError());

@@ -62,6 +62,9 @@ SYMBOLS = {
     "lumen_encode": (C.c_int, [_vp, _vp, _u64p, C.c_uint32, _vpp]),
     "lumen_encode_shard": (C.c_int, [_vp, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, _vpp, _u32p, _u32p]),
     "lumen_rescale": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
+    "lumen_leaf_format_set": (C.c_int, [_vp, _u8p, C.c_uint32, _u8p, C.c_uint32, _u8p, C.c_uint32]),
+    "lumen_ct_serialized_size": (C.c_size_t, [_vp, C.c_uint32]),
+    "lumen_ct_serialize": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _u8p, C.c_size_t]),
     "lumen_leaf_digests": (C.c_int, [_vp, _vp, _u8p]),
     "lumen_load_public_key": (C.c_int, [_vp, _u64p]),
     "lumen_encrypt_pk": (C.c_int, [_vp, _u64p, C.c_uint32, _u8p, C.c_uint64, C.POINTER(_vp)]),
@@ -284,6 +287,26 @@ class Context:
         h = C.c_void_p()
         self._ck(self.lib.lumen_rescale(self.h, s.h, target_limbs, C.byref(h)))
         return DeviceSet(self, h)
+
+    def leaf_format_set(self, head=None, poly_head=None, limb_head=None):
+        """Serialisation layout of a ciphertext (lumen_leaf_format_set); all None: the default framing."""
+        if head is None and poly_head is None and limb_head is None:
+            self._ck(self.lib.lumen_leaf_format_set(self.h, None, 0, None, 0, None, 0))
+            return
+        segs = [np.frombuffer(bytes(x or b""), dtype=np.uint8).copy() if len(x or b"") else np.zeros(1, np.uint8)
+                for x in (head, poly_head, limb_head)]
+        lens = [len(x or b"") for x in (head, poly_head, limb_head)]
+        self._ck(self.lib.lumen_leaf_format_set(self.h, segs[0].ctypes.data_as(_u8p), lens[0],
+                                                segs[1].ctypes.data_as(_u8p), lens[1],
+                                                segs[2].ctypes.data_as(_u8p), lens[2]))
+
+    def ct_serialize(self, s, first=0, n=None):
+        """bytes of ciphertexts [first, first+n) of `s` in the current format, concatenated"""
+        n = s.count - first if n is None else n
+        each = self.lib.lumen_ct_serialized_size(self.h, s.nl)
+        out = np.zeros(max(each * n, 1), dtype=np.uint8)
+        self._ck(self.lib.lumen_ct_serialize(self.h, s.h, first, n, out.ctypes.data_as(_u8p), each * n))
+        return out[:each * n].tobytes()
 
     def leaf_digests(self, s):
         out = np.zeros((s.count, 32), dtype=np.uint8)

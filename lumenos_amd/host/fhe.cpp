@@ -97,7 +97,7 @@ std::vector<uint64_t> Parameters::GaloisElementsForInnerSum(int batch, int n) co
 Ciphertexts &Ciphertexts::operator=(Ciphertexts &&o) noexcept {
     if (this != &o) {
         if (set_) lumen_set_destroy(ctx_, set_);
-        ctx_ = o.ctx_, set_ = o.set_;
+        ctx_ = o.ctx_, set_ = o.set_, Meta = o.Meta;
         o.ctx_ = nullptr, o.set_ = nullptr;
     }
     return *this;
@@ -126,6 +126,50 @@ std::vector<uint64_t> Ciphertexts::Download() const {
     if (count && lumen_set_download(ctx_, set_, 0, count, out.data()))
         throw std::runtime_error(std::string("lumen_set_download: ") + lumen_last_error(ctx_));
     return out;
+}
+
+uint64_t RescaledScale(const Parameters &params, uint64_t scale, int fromLevel, int toLevel) {
+    // Evaluator.Rescale: Scale <- Scale * q_l^-1 mod T for the dropped limb l
+    const uint64_t T = params.T;
+    for (int l = fromLevel; l > toLevel; l--) scale = MulMod(scale % T, InvMod(params.Q[(size_t)l] % T, T), T);
+    return scale;
+}
+
+static std::string hex_float(uint64_t v) {
+    // big.Float.Text('x', 32) of an integer below 2^64: 0x1.<32 hex digits>p+EE
+    if (!v) return "0x0p+00";
+    int e = 63;
+    while (!((v >> e) & 1)) e--;
+    const unsigned __int128 frac = ((unsigned __int128)(v ^ (1ull << e))) << (128 - e); // 128 fraction bits
+    char buf[64];
+    snprintf(buf, sizeof(buf), "0x1.%016llx%016llxp+%02d", (unsigned long long)(uint64_t)(frac >> 64),
+             (unsigned long long)(uint64_t)frac, e);
+    return buf;
+}
+
+std::string MetaDataJSON(const MetaData &md, uint64_t plaintextModulus) {
+    char buf[512];
+    snprintf(buf, sizeof(buf),
+             "{\"PlaintextMetaData\":{\"Scale\":{\"Value\":\"%s\",\"Mod\":\"%llu\"},\"IsBatched\":\"0x%02x\","
+             "\"LogDimensions\":[\"0x%02x\",\"0x%02x\"]},\"CiphertextMetaData\":{\"IsNTT\":\"0x%02x\","
+             "\"IsMontgomery\":\"0x%02x\"}}",
+             hex_float(md.Scale).c_str(), (unsigned long long)plaintextModulus, md.IsBatched ? 1 : 0,
+             (unsigned)md.LogRows, (unsigned)md.LogCols, md.IsNTT ? 1 : 0, md.IsMontgomery ? 1 : 0);
+    return buf;
+}
+
+void SetCiphertextFormat(ServerBFV &backend, const MetaData &md, int level) {
+    auto le64 = [](std::vector<uint8_t> &v, uint64_t x) {
+        for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i)));
+    };
+    const std::string json = MetaDataJSON(md, backend.GetParameters().T);
+    std::vector<uint8_t> head(json.begin(), json.end()), poly, limb;
+    le64(head, 2); // structs.Vector[ring.Poly]: two polynomials
+    le64(poly, (uint64_t)level + 1);
+    le64(limb, (uint64_t)backend.GetParameters().N());
+    backend.check(lumen_leaf_format_set(backend.Context(), head.data(), (uint32_t)head.size(), poly.data(),
+                                        (uint32_t)poly.size(), limb.data(), (uint32_t)limb.size()),
+                  "lumen_leaf_format_set");
 }
 
 // ------------------------------------------------------------------ host ring helpers
@@ -276,7 +320,9 @@ Ciphertexts ServerBFV::EncryptNewBatch(const std::vector<Plaintext> &pts) {
     lumen_set *set = nullptr;
     check(lumen_encrypt_pk(ctx_, flat.data(), (uint32_t)pts.size(), enc_seed_, enc_next_, &set), "lumen_encrypt_pk");
     enc_next_ += pts.size();
-    return Ciphertexts(ctx_, set);
+    MetaData md; // fresh encryption: Scale 1, NTT domain, batched 2 x N/2 slots
+    md.LogCols = params_.LogN - 1;
+    return Ciphertexts(ctx_, set, md);
 }
 
 Ciphertexts ServerBFV::EncryptColumnsNew(const std::vector<uint64_t> &values, int rows, int count) {
@@ -287,7 +333,9 @@ Ciphertexts ServerBFV::EncryptColumnsNew(const std::vector<uint64_t> &values, in
     check(lumen_encrypt_values(ctx_, values.data(), (uint32_t)rows, (uint32_t)count, enc_seed_, enc_next_, &set),
           "lumen_encrypt_values");
     enc_next_ += (uint64_t)count;
-    return Ciphertexts(ctx_, set);
+    MetaData md;
+    md.LogCols = params_.LogN - 1;
+    return Ciphertexts(ctx_, set, md);
 }
 
 // ------------------------------------------------------------------ ring switch
@@ -312,7 +360,7 @@ Ciphertexts Encode(const Ciphertexts &matrix, int rows, int rhoInv, ServerBFV &b
     const std::vector<uint64_t> zeroCol = backend.EncryptNew(zeroColPt);
     lumen_set *enc = nullptr;
     backend.check(lumen_encode(backend.Context(), matrix.Handle(), zeroCol.data(), (uint32_t)rhoInv, &enc), "lumen_encode");
-    return Ciphertexts(backend.Context(), enc);
+    return Ciphertexts(backend.Context(), enc, matrix.Meta); // Add / Sub / Mul by a scalar keep the scale
 }
 
 void NTT(Ciphertexts &values, int size, ServerBFV &backend) {
@@ -354,7 +402,10 @@ std::pair<LigeroProver, std::vector<uint8_t>> LigeroCommitter::Commit(const Ciph
     // processLeafParallel (ligero.go:126-183): mod-switch every column to level 1, serialise, hash
     lumen_set *lvl1 = nullptr;
     backend.check(lumen_rescale(h, encoded.Handle(), 2, &lvl1), "lumen_rescale");
-    Ciphertexts level1(h, lvl1);
+    MetaData md = encoded.Meta; // Encode keeps the scale (Mul by a scalar, Add, Sub: ntt.go)
+    md.Scale = RescaledScale(backend.GetParameters(), md.Scale, encoded.Level(), 1);
+    Ciphertexts level1(h, lvl1, md);
+    SetCiphertextFormat(backend, md, 1); // what ct.WriteTo(buf) would emit for these leaves (ligero.go:156-157)
     std::vector<core::Digest> leaves((size_t)level1.Len());
     if (!leaves.empty()) backend.check(lumen_leaf_digests(h, lvl1, leaves[0].data()), "lumen_leaf_digests");
     core::MerkleTree tree = core::MerkleTree::FromLeafDigests(std::move(leaves)); // core.NewTree
@@ -374,7 +425,10 @@ Ciphertexts matrixInnerSumEval(const Ciphertexts &matrix, const Plaintext &plain
     lumen_set *out = nullptr;
     backend.check(lumen_matrix_inner_sum(backend.Context(), matrix.Handle(), plaintext.Value.data(), (uint32_t)rows, &out),
                   "lumen_matrix_inner_sum");
-    return Ciphertexts(backend.Context(), out);
+    // MulNew: Scale_ct * Scale_pt (Encoder.Encode leaves 1); InnerSum keeps it; the Rescale loop to level 1
+    MetaData md = matrix.Meta;
+    md.Scale = RescaledScale(backend.GetParameters(), md.Scale, matrix.Level(), 1);
+    return Ciphertexts(backend.Context(), out, md);
 }
 
 std::vector<int> sampleQueryIndices(core::Transcript &transcript, int queries, int extCols) {
@@ -420,7 +474,7 @@ EncryptedProof LigeroProver::Prove(core::Element point, ServerBFV &backend, core
     std::vector<uint32_t> idx(proof.QueryIndices.begin(), proof.QueryIndices.end());
     lumen_set *q = nullptr;
     backend.check(lumen_gather(backend.Context(), EncodedMatrix.Handle(), idx.data(), (uint32_t)idx.size(), &q), "lumen_gather");
-    proof.QueriedCols = Ciphertexts(backend.Context(), q);
+    proof.QueriedCols = Ciphertexts(backend.Context(), q, EncodedMatrix.Meta);
     for (int i : proof.QueryIndices) proof.MerklePaths.push_back(Tree.GetMerklePath((unsigned)i));
     querySpan->End();
     delete querySpan;
@@ -433,19 +487,14 @@ EncryptedProof LigeroProver::Prove(core::Element point, ServerBFV &backend, core
 }
 
 static void write_cts(std::vector<uint8_t> &buf, const Ciphertexts &c) {
-    const std::vector<uint64_t> host = c.Download();
+    // ct.WriteTo(buf) for every ciphertext of the slice, in the backend's current serialisation format
     const int count = c.Len();
     if (!count) return;
-    const uint32_t nl = (uint32_t)c.Level() + 1;
-    const size_t ctw = host.size() / (size_t)count;
-    const uint32_t N = (uint32_t)(ctw / (2 * nl));
-    for (int i = 0; i < count; i++) {
-        const uint32_t hdr[4] = {0x54434d4cu, 2u, nl, N}; // stand-in for rlwe.Ciphertext.WriteTo
-        const uint8_t *h = reinterpret_cast<const uint8_t *>(hdr);
-        buf.insert(buf.end(), h, h + 16);
-        const uint8_t *d = reinterpret_cast<const uint8_t *>(host.data() + (size_t)i * ctw);
-        buf.insert(buf.end(), d, d + ctw * 8);
-    }
+    const size_t each = lumen_ct_serialized_size(c.Context(), (uint32_t)c.Level() + 1);
+    const size_t at = buf.size();
+    buf.resize(at + each * (size_t)count);
+    if (lumen_ct_serialize(c.Context(), c.Handle(), 0, (uint32_t)count, buf.data() + at, each * (size_t)count))
+        throw std::runtime_error(std::string("lumen_ct_serialize: ") + lumen_last_error(c.Context()));
 }
 
 std::vector<uint8_t> EncryptedProof::MarshalBinary() const {

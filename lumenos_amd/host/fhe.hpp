@@ -51,11 +51,21 @@ struct Plaintext { // *rlwe.Plaintext: one polynomial, NTT domain, [level+1][N]
 class ServerBFV;
 class RingSwitchServer;
 
+// rlwe.MetaData of the ciphertexts of one slice (they are produced by the same calls, so they share it):
+// what the Go shim's download() has to write into every rlwe.Ciphertext it materialises (SURVEY 8b,
+// "Ownership").  Scale is bgv's plaintext scale modulo T: 1 after EncryptNew, multiplied by the
+// plaintext's scale in MulNew and by q_l^-1 mod T for every limb Rescale drops.
+struct MetaData {
+    uint64_t Scale = 1;
+    bool IsNTT = true, IsMontgomery = false, IsBatched = true;
+    int LogRows = 1, LogCols = 0; // LogDimensions of the 2 x N/2 slot matrix
+};
+
 // []*rlwe.Ciphertext resident in HBM
 class Ciphertexts {
   public:
     Ciphertexts() = default;
-    Ciphertexts(lumen_ctx *ctx, lumen_set *set) : ctx_(ctx), set_(set) {}
+    Ciphertexts(lumen_ctx *ctx, lumen_set *set, MetaData md = MetaData()) : Meta(md), ctx_(ctx), set_(set) {}
     Ciphertexts(Ciphertexts &&o) noexcept { *this = std::move(o); }
     Ciphertexts &operator=(Ciphertexts &&o) noexcept;
     Ciphertexts(const Ciphertexts &) = delete;
@@ -66,11 +76,23 @@ class Ciphertexts {
     int Level() const;
     lumen_set *Handle() const { return set_; }
     lumen_ctx *Context() const { return ctx_; }
+    MetaData Meta;
+    uint64_t Scale() const { return Meta.Scale; }
 
   private:
     lumen_ctx *ctx_ = nullptr;
     lumen_set *set_ = nullptr;
 };
+
+// Scale after `for ct.Level() > target { Rescale }` from level `from`: scale * prod q_l^-1 mod T
+uint64_t RescaledScale(const Parameters &params, uint64_t scale, int fromLevel, int toLevel);
+// The MetaData block rlwe.Ciphertext.WriteTo puts in front of the polynomials, as recalled
+// [LATTIGO-RECALL rlwe/metadata.go: MarshalBinary = MarshalJSON of {PlaintextMetaData, CiphertextMetaData},
+// booleans and log-dimensions as "0x%02x" strings, Scale as {Value, Mod}]; a Go host replaces it with the
+// real bytes (lumen_leaf_format_set).
+std::string MetaDataJSON(const MetaData &md, uint64_t plaintextModulus);
+// installs head = MetaData | LE64(2), poly_head = LE64(level+1), limb_head = LE64(N) on the backend
+void SetCiphertextFormat(ServerBFV &backend, const MetaData &md, int level);
 
 // fhe.ServerBFV (fhe/bfv.go:13-58): plaintext field + parameters + evaluator/encoder/encryptor
 class ServerBFV {
@@ -149,7 +171,7 @@ struct EncryptedProof { // fhe/ligero.go:185-192
     std::vector<std::vector<core::Digest>> MerklePaths;
     std::vector<uint8_t> Root;
     std::vector<int> QueryIndices; // not part of the wire format; kept for tests
-    // ligero.go:646-705; ciphertext bytes are the documented stand-in for Lattigo's WriteTo
+    // ligero.go:646-705; every ciphertext through lumen_ct_serialize in the backend's current format
     std::vector<uint8_t> MarshalBinary() const;
 };
 

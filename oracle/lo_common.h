@@ -250,12 +250,19 @@ void lo_decrypt_big_coeffs_l0(const lo_params *p, const uint64_t *sk, const uint
 /* ---------------------------------------------------------------- ligero glue */
 /* calculateQueries (fhe/ligero.go:65-71) */
 int lo_calculate_queries(double security_bits, int rho_inv);
-/* leaf bytes of one level-1 ciphertext.  STAND-IN for Lattigo's
- * rlwe.Ciphertext.WriteTo (fhe/ligero.go:156-157) whose header bytes are
- * unknown offline: 16-byte header {u32 magic 'LMCT', u32 degree+1,
- * u32 limbs, u32 N} then raw little-endian limbs [poly][limb][N]. */
+/* leaf bytes of one ciphertext: rlwe.Ciphertext.WriteTo (fhe/ligero.go:156-157) as the layout
+ *     head | per polynomial: poly | per limb: limb | N little-endian u64
+ * fmt == NULL: the recalled framing with an empty MetaData block (lo_ligero.c) */
+typedef struct lo_ct_format {
+    const uint8_t *head, *poly, *limb;
+    uint32_t head_len, poly_len, limb_len;
+} lo_ct_format;
+size_t lo_ct_serialized_size_fmt(const lo_ct_format *f, uint32_t nl, uint32_t N);
+void lo_ct_serialize_fmt(const uint64_t *ct, uint32_t nl, uint32_t N, const lo_ct_format *f, uint8_t *out);
 size_t lo_ct_serialized_size(uint32_t nl, uint32_t N);
 void lo_ct_serialize(const uint64_t *ct, uint32_t nl, uint32_t N, uint8_t *out);
+void lo_commit_leaves_fmt(const lo_params *p, const uint64_t *encoded, uint32_t count, uint32_t nl,
+                          const lo_ct_format *fmt, uint64_t *level1, uint8_t *digests);
 /* processLeafParallel (fhe/ligero.go:126-183): rescale every encoded column to level 1, serialise, SHA-256.
  * level1: [count][2][2][N]; digests: [count][32] */
 void lo_commit_leaves(const lo_params *p, const uint64_t *encoded, uint32_t count, uint32_t nl,

@@ -118,7 +118,10 @@ class Oracle:
             "lo_calculate_queries": (C.c_int, [C.c_double, C.c_int]),
             "lo_ct_serialized_size": (C.c_size_t, [C.c_uint32, C.c_uint32]),
             "lo_ct_serialize": (None, [u64p, C.c_uint32, C.c_uint32, u8p]),
+            "lo_ct_serialized_size_fmt": (C.c_size_t, [vp, C.c_uint32, C.c_uint32]),
+            "lo_ct_serialize_fmt": (None, [u64p, C.c_uint32, C.c_uint32, vp, u8p]),
             "lo_commit_leaves": (None, [vp, u64p, C.c_uint32, C.c_uint32, u64p, u8p]),
+            "lo_commit_leaves_fmt": (None, [vp, u64p, C.c_uint32, C.c_uint32, vp, u64p, u8p]),
             "lo_matrix_inner_sum": (None, [vp, u64p, C.c_uint32, C.c_uint32, u64p, C.c_uint32, C.POINTER(u64p), u64p]),
             "lo_sample_query_indices": (None, [vp, C.c_uint32, C.c_uint32, u32p]),
             "lo_prove_b_vector": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p]),
@@ -179,6 +182,18 @@ class Oracle:
         rt = np.frombuffer(root, dtype=np.uint8).copy()
         path = np.ascontiguousarray(path, dtype=np.uint8)
         return bool(self.lib.lo_merkle_verify(_p8(ld), _p8(path), path.shape[0], _p8(rt), index))
+
+
+class CtFormat(C.Structure):
+    """lo_ct_format: head | per poly: poly | per limb: limb | data (oracle/lo_common.h)"""
+    _fields_ = [("head", C.c_char_p), ("poly", C.c_char_p), ("limb", C.c_char_p),
+                ("head_len", C.c_uint32), ("poly_len", C.c_uint32), ("limb_len", C.c_uint32)]
+
+    @classmethod
+    def make(cls, head: bytes, poly: bytes, limb: bytes):
+        f = cls(head, poly, limb, len(head), len(poly), len(limb))
+        f._keep = (head, poly, limb)
+        return f
 
 
 class Transcript:
@@ -461,12 +476,15 @@ class Params:
         self.o.lib.lo_decrypt_big_coeffs_l0(self.h, _p64(sk), _p64(ct), ct.shape[1], _p64(m))
         return m
 
-    def commit_leaves(self, encoded):
+    def commit_leaves(self, encoded, fmt=None):
+        """fmt: (head, poly, limb) byte strings of the serialisation layout, or None for the default framing"""
         encoded = np.ascontiguousarray(encoded, dtype=np.uint64)
         count, _, nl, N = encoded.shape
         level1 = np.zeros((count, 2, 2, N), dtype=np.uint64)
         digests = np.zeros((count, 32), dtype=np.uint8)
-        self.o.lib.lo_commit_leaves(self.h, _p64(encoded), count, nl, _p64(level1), _p8(digests))
+        f = CtFormat.make(*fmt) if fmt else None
+        self.o.lib.lo_commit_leaves_fmt(self.h, _p64(encoded), count, nl, C.byref(f) if f else None, _p64(level1),
+                                        _p8(digests))
         return level1, digests
 
     def matrix_inner_sum(self, matrix, pt, rows, evks):
@@ -476,12 +494,14 @@ class Params:
         self.o.lib.lo_matrix_inner_sum(self.h, _p64(matrix), cols, nl, _p64(pt), rows, self._evk_ptrs(evks), _p64(out))
         return out
 
-    def ct_serialize(self, ct):
+    def ct_serialize(self, ct, fmt=None):
         ct = np.ascontiguousarray(ct, dtype=np.uint64)
         _, nl, N = ct.shape
-        sz = self.o.lib.lo_ct_serialized_size(nl, N)
+        f = CtFormat.make(*fmt) if fmt else None
+        fp = C.byref(f) if f else None
+        sz = self.o.lib.lo_ct_serialized_size_fmt(fp, nl, N)
         out = np.zeros(sz, dtype=np.uint8)
-        self.o.lib.lo_ct_serialize(_p64(ct), nl, N, _p8(out))
+        self.o.lib.lo_ct_serialize_fmt(_p64(ct), nl, N, fp, _p8(out))
         return out.tobytes()
 
     def __del__(self):

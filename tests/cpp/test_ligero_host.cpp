@@ -99,8 +99,30 @@ int main(int argc, char **argv) {
     span->End();
     printf("Number of multiplications: %d\n", server.MulCounter());
 
+    // download(): the MetaData the shim writes into the rlwe.Ciphertexts it hands back -- Scale is the
+    // product of the dropped moduli's inverses modulo T (SURVEY 8b "Ownership"), tracked by the mirror
+    const uint64_t scale = lo_rescale_scale(op, L, 2);
+    REQUIRE(ciphertexts.Scale() == 1, "fresh encryptions carry scale 1");
+    REQUIRE(proof.MatR.Scale() == scale && proof.MatZ.Scale() == scale && proof.QueriedCols.Scale() == scale,
+            "scale bookkeeping: MatR %llu MatZ %llu Queried %llu, expected %llu", (unsigned long long)proof.MatR.Scale(),
+            (unsigned long long)proof.MatZ.Scale(), (unsigned long long)proof.QueriedCols.Scale(), (unsigned long long)scale);
+    REQUIRE(proof.MatR.Meta.IsNTT && proof.MatR.Meta.IsBatched && !proof.MatR.Meta.IsMontgomery &&
+                proof.MatR.Meta.LogRows == 1 && proof.MatR.Meta.LogCols == LogN - 1, "metadata flags");
+    REQUIRE(proof.MatR.Level() == 1 && proof.QueriedCols.Level() == 1, "proof ciphertexts are at level 1");
+
+    // the serialisation format Commit installed: MetaData JSON | LE64(2), LE64(limbs), LE64(N); the checker
+    // rebuilds the same bytes with the oracle's serialiser
+    const std::string json = fhe::MetaDataJSON(proof.QueriedCols.Meta, Modulus);
+    std::vector<uint8_t> f_head(json.begin(), json.end()), f_poly, f_limb;
+    auto le64 = [](std::vector<uint8_t> &v, uint64_t x) {
+        for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i)));
+    };
+    le64(f_head, 2), le64(f_poly, 2), le64(f_limb, (uint64_t)N);
+    lo_ct_format fmt = {f_head.data(), f_poly.data(), f_limb.data(), (uint32_t)f_head.size(), (uint32_t)f_poly.size(),
+                        (uint32_t)f_limb.size()};
     std::vector<uint8_t> marshaled = proof.MarshalBinary();
-    const size_t ct1 = 16 + (size_t)4 * N * 8;
+    const size_t ct1 = lo_ct_serialized_size_fmt(&fmt, 2, (uint32_t)N);
+    REQUIRE(ct1 == json.size() + 8 + 2 * (8 + 2 * (8 + (size_t)N * 8)), "serialised size");
     const int S = cols * rhoInv;
     int depth = 0;
     while ((1 << depth) < S) depth++;
@@ -108,7 +130,6 @@ int main(int argc, char **argv) {
             "marshaled size %zu", marshaled.size());
 
     // ---- client: decrypt (EncryptedProof.Decrypt, ligero.go:381-502) with the oracle
-    const uint64_t scale = lo_rescale_scale(op, L, 2);
     auto decrypt = [&](const std::vector<uint64_t> &host, int idx, int nvals) {
         std::vector<uint64_t> v(nvals);
         lo_decrypt_decode(op, sk.data(), host.data() + (size_t)idx * 4 * N, 2, scale, v.data(), nvals);
@@ -149,7 +170,9 @@ int main(int argc, char **argv) {
     REQUIRE(qidx == proof.QueryIndices, "query indices differ from the verifier's transcript");
     std::vector<uint8_t> leaf(ct1);
     for (size_t qi = 0; qi < qidx.size(); qi++) {
-        lo_ct_serialize(hQ.data() + qi * 4 * N, 2, N, leaf.data());
+        lo_ct_serialize_fmt(hQ.data() + qi * 4 * N, 2, (uint32_t)N, &fmt, leaf.data());
+        REQUIRE(!memcmp(leaf.data(), marshaled.data() + 11 + ((size_t)2 * cols + qi) * ct1, ct1),
+                "marshaled bytes of queried column %zu differ from the checker's serialisation", qi);
         core::Digest d = core::Sha256(leaf.data(), leaf.size());
         REQUIRE(core::VerifyMerklePath(d, proof.MerklePaths[qi], proof.Root, (unsigned)qidx[qi]),
                 "failed to verify merkle path for column %d", qidx[qi]);

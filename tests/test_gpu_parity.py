@@ -113,6 +113,54 @@ def test_leaf_digests_and_merkle(oracle, small):
     assert root == oroot and np.array_equal(nodes, onodes)
 
 
+@pytest.mark.parametrize("lens", [(0, 0, 0), (8, 8, 8), (233, 8, 8), (1, 3, 5), (63, 64, 7), (1024, 2, 0), (130, 0, 61)])
+def test_leaf_format_any_byte_alignment(oracle, small, lens):
+    """The serialisation layout is a parameter (lumen_leaf_format_set): head | per polynomial poly_head |
+    per limb limb_head | raw limbs.  Lattigo's MetaData block has no reason to be a multiple of 4 or 8
+    bytes, so the limb data may sit at any byte offset of SHA-256's blocks: digests and serialised bytes
+    must equal the oracle's for every alignment, for one and two limbs, and the default framing returns
+    when the format is cleared."""
+    P, ctx = small
+    rng = np.random.default_rng(sum(lens) + 1)
+    head, poly, limb = (bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in lens)
+    try:
+        ctx.leaf_format_set(head, poly, limb)
+        for nl in (2, 1):
+            cts = random_cts(P, 67, nl, seed=61 + nl)  # more than one wave, not a multiple of 64
+            s = ctx.upload(cts)
+            dig = ctx.leaf_digests(s)
+            blob = ctx.ct_serialize(s, 3, 2)
+            want = [P.ct_serialize(cts[c], (head, poly, limb)) for c in range(67)]
+            assert blob == want[3] + want[4]
+            assert len(want[0]) == sum(lens[:1]) + 2 * (lens[1] + nl * (lens[2] + 8 * P.N))
+            for c in range(67):
+                assert dig[c].tobytes() == oracle.sha256(want[c]), (nl, c)
+            ctx.leaf_digests_begin(s)
+            assert np.array_equal(ctx.leaf_digests_end(), dig)
+    finally:
+        ctx.leaf_format_set()
+    cts = random_cts(P, 2, 2, seed=7)
+    assert ctx.leaf_digests(ctx.upload(cts))[1].tobytes() == oracle.sha256(P.ct_serialize(cts[1]))
+    with pytest.raises(Exception):
+        ctx.leaf_format_set(b"x" * 1025, b"", b"")
+
+
+def test_set_destroyed_while_its_leaves_are_hashed(small):
+    """A set freed between lumen_leaf_digests_begin and _end: the destroy waits for the side stream's job
+    (it reads that storage); the digests are the synchronous ones and a set created right after may reuse
+    the storage safely."""
+    P, ctx = small
+    cts = random_cts(P, 300, 2, seed=71)
+    s = ctx.upload(cts)
+    want = ctx.leaf_digests(s)
+    ctx.leaf_digests_begin(s)
+    s.free()
+    t = ctx.new_set(300, 2).fill_random(5)  # same size: takes the block the pool just got back
+    got = ctx.leaf_digests_end()
+    assert np.array_equal(got, want)
+    t.free()
+
+
 def test_gather(oracle, small):
     P, ctx = small
     cts = random_cts(P, 9, 2, seed=41)
@@ -612,7 +660,7 @@ def test_error_paths_report_status_and_message(oracle, small):
     fails(lambda: fresh.decrypt(fresh.new_set(1, 2), 1), "no secret key")
     fresh.load_secret_key(np.zeros((P.L, P.N), dtype=np.uint64))
     fails(lambda: fresh.decrypt(fresh.new_set(1, 3), 1), "one or two limbs")
-    bad = np.full((2, P.L, P.N), 2**63, dtype=np.uint64)
+    bad = np.full((2, P.L + P.K, P.N), 2**63, dtype=np.uint64)
     fails(lambda: fresh.load_public_key(bad), "out of range")
     # one asynchronous leaf job at a time
     fresh.leaf_digests_begin(fresh.new_set(3, 2).fill_random(4))

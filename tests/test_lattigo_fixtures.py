@@ -1,0 +1,476 @@
+"""Lattigo differential: consumes the fixtures tools/go_dump writes on a Go host
+(tests/golden/lattigo/*.lmfx) and checks the CPU oracle -- and with `-m gpu` the HIP path through
+the C ABI -- against Lattigo's own outputs, stage by stage:
+
+    params.lmfx      psi per modulus, psi_T, the NTT table of q_0, Galois elements, core.PrimeField table
+    encrypt.lmfx     Encoder.Encode, EncryptNew (decrypts; fresh noise is the few units of a division by P)
+    mul_scalar.lmfx  Evaluator.Mul(ct, uint64) centring, Add, Sub
+    mul_plain.lmfx   MulNew(ct, pt)
+    rescale.lmfx     Rescale once and the loop to level 1, Scale bookkeeping
+    writeto.lmfx     ct.WriteTo bytes: the leaf layout (head / poly_head / limb_head) and its SHA-256
+    innersum_*.lmfx  MulNew + InnerSum(ct, 1, n) + Rescale with real Galois keys (n = N/2 and n = N)
+    ringswitch.lmfx  ApplyEvaluationKey into the small ring
+    ct_ntt.lmfx      fhe.NTT on ciphertexts            (only with `go run -tags withfhe`)
+
+Until those files exist every "lattigo" case SKIPS with the reason below -- the restatement stays
+"parity unpinned" (DESIGN.md section 4).  The same checks also run on a "synthetic" set written by the
+oracle itself in Lattigo's storage conventions (keys in Montgomery form, per-key digit matrices, the
+container format): that proves the ingestion code (layout, Montgomery conversion, key flattening, leaf
+layout derivation) and nothing about Lattigo.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import lmfx
+from helpers import T_REF, make_context
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LATTIGO_DIR = os.path.join(ROOT, "tests", "golden", "lattigo")
+SKIP = ("no Lattigo fixtures in tests/golden/lattigo: run tools/go_dump on a Go host "
+        "(this image has no Go toolchain); parity with Lattigo stays unpinned until then")
+
+
+# ------------------------------------------------------------------ conversions from Lattigo's storage
+def from_montgomery(a, moduli):
+    """[..., limb, N] in Montgomery form (x * 2^64 mod q) -> standard form"""
+    a = np.asarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    for l, q in enumerate(moduli):
+        inv = pow(1 << 64, -1, q)
+        out[..., l, :] = (a[..., l, :].astype(object) * inv % q).astype(np.uint64)
+    return out
+
+
+def to_montgomery(a, moduli):
+    a = np.asarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    for l, q in enumerate(moduli):
+        out[..., l, :] = (a[..., l, :].astype(object) * ((1 << 64) % q) % q).astype(np.uint64)
+    return out
+
+
+def std_ct(rec, name):
+    """ciphertext record -> canonical NTT-domain residues [2][limbs][N] (what the ABI takes)"""
+    flags = rec[name + ".flags"]
+    assert flags[0] == 1 and flags[1] == 0, f"{name}: expected an NTT-domain, non-Montgomery ciphertext, flags {flags}"
+    return np.ascontiguousarray(rec[name])
+
+
+def galois_key(rec, name, moduli, montgomery):
+    """EvaluationKey record [D*D2*2][L+K][N] -> the ABI's [digit][b|a][L+K][N] (D2 = 1 for Galois keys)"""
+    d, d2, _base = (int(x) for x in rec[name + ".shape"])
+    assert d2 == 1, "Galois keys have no power-of-two decomposition"
+    k = rec[name].reshape(d, 2, len(moduli), -1)
+    return from_montgomery(k, moduli) if montgomery else np.ascontiguousarray(k)
+
+
+def ringswitch_key(rec, name, moduli, L, K, montgomery):
+    """ring-switch key [D*D2*2][L+K][N] -> [digit_pow2][b|a][q0, p_0..p_{K-1}][N] of RNS digit 0
+    (level 0 only uses q_0: lumen_load_ringswitch_key)"""
+    d, d2, _base = (int(x) for x in rec[name + ".shape"])
+    k = rec[name].reshape(d, d2, 2, len(moduli), -1)
+    k = from_montgomery(k, moduli) if montgomery else k
+    return np.ascontiguousarray(k[0][:, :, [0] + list(range(L, L + K)), :])
+
+
+def leaf_format(blob, ct):
+    """Cut head / poly_head / limb_head out of ONE serialised ciphertext by locating the raw little-endian
+    image of every limb (what the Go shim does with ct.WriteTo)."""
+    npoly, nl, N = ct.shape
+    pos = []
+    at = 0
+    for k in range(npoly):
+        for l in range(nl):
+            img = ct[k, l].astype("<u8").tobytes()
+            i = blob.find(img, at)
+            assert i >= 0, f"limb image ({k},{l}) not found in the serialised bytes: limbs are not raw LE u64"
+            pos.append(i)
+            at = i + len(img)
+    assert at == len(blob), "bytes after the last limb"
+    size = 8 * N
+    limb = blob[pos[0] + size:pos[1]] if nl > 1 else b""
+    between = blob[pos[nl - 1] + size:pos[nl]]  # poly_head | limb_head of the second polynomial
+    poly = between[:len(between) - len(limb)]
+    assert between[len(poly):] == limb
+    head = blob[:pos[0] - len(poly) - len(limb)]
+    assert blob[len(head):pos[0]] == poly + limb
+    for k in range(npoly):
+        for l in range(1, nl):
+            assert blob[pos[k * nl + l] - len(limb):pos[k * nl + l]] == limb
+    return head, poly, limb
+
+
+# ------------------------------------------------------------------ synthetic fixtures (oracle -> LMFX)
+def synthesize(oracle, out_dir, log_n=10, cols=16):
+    """The files tools/go_dump would write, produced by the oracle in Lattigo's storage conventions."""
+    from lumenos_amd import params as lp
+    from oracle.loader import Params
+    B = lp.generate_bgv_params_for_ntt(cols, log_n)
+    P = Params.from_moduli(oracle, log_n, B.q, B.p, B.T)
+    P.seed(4242)
+    N, L, K = P.N, P.L, P.K
+    mods = P.moduli
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    flags = lambda lvl: np.array([1, 0, 1, lvl], dtype=np.uint64)
+
+    def ct_rec(d, name, ct, scale=1):
+        d[name] = ct
+        d[name + ".flags"] = flags(ct.shape[1] - 1)
+        d[name + ".scale"] = np.array([scale], dtype=np.uint64)
+
+    lg = log_n
+    psi0 = P.psi[0]
+    table = np.array([pow(psi0, int(lp.bit_reverse(j, lg)), mods[0]) * (1 << 64) % mods[0] for j in range(N)],
+                     dtype=np.uint64)
+    lmfx.write(os.path.join(out_dir, "params.lmfx"), {
+        "logN": np.array([log_n], dtype=np.uint64), "Q": np.array(mods[:L], dtype=np.uint64),
+        "P": np.array(mods[L:], dtype=np.uint64), "T": np.array([T_REF], dtype=np.uint64),
+        "psi": np.array(P.psi, dtype=np.uint64), "psi_T": np.array([lp.encoder_psi(T_REF, log_n)], dtype=np.uint64),
+        "roots_forward_q0_montgomery": table,
+        "galois_elements_inner_sum_half": np.array(P.inner_sum_galois_elements(N // 2), dtype=np.uint64),
+        "galois_elements_inner_sum_full": np.array(P.inner_sum_galois_elements(N), dtype=np.uint64),
+        "field_roots_forward": oracle.field_roots(T_REF, 2 * cols),
+    })
+    values = np.array([(i * 0x9e3779b97f4a7c15 + 12345) % (1 << 64) % T_REF for i in range(N)], dtype=np.uint64)
+    pt = P.encode(values)
+    ct = P.encrypt(pk, pt)
+    d = {"values": values, "plaintext": pt[None], "sk": to_montgomery(sk, mods)[None],
+         "pk": to_montgomery(pk, mods), "keys_montgomery": np.array([1], dtype=np.uint64), "decrypted": values}
+    ct_rec(d, "ciphertext", ct)
+    lmfx.write(os.path.join(out_dir, "encrypt.lmfx"), d)
+
+    d = {}
+    ct_rec(d, "in", ct)
+    for i, w in enumerate([95661681840738641, 33554304, T_REF - 1, 3]):
+        s = [int(oracle.lib.lo_centered_scalar(w, T_REF, q)) for q in mods[:L]]
+        o = np.stack([np.stack([(ct[k, l].astype(object) * s[l] % mods[l]).astype(np.uint64) for l in range(L)])
+                      for k in range(2)])
+        d[f"w{i}"] = np.array([w], dtype=np.uint64)
+        ct_rec(d, f"out{i}", o)
+    q = np.array(mods[:L], dtype=object)[None, :, None]
+    ct_rec(d, "add", ((ct.astype(object) * 2) % q).astype(np.uint64))
+    ct_rec(d, "sub", ct)
+    lmfx.write(os.path.join(out_dir, "mul_scalar.lmfx"), d)
+
+    r = np.array([(i * 0xbf58476d1ce4e5b9 + 7) % (1 << 64) for i in range(N)], dtype=np.uint64)
+    rpt = P.encode(r)
+    d = {"r": r, "plaintext": rpt[None]}
+    ct_rec(d, "in", ct)
+    ct_rec(d, "out", P.mul_plain(ct, rpt))
+    lmfx.write(os.path.join(out_dir, "mul_plain.lmfx"), d)
+
+    d = {}
+    ct_rec(d, "in", ct)
+    ct_rec(d, "once", P.rescale(ct), P.rescale_scale(L, L - 1))
+    l1 = P.rescale_to_level1(ct)
+    ct_rec(d, "level1", l1, P.rescale_scale(L, 2))
+    lmfx.write(os.path.join(out_dir, "rescale.lmfx"), d)
+
+    md = b'{"PlaintextMetaData":{"Scale":"synthetic"},"CiphertextMetaData":{"IsNTT":"0x01"}}_'  # odd length
+    fmt = (md + (2).to_bytes(8, "little"), (2).to_bytes(8, "little"), N.to_bytes(8, "little"))
+    d = {"bytes": np.frombuffer(P.ct_serialize(l1, fmt), dtype=np.uint8), "metadata_bytes": np.frombuffer(md, dtype=np.uint8)}
+    ct_rec(d, "ct", l1, P.rescale_scale(L, 2))
+    lmfx.write(os.path.join(out_dir, "writeto.lmfx"), d)
+
+    for n in (N // 2, N):
+        gl = P.inner_sum_galois_elements(n)
+        evks = [P.keygen_galois(sk, g) for g in gl]
+        d = {"n": np.array([n], dtype=np.uint64), "galois_elements": np.array(gl[::-1], dtype=np.uint64),  # any order
+             "keys_montgomery": np.array([1], dtype=np.uint64), "sk": to_montgomery(sk, mods)[None], "r": r,
+             "plaintext": rpt[None]}
+        for i, (g, e) in enumerate(list(zip(gl, evks))[::-1]):
+            d[f"key{i}.galois_element"] = np.array([g], dtype=np.uint64)
+            d[f"key{i}"] = to_montgomery(e, mods).reshape(-1, L + K, N)
+            d[f"key{i}.shape"] = np.array([e.shape[0], 1, 0], dtype=np.uint64)
+        ct_rec(d, "in", ct)
+        inner = P.inner_sum(P.mul_plain(ct, rpt), n, evks)
+        ct_rec(d, "inner_sum", inner)
+        out = P.rescale_to_level1(inner)
+        ct_rec(d, "out", out, P.rescale_scale(L, 2))
+        d["slot0"] = P.decrypt(sk, out, 1, P.rescale_scale(L, 2))
+        lmfx.write(os.path.join(out_dir, f"innersum_{n}.lmfx"), d)
+
+    small = 8
+    sk_small = P.keygen_secret_small(small)
+    key = P.keygen_ringswitch(sk, sk_small, small)  # [npw2][2][1+K][N], RNS digit 0, limbs {q0, P}
+    nd2 = key.shape[0]
+    beta = P.beta()
+    full = np.zeros((beta, nd2, 2, L + K, N), dtype=np.uint64)
+    full[0][:, :, [0] + list(range(L, L + K)), :] = key
+    d = {"logN_small": np.array([small], dtype=np.uint64), "key": to_montgomery(full, mods).reshape(-1, L + K, N),
+         "key.shape": np.array([beta, nd2, 13], dtype=np.uint64), "keys_montgomery": np.array([1], dtype=np.uint64)}
+    ct_rec(d, "in", l1, P.rescale_scale(L, 2))
+    out = P.ring_switch(l1, key, small)
+    d["out"] = out[:, None, :]
+    d["out.flags"] = flags(0)
+    d["out.scale"] = np.array([P.rescale_scale(L, 2)], dtype=np.uint64)
+    lmfx.write(os.path.join(out_dir, "ringswitch.lmfx"), d)
+
+    S = 2 * cols
+    roots = oracle.field_roots(T_REF, S)
+    ins = np.stack([P.encrypt(pk, P.encode(values[:64] + i)) for i in range(S)])
+    outs = P.ct_ntt(ins, S, roots)
+    d = {"mul_counter": np.array([0], dtype=np.uint64)}
+    for i in range(S):
+        ct_rec(d, f"in{i}", ins[i])
+        ct_rec(d, f"out{i}", outs[i])
+    lmfx.write(os.path.join(out_dir, "ct_ntt.lmfx"), d)
+
+
+# ------------------------------------------------------------------ fixtures
+@pytest.fixture(scope="module", params=["lattigo", "synthetic"])
+def fx(request, oracle, tmp_path_factory):
+    if request.param == "lattigo":
+        if not glob.glob(os.path.join(LATTIGO_DIR, "*.lmfx")):
+            pytest.skip(SKIP)
+        d = LATTIGO_DIR
+    else:
+        d = str(tmp_path_factory.mktemp("lmfx_synth"))
+        synthesize(oracle, d)
+    from oracle.loader import Params
+    rec = lmfx.read(os.path.join(d, "params.lmfx"))
+    Q, Pm = [int(x) for x in rec["Q"]], [int(x) for x in rec["P"]]
+    P = Params.from_moduli(oracle, int(rec["logN"][0]), Q, Pm, int(rec["T"][0]))
+
+    def load(name):
+        path = os.path.join(d, name)
+        if not os.path.exists(path):
+            pytest.skip(f"{name} not in the fixture set ({request.param})")
+        return lmfx.read(path)
+    return request.param, P, rec, load
+
+
+def sk_of(P, rec):
+    sk = rec["sk"][0]
+    return from_montgomery(sk, P.moduli) if int(rec["keys_montgomery"][0]) else sk
+
+
+# ------------------------------------------------------------------ CPU: oracle vs fixtures
+def test_params(oracle, fx):
+    """The primitive 2N-th roots, the encoder's root modulo T, the NTT table order of q_0, the Galois
+    elements InnerSum needs and core.PrimeField's table: everything the restatement derived by itself."""
+    from lumenos_amd import params as lp
+    _, P, rec, _ = fx
+    assert [int(x) for x in rec["psi"]] == P.psi, "psi: Lattigo picks another primitive root / 2N-th root"
+    assert int(rec["psi_T"][0]) == lp.encoder_psi(T_REF, P.logN)
+    q0, psi0 = P.moduli[0], P.psi[0]
+    tab = rec["roots_forward_q0_montgomery"]
+    inv = pow(1 << 64, -1, q0)
+    for j in (0, 1, 2, 3, P.N // 2, P.N - 1):
+        assert int(tab[lp.bit_reverse(j, P.logN)]) * inv % q0 == pow(psi0, j, q0), j
+    assert set(int(x) for x in rec["galois_elements_inner_sum_half"]) == set(P.inner_sum_galois_elements(P.N // 2))
+    assert set(int(x) for x in rec["galois_elements_inner_sum_full"]) == set(P.inner_sum_galois_elements(P.N)), \
+        "InnerSum over all N slots: SURVEY Appendix D-1 (row swap 2N-1 expected)"
+    fr = rec["field_roots_forward"]
+    assert np.array_equal(fr, oracle.field_roots(T_REF, len(fr)))
+
+
+def test_encode_encrypt(oracle, fx):
+    _, P, _, load = fx
+    rec = load("encrypt.lmfx")
+    assert np.array_equal(P.encode(rec["values"]), rec["plaintext"][0]), "Encoder.Encode (slot order / T^-1 form)"
+    sk = sk_of(P, rec)
+    ct = std_ct(rec, "ciphertext")
+    assert np.array_equal(P.decrypt(sk, ct, P.N), rec["values"]) and np.array_equal(rec["decrypted"], rec["values"])
+    # fresh noise: c0 + c1*s - pt, coefficient domain, limb 0
+    q0 = P.moduli[0]
+    zero = ct.copy()
+    zero[0] = ((ct[0].astype(object) + np.array(P.moduli[:P.L], dtype=object)[:, None] - rec["plaintext"][0].astype(object))
+               % np.array(P.moduli[:P.L], dtype=object)[:, None]).astype(np.uint64)
+    ph = P.decrypt_phase(sk, zero[:, :1])
+    e = ph[0].astype(object) * pow(T_REF % q0, -1, q0) % q0
+    e = np.array([int(x) if x < q0 // 2 else int(x) - q0 for x in e], dtype=np.float64)
+    assert np.abs(e).max() < 64, (f"fresh noise max |e| = {np.abs(e).max():.0f}: an encryption over QP divided by P "
+                                  "leaves a few units (DESIGN.md section 4); ~2^8 would mean Lattigo encrypts in Q alone")
+    pk = from_montgomery(rec["pk"], P.moduli) if int(rec["keys_montgomery"][0]) else rec["pk"]
+    assert pk.shape == (2, P.L + P.K, P.N), "rlwe.PublicKey lives over QP"
+    s = sk[:P.L + P.K]
+    for l, q in enumerate(P.moduli):  # pk0 + pk1*s = e_pk: small
+        v = (pk[0, l].astype(object) + pk[1, l].astype(object) * s[l].astype(object)) % q
+        assert np.abs(np.array([int(x) if x < q // 2 else int(x) - q for x in P.limb_intt(v.astype(np.uint64), l)],
+                               dtype=np.float64)).max() <= 20, l
+
+
+def test_mul_scalar_add_sub(oracle, fx):
+    """Evaluator.Mul(ct, uint64): w mod T centred to (-T/2, T/2], then reduced per limb."""
+    _, P, _, load = fx
+    rec = load("mul_scalar.lmfx")
+    ct = std_ct(rec, "in")
+    L = ct.shape[1]
+    q = np.array(P.moduli[:L], dtype=object)[None, :, None]
+    i = 0
+    while f"w{i}" in rec:
+        w = int(rec[f"w{i}"][0])
+        s = np.array([int(oracle.lib.lo_centered_scalar(w, T_REF, m)) for m in P.moduli[:L]], dtype=object)[None, :, None]
+        assert np.array_equal((ct.astype(object) * s % q).astype(np.uint64), std_ct(rec, f"out{i}")), w
+        i += 1
+    assert i >= 2
+    assert np.array_equal((ct.astype(object) * 2 % q).astype(np.uint64), std_ct(rec, "add"))
+    assert np.array_equal(ct, std_ct(rec, "sub"))
+
+
+def test_mul_plain(oracle, fx):
+    _, P, _, load = fx
+    rec = load("mul_plain.lmfx")
+    assert np.array_equal(P.encode(rec["r"]), rec["plaintext"][0]), "Encode of raw u64 words (ligero.go:202-205)"
+    assert np.array_equal(P.mul_plain(std_ct(rec, "in"), rec["plaintext"][0]), std_ct(rec, "out")), \
+        "MulNew(ct, pt): the plaintext is multiplied by T (DESIGN.md section 4)"
+
+
+def test_rescale(oracle, fx):
+    _, P, _, load = fx
+    rec = load("rescale.lmfx")
+    ct = std_ct(rec, "in")
+    L = ct.shape[1]
+    assert np.array_equal(P.rescale(ct), std_ct(rec, "once")), "DivRoundByLastModulusNTT (SURVEY A.3)"
+    assert np.array_equal(P.rescale_to_level1(ct), std_ct(rec, "level1"))
+    s_in = int(rec["in.scale"][0])
+    assert int(rec["once.scale"][0]) == s_in * P.rescale_scale(L, L - 1) % T_REF, "Scale <- Scale * q_l^-1 mod T"
+    assert int(rec["level1.scale"][0]) == s_in * P.rescale_scale(L, 2) % T_REF
+
+
+def test_writeto_layout(oracle, fx):
+    """ct.WriteTo = head | per polynomial poly_head | per limb limb_head | raw LE limbs, and the recalled
+    framing (u64 counts after the MetaData block)."""
+    kind, P, _, load = fx
+    rec = load("writeto.lmfx")
+    ct = std_ct(rec, "ct")
+    blob = rec["bytes"].tobytes()
+    head, poly, limb = leaf_format(blob, ct)
+    assert P.ct_serialize(ct, (head, poly, limb)) == blob
+    md = rec["metadata_bytes"].tobytes()
+    nl, N = ct.shape[1], ct.shape[2]
+    assert head == md + (2).to_bytes(8, "little"), "head = MetaData | u64 polynomial count"
+    assert poly == nl.to_bytes(8, "little") and limb == N.to_bytes(8, "little"), "u64 limb count / u64 N"
+    if kind == "lattigo":
+        print("MetaData block:", md)  # the bytes host/fhe.cpp's MetaDataJSON has to reproduce
+
+
+def _inner_sum_inputs(P, rec):
+    mont = int(rec["keys_montgomery"][0])
+    keys = {}
+    i = 0
+    while f"key{i}" in rec:
+        keys[int(rec[f"key{i}.galois_element"][0])] = galois_key(rec, f"key{i}", P.moduli, mont)
+        i += 1
+    n = int(rec["n"][0])
+    gl = P.inner_sum_galois_elements(n)
+    assert set(gl) == set(keys), "Galois elements of InnerSum(ct, 1, n)"
+    return n, gl, [keys[g] for g in gl]
+
+
+@pytest.mark.parametrize("which", ["half", "full"])
+def test_inner_sum(oracle, fx, which):
+    """MulNew -> InnerSum(ct, 1, n) -> Rescale loop with Lattigo's own Galois keys: the hybrid key switch
+    (float64 correction v, ModDown floor convention) bit for bit."""
+    _, P, _, load = fx
+    rec = load(f"innersum_{P.N // 2 if which == 'half' else P.N}.lmfx")
+    n, gl, evks = _inner_sum_inputs(P, rec)
+    ct, pt = std_ct(rec, "in"), rec["plaintext"][0]
+    assert np.array_equal(P.inner_sum(P.mul_plain(ct, pt), n, evks), std_ct(rec, "inner_sum")), "InnerSum"
+    out = P.matrix_inner_sum(ct[None], pt, n, evks)[0]
+    assert np.array_equal(out, std_ct(rec, "out"))
+    sk = sk_of(P, rec)
+    assert int(P.decrypt(sk, out, 1, int(rec["out.scale"][0]))[0]) == int(rec["slot0"][0])
+
+
+def test_ring_switch(oracle, fx):
+    _, P, _, load = fx
+    rec = load("ringswitch.lmfx")
+    small = int(rec["logN_small"][0])
+    key = ringswitch_key(rec, "key", P.moduli, P.L, P.K, int(rec["keys_montgomery"][0]))
+    assert key.shape[0] == P.rs_num_digits(int(rec["key.shape"][2]) or 13)
+    ct = std_ct(rec, "in")
+    assert np.array_equal(P.ring_switch(ct, key, small), rec["out"][:, 0, :]), \
+        "ApplyEvaluationKey into the small ring (unsigned base-2^13 digits, sub-ring extraction)"
+
+
+def test_ct_ntt(oracle, fx):
+    _, P, prm, load = fx
+    rec = load("ct_ntt.lmfx")
+    S = 0
+    while f"in{S}" in rec:
+        S += 1
+    ins = np.stack([std_ct(rec, f"in{i}") for i in range(S)])
+    outs = np.stack([std_ct(rec, f"out{i}") for i in range(S)])
+    roots = prm["field_roots_forward"]
+    assert len(roots) == S
+    assert np.array_equal(P.ct_ntt(ins, S, roots), outs), "fhe.NTT on ciphertexts (fhe/ntt.go)"
+
+
+# ------------------------------------------------------------------ GPU: HIP path vs fixtures
+@pytest.mark.gpu
+def test_gpu_against_fixtures(oracle, fx):
+    """Every device stage on the fixture's inputs equals the fixture's outputs, through the C ABI."""
+    _, P, prm, load = fx
+    ctx = make_context(P)
+    try:
+        rec = load("mul_plain.lmfx")
+        got = ctx.mul_plain(ctx.upload(std_ct(rec, "in")[None]), rec["plaintext"][0]).download()[0]
+        assert np.array_equal(got, std_ct(rec, "out")), "lumen_mul_plain"
+
+        rec = load("rescale.lmfx")
+        ct = std_ct(rec, "in")
+        assert np.array_equal(ctx.rescale(ctx.upload(ct[None]), ct.shape[1] - 1).download()[0], std_ct(rec, "once"))
+        assert np.array_equal(ctx.rescale(ctx.upload(ct[None]), 2).download()[0], std_ct(rec, "level1"))
+
+        rec = load("writeto.lmfx")
+        ct = std_ct(rec, "ct")
+        blob = rec["bytes"].tobytes()
+        ctx.leaf_format_set(*leaf_format(blob, ct))
+        s = ctx.upload(ct[None])
+        assert ctx.ct_serialize(s) == blob, "lumen_ct_serialize"
+        assert ctx.leaf_digests(s)[0].tobytes() == oracle.sha256(blob), "lumen_leaf_digests = SHA-256(ct.WriteTo)"
+        ctx.leaf_format_set()
+
+        for name in (f"innersum_{P.N // 2}.lmfx", f"innersum_{P.N}.lmfx"):
+            rec = load(name)
+            n, gl, evks = _inner_sum_inputs(P, rec)
+            for g, e in zip(gl, evks):
+                ctx.load_galois_key(g, e)
+            ct, pt = std_ct(rec, "in"), rec["plaintext"][0]
+            inner = ctx.inner_sum(ctx.mul_plain(ctx.upload(ct[None]), pt), n).download()[0]
+            assert np.array_equal(inner, std_ct(rec, "inner_sum")), name
+            assert np.array_equal(ctx.matrix_inner_sum(ctx.upload(ct[None]), pt, n).download()[0], std_ct(rec, "out")), name
+
+        rec = load("ringswitch.lmfx")
+        small = int(rec["logN_small"][0])
+        key = ringswitch_key(rec, "key", P.moduli, P.L, P.K, int(rec["keys_montgomery"][0]))
+        ctx.load_ringswitch_key(small, key)
+        assert np.array_equal(ctx.ring_switch(ctx.upload(std_ct(rec, "in")[None]))[0], rec["out"][:, 0, :])
+
+        rec = load("encrypt.lmfx")
+        sk = sk_of(P, rec)
+        ctx.load_secret_key(sk)
+        from lumenos_amd import params as lp
+        ctx.encoder_set(lp.encoder_psi(T_REF, P.logN))
+        l1 = ctx.rescale(ctx.upload(std_ct(rec, "ciphertext")[None]), 2)
+        assert np.array_equal(ctx.decrypt(l1, P.N, P.rescale_scale(P.L, 2))[0], rec["values"]), "lumen_decrypt"
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ct_ntt_against_fixture(oracle, fx):
+    _, P, prm, load = fx
+    rec = load("ct_ntt.lmfx")
+    S = 0
+    while f"in{S}" in rec:
+        S += 1
+    ins = np.stack([std_ct(rec, f"in{i}") for i in range(S)])
+    outs = np.stack([std_ct(rec, f"out{i}") for i in range(S)])
+    ctx = make_context(P)
+    try:
+        ctx.field_set(prm["field_roots_forward"])
+        s = ctx.upload(ins)
+        ctx.ct_ntt(s, S)
+        assert np.array_equal(s.download(), outs), "lumen_ct_ntt = fhe.NTT"
+        n_mul = int(rec["mul_counter"][0])
+        if n_mul:
+            assert ctx.mul_counter() == n_mul, "ServerBFV.MulCounter"
+    finally:
+        ctx.close()

@@ -62,18 +62,54 @@ PMC_NAMES = {"ks_modup_ntt": "k_modup_ntt", "ks_moddown_ntt": "k_moddown_ntt", "
              "ks_intt_c1": "k_limb_ntt", "ks_intt_p": "k_limb_ntt"}
 
 
-def pmc_traffic(kernel, cfg):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command
-    (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied by tools/collect_pmc.py).
-    bench.py cannot collect hardware counters itself; null when no PMC summary is committed."""
+def pmc_table(cfg):
+    """The committed rocprofv3 PMC summary of this same command (tools/profile_bench.sh: separate
+    FETCH_SIZE / WRITE_SIZE / SQ passes, gfx950 corrections applied by tools/collect_pmc.py).  bench.py
+    cannot collect hardware counters itself.  The summary is stamped with the hash of the HIP sources it
+    was measured on: a different build gets None, not somebody else's counters."""
     path = os.path.join(ROOT, "profiles", f"pmc_traffic_{cfg}.json")
     if not os.path.exists(path):
         return None
     tab = json.load(open(path))
+    from lumenos_amd import _build
+    if tab.get("__source_hash__") != _build.source_hash():
+        return None
+    return tab
+
+
+def pmc_entry(tab, kernel):
+    if not tab:
+        return None
     for name, v in tab.items():
-        if name.startswith(PMC_NAMES.get(kernel, kernel)) and v.get("hbm_bytes_per_launch"):
-            return round(v["hbm_bytes_per_launch"])
+        if isinstance(v, dict) and name.startswith(PMC_NAMES.get(kernel, kernel)):
+            return v
     return None
+
+
+def algorithmic_bytes(job, name, launches, units):
+    """SURVEY 8d bytes of ALL launches of one profiled kernel family in a step (None: not tabulated)."""
+    N, L, K = job.N, job.L, job.K
+    LK, beta = L + K, (L + K - 1) // K
+    ct = lambda nl: 2 * nl * N * 8
+    if name in NTT_KERNELS:
+        return 16.0 * N * units                      # one limb transform: read + write N words
+    if name == "ks_mac":                             # per column: beta digits x LK limbs read, 2 x LK limbs written;
+        return units * (beta * LK + 2 * LK) * N * 8.0 + launches * 2 * beta * LK * N * 8.0  # + the key once per launch
+    if name == "ks_pack_v":                          # in place on the digit pairs: read + write
+        return None                                  # (units are columns of two different shapes: c1 and P limbs)
+    if name == "ct_axis_pass":                       # Encode: read cols + 1 ciphertexts, write S (all passes together)
+        return (job.cols + 1 + job.S) * float(ct(L))
+    if name == "mul_plain":
+        return units * 2.0 * ct(L)
+    if name == "rescale_coef":                       # per polynomial: read nl limbs, write 2
+        return units * (L + 2) * N * 8.0
+    if name == "leaf_sha256":
+        return units * float(ct(2))
+    return None
+
+
+NTT_KERNELS = ("ks_modup_ntt", "ks_moddown_ntt", "rescale_limb_ntt", "rescale_last_intt", "ks_intt_c1", "ks_intt_p",
+               "limb_ntt", "limb_intt", "rescale_intt", "rescale_ntt")
 
 
 class Job:
@@ -117,6 +153,54 @@ class Job:
         # column shards (input columns; encoded columns are sharded by the transform itself)
         self.col_lo, self.col_hi = self.cols * rank // world, self.cols * (rank + 1) // world
         ctx.sync()
+
+    # ---- host I/O of a prover run, measured by --include-io
+    def io_setup(self):
+        """Pinned host buffers (lumen_host_alloc): the input ciphertexts as the Go shim's stage() lays
+        them out, and room for the proof's ciphertexts; a clone context whose stream carries downloads
+        while the main context computes."""
+        from lumenos_amd.hip import pinned_empty
+        self.h_matrix = pinned_empty((self.cols, 2, self.L, self.N))
+        self.matrix.download_into(self.h_matrix)  # content: the synthetic matrix itself
+        self.h_r = pinned_empty((self.col_hi - self.col_lo, 2, 2, self.N))
+        self.h_z = pinned_empty((self.col_hi - self.col_lo, 2, 2, self.N))
+        self.h_q = pinned_empty((self.queries, 2, 2, self.N))
+        self.io_ctx = self.ctx.clone()
+
+    def step_io(self):
+        """One step including the PCIe legs a drop-in pays: upload of the input ciphertexts (12.9 GB at D),
+        download of MatR / MatZ / the queried columns (4.4 GB at D).  MatR crosses the link on the clone's
+        stream while MatZ is computed; the upload cannot overlap (Encode needs every column)."""
+        import threading
+        ctx = self.ctx
+        t = {}
+        t0 = time.perf_counter()
+        self.matrix.upload(self.h_matrix)
+        t["upload_s"] = time.perf_counter() - t0
+        mine = ctx.encode(self.matrix, self.zero_ct, RHO_INV)
+        lvl1 = ctx.rescale(mine, 2)
+        mine.free()
+        ctx.leaf_digests_begin(lvl1)
+        cols = self.matrix.slice(self.col_lo, self.col_hi - self.col_lo)
+        mat_r = ctx.matrix_inner_sum(cols, self.r_pt, self.rows)
+        ctx.sync()
+        th = threading.Thread(target=lambda: self.io_ctx.download_into(mat_r, self.h_r))
+        th.start()
+        mat_z = ctx.matrix_inner_sum(cols, self.b_pt, self.rows)
+        cols.free()
+        q = ctx.gather(lvl1, self.query_idx)
+        dig = ctx.leaf_digests_end()
+        nodes, root = ctx.merkle_build(dig)
+        ctx.sync()
+        t1 = time.perf_counter()
+        mat_z.download_into(self.h_z)
+        q.download_into(self.h_q)
+        th.join()
+        t["download_tail_s"] = time.perf_counter() - t1
+        t["total_s"] = time.perf_counter() - t0
+        for s in (q, mat_r, mat_z, lvl1):
+            s.free()
+        return t
 
     def step(self, dist=None):
         ctx = self.ctx
@@ -258,6 +342,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal only)")
+    ap.add_argument("--include-io", action="store_true",
+                    help="also time steps that upload the input ciphertexts from and download the proof's "
+                         "ciphertexts to pinned host memory (reported as io_inclusive_s; never `value`)")
     ap.add_argument("--ring-switch-logn", type=int, default=0,
                     help="BASELINE config 5: ring-switch MatR/MatZ to this ring degree (fhe/ring_switch.go)")
     args = ap.parse_args()
@@ -303,26 +390,57 @@ def main():
     sec_per_step = elapsed / args.steps
 
     # ---- dominant-kernel roofline: one more (untimed) step with HIP events around every launch
-    roofline, stages = None, None
+    roofline, stages, executed = None, None, None
     if not args.no_kernel_profile:
         job.ctx.prof_reset()
         job.ctx.prof_enable(True)
         job.step(dist)
         job.ctx.prof_enable(False)
         tab = {k: job.ctx.prof_read(k) for k in job.ctx.prof_names()}
-        stages = {k: {"ms": round(v[0], 3), "launches": v[1], "units": v[2]} for k, v in sorted(tab.items())}
-        ntt_kernels = {k: v for k, v in tab.items()
-                       if k in ("ks_modup_ntt", "ks_moddown_ntt", "rescale_limb_ntt", "rescale_last_intt",
-                                "ks_intt_c1", "ks_intt_p", "limb_ntt", "limb_intt")}
+        pmc = pmc_table(args.config)
+        stages = {}
+        for k, (ms, launches, units) in sorted(tab.items()):
+            e = {"ms": round(ms, 3), "launches": launches, "units": units}
+            ab = algorithmic_bytes(job, k, launches, units)
+            if ab and ms > 0:  # SURVEY 8d bytes / HIP-event time of the launches, against the 8 TB/s HBM peak
+                e["alg_gbps"] = round(ab / (ms * 1e-3) / 1e9, 1)
+                e["hbm_frac"] = round(ab / (ms * 1e-3) / 8e12, 4)
+            stages[k] = e
+        ntt_kernels = {k: v for k, v in tab.items() if k in NTT_KERNELS}
+        executed = sum(v[2] for v in ntt_kernels.values())
         if ntt_kernels:
             dom = max(ntt_kernels, key=lambda k: ntt_kernels[k][0])
             ms, launches, units = ntt_kernels[dom]
             alg_bytes_per_launch = 16.0 * job.N * units / launches  # 16*N B per limb transform
             achieved = alg_bytes_per_launch / (ms / launches * 1e-3) / 1e9
+            pe = pmc_entry(pmc, dom)
+            sq = (pe or {}).get("sq_per_launch") or {}
+            bfly = units / launches * job.N / 2 * job.log_n  # butterflies of one launch
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                        "traffic": pmc_traffic(dom, args.config),
-                        "avg_launch_ms": round(ms / launches, 4), "limb_ntts_per_launch": units // launches}
+                        "traffic": round(pe["hbm_bytes_per_launch"]) if pe and pe.get("hbm_bytes_per_launch") else None,
+                        "avg_launch_ms": round(ms / launches, 4), "limb_ntts_per_launch": units // launches,
+                        # what actually bounds the kernel: 64-bit modular butterflies on the VALU (no MFMA).  From
+                        # the committed SQ counters of this build (null if the profile is of another build):
+                        # fraction of SIMD cycles issuing VALU work, and wave-level VALU instructions per butterfly
+                        "valu_frac": round(pe["valu_busy_frac"], 4) if pe and pe.get("valu_busy_frac") else None,
+                        "valu_insts_per_butterfly": round(sq["SQ_INSTS_VALU"] * 64.0 / bfly, 2)
+                        if sq.get("SQ_INSTS_VALU") else None,
+                        "note": "VALU-bound integer kernel: the >= 50 % HBM target of north_star is not reachable at "
+                                "10 multiply-adds per 64-bit Shoup product; see DESIGN.md section 6"}
+    io = None
+    if args.include_io and world == 1:
+        job.io_setup()
+        job.step_io()  # warm-up: first touch of the bounce paths
+        runs = [job.step_io() for _ in range(max(1, args.steps))]
+        best = min(runs, key=lambda r: r["total_s"])
+        gb_in = job.cols * 2 * job.L * job.N * 8 / 1e9
+        gb_out = (2 * (job.col_hi - job.col_lo) + job.queries) * 4 * job.N * 8 / 1e9
+        io = {"io_inclusive_s": round(best["total_s"], 4), "upload_s": round(best["upload_s"], 4),
+              "download_tail_s": round(best["download_tail_s"], 4), "upload_GB": round(gb_in, 2),
+              "download_GB": round(gb_out, 2), "upload_GBps": round(gb_in / best["upload_s"], 1),
+              "staging": "pinned host buffers (lumen_host_alloc); MatR downloads on a clone context's stream "
+                         "under the MatZ inner product; input upload not overlapped (Encode needs all columns)"}
     if rank == 0:
         census = limb_ntt_census(job.rows, job.cols, job.L, job.K, job.log_n)
         out = {
@@ -343,11 +461,17 @@ def main():
                                    + (f" +ring-switch->LogN={args.ring_switch_logn}" if args.ring_switch_logn else ""),
                        "parallelism": f"columns sharded over {world} GPU(s); digest all-gather",
                        "baseline_ref": "BASELINE.md: reference Go/Lattigo CPU, m7i.8xlarge 32 vCPU"},
-            "limb_ntts_per_s": round(census / sec_per_step, 1),
-            "ct_ntts_per_s": round(census / sec_per_step / (2 * job.L), 1),
+            # limb transforms the device EXECUTES per step (sum of the NTT kernels' units: the rescale to level 1
+            # runs on coefficients, 14 transforms per polynomial instead of the reference's 75) ...
+            "limb_ntts_executed_per_s": round(executed * world / sec_per_step, 1) if executed else None,
+            # ... and the reference's own transform count for the same step (SURVEY 8d census) over the same time
+            "limb_ntts_reference_equiv_per_s": round(census / sec_per_step, 1),
+            "ct_ntts_reference_equiv_per_s": round(census / sec_per_step / (2 * job.L), 1),
             "roofline": roofline,
             "kernels": stages,
         }
+        if io:
+            out.update(io)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out))

@@ -127,6 +127,23 @@ int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *
                        uint32_t rho_inv, uint32_t rank, uint32_t world, lumen_set **encoded,
                        uint32_t *col_index, uint32_t *n_cols);
 
+/* ---- multi-GPU Commit, lane-sharded: the ciphertext-axis transform never mixes lanes, so rank g
+ * of W = 2^log_world encodes coefficients [g*N/W, (g+1)*N/W) of every limb of EVERY ciphertext (a "lane
+ * shard": a set whose limbs are N/W words wide), and owns whole ciphertexts of a contiguous block of
+ * columns everywhere else.  Per step and rank: two all-to-alls over xGMI, done by the host with RCCL on the
+ * sets' device pointers -- both layouts are ct-major, so every block that travels is a contiguous slice:
+ *     own input columns --lumen_lanes_split--> W blocks --all-to-all--> lane shard of all columns
+ *     --lumen_encode (on the lane shard, with the same slice of the one Enc(0))--> lane shard of the S
+ *     encoded columns --all-to-all--> W blocks of own encoded columns --lumen_lanes_assemble--> full width.
+ * A rank uploads 1/W of the matrix and no work is replicated.  Lane sets are accepted by create /
+ * destroy / slice / upload / download / fill_random / gather and lumen_encode only. */
+int lumen_set_create_lanes(lumen_ctx *ctx, uint32_t count, uint32_t num_limbs, uint32_t log_world, lumen_set **out);
+uint32_t lumen_set_log_world(const lumen_set *set);
+/* full-width columns [n] -> lane set of W*n ciphertexts, block g (lane ciphertexts [g*n, (g+1)*n)) for rank g */
+int lumen_lanes_split(lumen_ctx *ctx, const lumen_set *columns, uint32_t log_world, lumen_set **lanes);
+/* lane set of W*n ciphertexts, block g received from rank g -> full-width columns [n] */
+int lumen_lanes_assemble(lumen_ctx *ctx, const lumen_set *lanes, lumen_set **columns);
+
 /* ---- Evaluator.Rescale looped `for ct.Level() > target` (fhe/ligero.go:149-155,
  * 271-273, 331-333).  out is a new set with target_limbs limbs. */
 int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t target_limbs, lumen_set **out);
@@ -159,6 +176,11 @@ int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8_t *digests
  * and unmodified until _end, which waits and writes count*32 bytes.  One job in flight per context. */
 int lumen_leaf_digests_begin(lumen_ctx *ctx, const lumen_set *level1);
 int lumen_leaf_digests_end(lumen_ctx *ctx, uint8_t *digests);
+/* the same job ended without bringing the digests to the host: *dev_digests = count*32 bytes of device
+ * memory (valid until the next _begin), what an RCCL all-gather reads; and core.NewTree's root over
+ * digests that sit in device memory (the all-gathered leaves): only the root crosses PCIe */
+int lumen_leaf_digests_end_device(lumen_ctx *ctx, void **dev_digests);
+int lumen_merkle_root_device(lumen_ctx *ctx, const void *dev_leaf_digests, uint32_t n_leaves, uint8_t *root);
 /* core.NewTree over leaf digests (core/tree.go:113-163): nodes = all levels,
  * bottom-up, (returns node count through n_nodes); root: 32 bytes. */
 int lumen_merkle_build(lumen_ctx *ctx, const uint8_t *leaf_digests, uint32_t n_leaves,

@@ -9,6 +9,17 @@ LIB = os.path.join(CSRC, "liblumenos_hip.so")
 ARCH = "gfx950"
 
 
+def source_hash():
+    """SHA-256 over the HIP sources and headers: stamps profiles (PMC summaries) so that bench.py only
+    quotes hardware counters collected on the code it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

@@ -43,6 +43,10 @@ struct lm_galois_key {
 struct lumen_set {
     uint32_t count = 0;
     uint32_t nl = 0;
+    // lane shard (multi-GPU Encode): the set holds coefficients [rank * N >> logw, (rank + 1) * N >> logw)
+    // of every limb, i.e. limbs of N >> logw words.  0 for ordinary sets; only the lane entry points,
+    // upload / download / fill and destroy accept anything else.
+    uint32_t logw = 0;
     u64 *d = nullptr;
     size_t words = 0;
     bool owner = true;
@@ -79,6 +83,10 @@ struct lumen_ctx {
     hipStream_t stream = nullptr;  // where every entry point enqueues (may be swapped to stream2 internally)
     hipStream_t stream2 = nullptr; // second lane for independent column batches (key-switch pipeline)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // low-priority streams, one per lane, for the HBM-bound gadget product of a key switch: it runs in
+    // the gaps the VALU-bound transforms of the other lane leave (LUMEN_KS_OVERLAP, lm_keyswitch.hip)
+    hipStream_t stream_lo[2] = {nullptr, nullptr};
+    hipEvent_t ev_lo_a[2] = {nullptr, nullptr}, ev_lo_b[2] = {nullptr, nullptr};
     hipStream_t stream_aux = nullptr; // side jobs that overlap the main stream (leaf hashing)
     hipEvent_t ev_aux = nullptr;
     uint32_t aux_digests = 0;         // leaves of the lumen_leaf_digests_begin job in flight
@@ -134,6 +142,11 @@ struct lumen_ctx {
           d_scal(sh->d_scal), gkeys(sh->gkeys), ext(sh->ext) {}
 };
 
+// words of one ciphertext of a set (lane shards are narrower)
+static inline size_t lm_ctw(const lumen_ctx *ctx, const lumen_set *s);
+#define LM_FULL_WIDTH(ctx, set, what) \
+    LM_CHECK(ctx, (set)->logw == 0, "%s: lane-sharded set (1/%u of every limb) where a full-width set is required", what, 1u << (set)->logw)
+
 // first statement of every entry point that takes a context: serialise callers and select the
 // context's device for the calling thread (a fresh OS thread -- every cgo call may be one -- starts
 // on device 0)
@@ -158,6 +171,8 @@ static inline void lm_ext_put(lumen_ctx *ctx, const std::string &key, std::share
     LM_SHARED_LOCK(ctx);
     ctx->ext[key] = std::move(v);
 }
+
+static inline size_t lm_ctw(const lumen_ctx *ctx, const lumen_set *s) { return (size_t)2 * s->nl * (ctx->N >> s->logw); }
 
 // waits for every stream of the context (main, second lane, side jobs)
 void lm_sync_all(lumen_ctx *ctx);

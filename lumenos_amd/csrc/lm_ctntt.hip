@@ -428,10 +428,13 @@ __global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mo
 // table slot -> output position for that pass (the plan's own permutation when NULL)
 // keep_pos: for a sharded run, device table slot -> slot (or LM_NOSLOT) applied to the stores of the
 // pass BEFORE the final one: the slots the rank's final groups do not read are not written
+// logw: the sets are lane shards holding N >> logw coefficients of every limb (the transform never
+// mixes lanes, so a shard runs exactly the same plan on narrower ciphertexts)
 static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, const u64 *srcA,
                     uint32_t splitA, const u64 *srcB, u64 *tmp, u64 *out, uint32_t final_g0 = 0,
-                    uint32_t final_ng = 0, const uint32_t *final_pos = nullptr, const uint32_t *keep_pos = nullptr) {
-    const size_t ctw = (size_t)2 * nl * ctx->N;
+                    uint32_t final_ng = 0, const uint32_t *final_pos = nullptr, const uint32_t *keep_pos = nullptr,
+                    uint32_t logw = 0) {
+    const size_t ctw = (size_t)2 * nl * (ctx->N >> logw);
     const uint32_t P = (uint32_t)plan->dev.size();
     LM_CHECK(ctx, ctw % LM_CT_W == 0, "ciphertext width not a multiple of the lane tile");
     const u64 *cur = srcA;
@@ -449,7 +452,7 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
         a.group0 = final_pass && final_ng ? final_g0 : 0;
         a.scal = ctx->d_scal;
         a.gsize = d.gsize, a.total = d.total, a.nlayers = d.nlayers;
-        a.fieldN1 = ctx->fieldN + 1, a.logN = ctx->logN, a.nl = nl, a.ctw = ctw;
+        a.fieldN1 = ctx->fieldN + 1, a.logN = ctx->logN - logw, a.nl = nl, a.ctw = ctw; // logN: limb width of THESE sets
         const uint32_t ng = final_pass && final_ng ? final_ng : d.ngroups;
         dim3 grid((uint32_t)(ctw / LM_CT_W), ng);
         size_t lds = (size_t)d.gsize * LM_CT_W * sizeof(u64) + ((size_t)d.total + 3 * d.nlayers) * sizeof(uint32_t);
@@ -512,6 +515,7 @@ extern "C" int lumen_field_set(lumen_ctx *ctx, const uint64_t *roots_forward, ui
 extern "C" int lumen_ct_ntt(lumen_ctx *ctx, lumen_set *values, uint32_t size) {
     LM_CHECK(nullptr, ctx && values, "lumen_ct_ntt: NULL argument");
     LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, values, "lumen_ct_ntt");
     if (size <= 1 || values->count == 0) return 0; // ntt.go:22-23
     if (int rc = check_field(ctx, size)) return rc;
     LM_CHECK(ctx, values->count % size == 0, "len(values)=%u is not a multiple of size=%u", values->count, size);
@@ -541,14 +545,16 @@ extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint6
     const uint32_t cols = matrix->count, S = cols * rho_inv, nl = matrix->nl;
     LM_CHECK(ctx, cols > 0, "matrix is empty"); // core/code.go:4-6 panics on an empty row
     if (int rc = check_field(ctx, S)) return rc;
-    const size_t ctw = (size_t)2 * nl * ctx->N;
+    // a lane shard (matrix->logw > 0) encodes like the whole: every lane sees the same butterflies, and the
+    // zero ciphertext handed over is the same slice of the one Enc(0)
+    const size_t ctw = lm_ctw(ctx, matrix);
     // the single Enc(0) of code.go:15-22, broadcast to slots cols..S-1 by the first pass
     u64 *dzero = (u64 *)lm_scratch(ctx, "zero_ct", ctw * sizeof(u64));
     if (!dzero) return 1;
     LM_HIP(ctx, hipMemcpyAsync(dzero, zero_ct, ctw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // zero_ct is caller memory
     lumen_set *out = nullptr;
-    if (int rc = lumen_set_create(ctx, S, nl, &out)) return rc;
+    if (int rc = lumen_set_create_lanes(ctx, S, nl, matrix->logw, &out)) return rc;
     lm_set_guard og(ctx, out);
     Plan *plan = nullptr;
     if (int rc = get_plan(ctx, S, S, &plan)) return rc;
@@ -561,7 +567,8 @@ extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint6
             tmp = (u64 *)lm_scratch(ctx, "ct_tmp", out->words * sizeof(u64));
             if (!tmp) return 1;
         }
-        if (int rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d)) return rc;
+        if (int rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d, 0, 0, nullptr, nullptr, matrix->logw))
+            return rc;
     }
     *encoded = og.release();
     return 0;
@@ -575,6 +582,7 @@ extern "C" int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const
                                   uint32_t *col_index, uint32_t *n_cols) {
     LM_CHECK(nullptr, ctx && matrix && zero_ct && encoded && col_index && n_cols, "lumen_encode_shard: NULL argument");
     LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, matrix, "lumen_encode_shard");
     LM_CHECK(ctx, world >= 1 && rank < world, "rank %u out of range for world %u", rank, world);
     LM_CHECK(ctx, rho_inv >= 1, "rho_inv must be >= 1");
     const uint32_t cols = matrix->count, S = cols * rho_inv, nl = matrix->nl;
@@ -620,5 +628,68 @@ extern "C" int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const
     if (g1 > g0)
         if (int rc = run_plan(ctx, plan, S, nl, matrix->d, cols, dzero, tmp, out->d, g0, g1 - g0, dpos, dkeep)) return rc;
     *encoded = og.release();
+    return 0;
+}
+
+
+// ---- multi-GPU exchange: lane-sharded <-> column-sharded.  Rank g of W = 2^logw holds
+// coefficients [g * N/W, (g+1) * N/W) of every limb of EVERY ciphertext during Encode, and whole
+// ciphertexts of ITS columns everywhere else.  Both layouts are ct-major, so the blocks an all-to-all
+// moves are contiguous slices (lumen_set_slice + lumen_set_device_ptr): the library only has to cut a
+// full-width set into W lane blocks and to put W lane blocks back together.
+//   split:    full [n][2][nl][N]          -> lanes [W][n][2][nl][N/W]   (block g goes to rank g)
+//   assemble: lanes [W][n][2][nl][N/W]    -> full [n][2][nl][N]         (block g came from rank g)
+__global__ __launch_bounds__(256) void k_lanes_move(const u64 *__restrict__ src, u64 *__restrict__ dst, uint32_t n,
+                                                    uint32_t limbs2 /* 2 * nl */, uint32_t logN, uint32_t logw,
+                                                    int assemble) {
+    // one 16-byte vector per thread; index over the full-width layout [ct][limb][coef / 2]
+    const size_t total = ((size_t)n * limbs2) << (logN - 1);
+    const uint32_t lognw = logN - logw;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = v << 1;                       // first coefficient index in the full layout
+        const uint32_t coef = (uint32_t)(i & (((size_t)1 << logN) - 1));
+        const size_t row = i >> logN;                  // ct * limbs2 + limb
+        const uint32_t g = coef >> lognw, c = coef & ((1u << lognw) - 1);
+        const size_t lane = (((size_t)g * n * limbs2 + row) << lognw) + c;
+        const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(src + (assemble ? lane : i));
+        ulonglong2 *d = reinterpret_cast<ulonglong2 *>(dst + (assemble ? i : lane));
+        *d = *s;
+    }
+}
+
+extern "C" int lumen_lanes_split(lumen_ctx *ctx, const lumen_set *columns, uint32_t log_world, lumen_set **lanes) {
+    LM_CHECK(nullptr, ctx && columns && lanes, "lumen_lanes_split: NULL argument");
+    LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, columns, "lumen_lanes_split");
+    LM_CHECK(ctx, log_world >= 1, "lumen_lanes_split: a world of one rank has nothing to split");
+    lumen_set *o = nullptr;
+    if (int rc = lumen_set_create_lanes(ctx, columns->count << log_world, columns->nl, log_world, &o)) return rc;
+    lm_set_guard og(ctx, o);
+    if (columns->words) {
+        lm_prof_scope ps(ctx, "lanes_split", columns->count);
+        hipLaunchKernelGGL(k_lanes_move, dim3(4096), dim3(256), 0, ctx->stream, columns->d, o->d, columns->count,
+                           2 * columns->nl, ctx->logN, log_world, 0);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    *lanes = og.release();
+    return 0;
+}
+
+extern "C" int lumen_lanes_assemble(lumen_ctx *ctx, const lumen_set *lanes, lumen_set **columns) {
+    LM_CHECK(nullptr, ctx && lanes && columns, "lumen_lanes_assemble: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, lanes->logw >= 1, "lumen_lanes_assemble: the set is not lane-sharded");
+    const uint32_t W = 1u << lanes->logw;
+    LM_CHECK(ctx, lanes->count % W == 0, "lumen_lanes_assemble: %u lane ciphertexts are not %u equal blocks", lanes->count, W);
+    lumen_set *o = nullptr;
+    if (int rc = lumen_set_create(ctx, lanes->count / W, lanes->nl, &o)) return rc;
+    lm_set_guard og(ctx, o);
+    if (o->words) {
+        lm_prof_scope ps(ctx, "lanes_assemble", o->count);
+        hipLaunchKernelGGL(k_lanes_move, dim3(4096), dim3(256), 0, ctx->stream, lanes->d, o->d, o->count, 2 * o->nl,
+                           ctx->logN, lanes->logw, 1);
+        LM_HIP(ctx, hipGetLastError());
+    }
+    *columns = og.release();
     return 0;
 }

@@ -57,6 +57,8 @@ lm_shared::~lm_shared() {
 void lm_sync_all(lumen_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+    for (int i = 0; i < 2; i++)
+        if (ctx->stream_lo[i]) hipStreamSynchronize(ctx->stream_lo[i]);
     if (ctx->stream_aux) hipStreamSynchronize(ctx->stream_aux);
 }
 
@@ -261,6 +263,11 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
             if (ctx->io_host[i]) hipHostFree(ctx->io_host[i]);
             if (ctx->ev_io[i]) hipEventDestroy(ctx->ev_io[i]);
         }
+        for (int i = 0; i < 2; i++) {
+            if (ctx->ev_lo_a[i]) hipEventDestroy(ctx->ev_lo_a[i]);
+            if (ctx->ev_lo_b[i]) hipEventDestroy(ctx->ev_lo_b[i]);
+            if (ctx->stream_lo[i]) hipStreamDestroy(ctx->stream_lo[i]);
+        }
         if (ctx->ev_stage) hipEventDestroy(ctx->ev_stage);
         if (ctx->ev_aux) hipEventDestroy(ctx->ev_aux);
         if (ctx->stream_aux) hipStreamDestroy(ctx->stream_aux);
@@ -288,13 +295,21 @@ extern "C" uint64_t lumen_mul_counter(const lumen_ctx *ctx) { return ctx ? ctx->
 
 // ------------------------------------------------------------------ sets
 extern "C" int lumen_set_create(lumen_ctx *ctx, uint32_t count, uint32_t num_limbs, lumen_set **out) {
+    return lumen_set_create_lanes(ctx, count, num_limbs, 0, out);
+}
+
+extern "C" int lumen_set_create_lanes(lumen_ctx *ctx, uint32_t count, uint32_t num_limbs, uint32_t log_world,
+                                      lumen_set **out) {
     LM_CHECK(nullptr, ctx && out, "lumen_set_create: NULL argument");
     LM_ENTER(ctx);
     LM_CHECK(ctx, num_limbs >= 1 && num_limbs <= ctx->L, "num_limbs %u out of range [1,%u]", num_limbs, ctx->L);
+    LM_CHECK(ctx, log_world <= 6 && (ctx->N >> log_world) >= 64, "a lane shard of 1/%u of N = %u is narrower than 64 coefficients",
+             1u << log_world, ctx->N);
     lumen_set *s = new lumen_set();
     s->count = count;
     s->nl = num_limbs;
-    s->words = (size_t)count * 2 * num_limbs * ctx->N;
+    s->logw = log_world;
+    s->words = (size_t)count * 2 * num_limbs * (ctx->N >> log_world);
     s->home = ctx;
     if (s->words) {
         const size_t bytes = s->words * sizeof(u64);
@@ -357,9 +372,10 @@ extern "C" int lumen_set_slice(lumen_ctx *ctx, const lumen_set *set, uint32_t fi
     LM_ENTER(ctx);
     LM_CHECK(ctx, (uint64_t)first + n <= set->count, "slice [%u,%u) exceeds set of %u", first, first + n, set->count);
     lumen_set *v = new lumen_set();
-    const size_t ctw = (size_t)2 * set->nl * ctx->N;
+    const size_t ctw = lm_ctw(ctx, set);
     v->count = n;
     v->nl = set->nl;
+    v->logw = set->logw;
     v->d = set->d + (size_t)first * ctw;
     v->words = (size_t)n * ctw;
     v->owner = false;
@@ -369,6 +385,7 @@ extern "C" int lumen_set_slice(lumen_ctx *ctx, const lumen_set *set, uint32_t fi
 
 extern "C" uint32_t lumen_set_count(const lumen_set *set) { return set ? set->count : 0; }
 extern "C" uint32_t lumen_set_limbs(const lumen_set *set) { return set ? set->nl : 0; }
+extern "C" uint32_t lumen_set_log_world(const lumen_set *set) { return set ? set->logw : 0; }
 extern "C" void *lumen_set_device_ptr(const lumen_set *set) { return set ? set->d : nullptr; }
 
 // ---- host <-> device staging.  A pinned host buffer (lumen_host_alloc: what the Go
@@ -426,7 +443,7 @@ extern "C" int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, 
     LM_CHECK(nullptr, ctx && set && host, "lumen_set_upload: NULL argument");
     LM_ENTER(ctx);
     LM_CHECK(ctx, (uint64_t)first + n <= set->count, "upload range [%u,%u) exceeds set of %u", first, first + n, set->count);
-    const size_t ctw = (size_t)2 * set->nl * ctx->N, bytes = (size_t)n * ctw * sizeof(u64);
+    const size_t ctw = lm_ctw(ctx, set), bytes = (size_t)n * ctw * sizeof(u64);
     char *dst = (char *)(set->d + (size_t)first * ctw);
     if (bytes <= ((size_t)1 << 20) || host_is_pinned(host)) {
         LM_HIP(ctx, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -450,7 +467,7 @@ extern "C" int lumen_set_download(lumen_ctx *ctx, const lumen_set *set, uint32_t
     LM_CHECK(nullptr, ctx && set && host, "lumen_set_download: NULL argument");
     LM_ENTER(ctx);
     LM_CHECK(ctx, (uint64_t)first + n <= set->count, "download range [%u,%u) exceeds set of %u", first, first + n, set->count);
-    const size_t ctw = (size_t)2 * set->nl * ctx->N, bytes = (size_t)n * ctw * sizeof(u64);
+    const size_t ctw = lm_ctw(ctx, set), bytes = (size_t)n * ctw * sizeof(u64);
     const char *src = (const char *)(set->d + (size_t)first * ctw);
     if (bytes <= ((size_t)1 << 20) || host_is_pinned(host)) {
         LM_HIP(ctx, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -496,7 +513,7 @@ extern "C" int lumen_set_fill_random(lumen_ctx *ctx, lumen_set *set, uint64_t se
     LM_ENTER(ctx);
     if (!set->words) return 0;
     hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, ctx->stream, set->d, set->words,
-                       ctx->N, set->nl, ctx->mods, (u64)seed);
+                       ctx->N >> set->logw, set->nl, ctx->mods, (u64)seed);
     LM_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -625,6 +625,7 @@ static int decrypt_phase_t(lumen_ctx *ctx, const u64 *ct, const tw_t *sk, u64 *p
 extern "C" int lumen_decrypt(lumen_ctx *ctx, const lumen_set *set, uint64_t scale, uint32_t nvalues, uint64_t *values) {
     LM_CHECK(nullptr, ctx && set && values, "lumen_decrypt: NULL argument");
     LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, set, "lumen_decrypt");
     LM_CHECK(ctx, set->nl >= 1 && set->nl <= 2, "lumen_decrypt takes ciphertexts of one or two limbs (have %u)", set->nl);
     LM_CHECK(ctx, nvalues >= 1 && nvalues <= ctx->N, "nvalues=%u out of range [1, N]", nvalues);
     const std::shared_ptr<SkTable> sk_hold = lm_ext_get<SkTable>(ctx, "secret_key");

@@ -139,6 +139,7 @@ extern "C" int lumen_ct_serialize(lumen_ctx *ctx, const lumen_set *set, uint32_t
                                   size_t cap) {
     LM_CHECK(nullptr, ctx && set && (out || !n), "lumen_ct_serialize: NULL argument");
     LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, set, "lumen_ct_serialize");
     LM_CHECK(ctx, (uint64_t)first + n <= set->count, "range [%u,%u) exceeds set of %u", first, first + n, set->count);
     const LeafFormat f = current_format(ctx, set->nl);
     const uint32_t N = ctx->N, nl = set->nl;
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(64) void k_leaf_sha256(const u64 *__restrict__ set,
 extern "C" int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8_t *digests) {
     LM_CHECK(nullptr, ctx && level1 && digests, "lumen_leaf_digests: NULL argument");
     LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, level1, "lumen_leaf_digests");
     if (!level1->count) return 0;
     uint8_t *dd = (uint8_t *)lm_scratch(ctx, "digests", (size_t)level1->count * 32);
     const leaf_fmt_t *fmt = nullptr;
@@ -274,6 +276,7 @@ extern "C" int lumen_leaf_digests(lumen_ctx *ctx, const lumen_set *level1, uint8
 extern "C" int lumen_leaf_digests_begin(lumen_ctx *ctx, const lumen_set *level1) {
     LM_CHECK(nullptr, ctx && level1, "lumen_leaf_digests_begin: NULL argument");
     LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, level1, "lumen_leaf_digests_begin");
     LM_CHECK(ctx, !ctx->aux_digests, "a lumen_leaf_digests_begin job is already in flight");
     if (!level1->count) return 0;
     const size_t bytes = (size_t)level1->count * 32;
@@ -315,6 +318,65 @@ extern "C" int lumen_leaf_digests_end(lumen_ctx *ctx, uint8_t *digests) {
     ctx->aux_lo = ctx->aux_hi = nullptr;
     LM_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
     memcpy(digests, ctx->aux_host, (size_t)n * 32);
+    return 0;
+}
+
+// ---- the same on digests that already sit in device memory (multi-GPU: the all-gathered leaf digests):
+// one launch per level, one thread per parent; only the 32-byte root crosses PCIe
+__global__ void k_merkle_level(const uint8_t *__restrict__ cur, uint8_t *__restrict__ next, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, m = (n + 1) / 2;
+    if (i >= m) return;
+    const uint32_t l = 2 * i, r = 2 * i + 1 < n ? 2 * i + 1 : 2 * i; // an unpaired last node is hashed with itself
+    u32 h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    u32 w[16];
+    const u32 *pl = reinterpret_cast<const u32 *>(cur + (size_t)l * 32), *pr = reinterpret_cast<const u32 *>(cur + (size_t)r * 32);
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = bswap32(pl[k]), w[8 + k] = bswap32(pr[k]);
+    sha256_compress(h, w, c_k256);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = 0;
+    w[0] = 0x80000000u, w[15] = 512;
+    sha256_compress(h, w, c_k256);
+    u32 *o = reinterpret_cast<u32 *>(next + (size_t)i * 32);
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = bswap32(h[k]);
+}
+
+extern "C" int lumen_merkle_root_device(lumen_ctx *ctx, const void *dev_leaf_digests, uint32_t n_leaves, uint8_t *root) {
+    LM_CHECK(nullptr, ctx && dev_leaf_digests && root, "lumen_merkle_root_device: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, n_leaves > 0, "cannot build a tree over zero leaves");
+    size_t total = 0;
+    for (uint32_t n = n_leaves; n > 1; n = (n + 1) / 2) total += (n + 1) / 2;
+    uint8_t *buf = (uint8_t *)lm_scratch(ctx, "merkle_nodes", std::max<size_t>(total, 1) * 32);
+    if (!buf) return 1;
+    const uint8_t *cur = (const uint8_t *)dev_leaf_digests;
+    uint8_t *next = buf;
+    for (uint32_t n = n_leaves; n > 1; n = (n + 1) / 2) {
+        const uint32_t m = (n + 1) / 2;
+        hipLaunchKernelGGL(k_merkle_level, dim3((m + 63) / 64), dim3(64), 0, ctx->stream, cur, next, n);
+        LM_HIP(ctx, hipGetLastError());
+        cur = next;
+        next += (size_t)m * 32;
+    }
+    LM_HIP(ctx, hipMemcpyAsync(root, cur, 32, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ends the lumen_leaf_digests_begin job WITHOUT bringing the digests to the host: *dev_digests points
+// at count * 32 bytes of device memory, valid until the next lumen_leaf_digests_begin on this context
+// (the buffer an RCCL all-gather reads)
+extern "C" int lumen_leaf_digests_end_device(lumen_ctx *ctx, void **dev_digests) {
+    LM_CHECK(nullptr, ctx && dev_digests, "lumen_leaf_digests_end_device: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, ctx->aux_digests, "no lumen_leaf_digests_begin job in flight");
+    ctx->aux_digests = 0;
+    ctx->aux_lo = ctx->aux_hi = nullptr;
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+    auto it = ctx->scratch.find("digests_async");
+    LM_CHECK(ctx, it != ctx->scratch.end() && it->second.first, "digest buffer missing");
+    *dev_digests = it->second.first;
     return 0;
 }
 
@@ -387,7 +449,7 @@ extern "C" int lumen_gather(lumen_ctx *ctx, const lumen_set *src, const uint32_t
     for (uint32_t i = 0; i < n; i++)
         LM_CHECK(ctx, idx[i] < src->count, "gather index %u out of range (%u ciphertexts)", idx[i], src->count);
     lumen_set *o = nullptr;
-    if (int rc = lumen_set_create(ctx, n, src->nl, &o)) return rc;
+    if (int rc = lumen_set_create_lanes(ctx, n, src->nl, src->logw, &o)) return rc;
     lm_set_guard og(ctx, o);
     if (n) {
         uint32_t *didx = (uint32_t *)lm_scratch(ctx, "gather_idx", (size_t)n * 4);
@@ -396,7 +458,7 @@ extern "C" int lumen_gather(lumen_ctx *ctx, const lumen_set *src, const uint32_t
         memcpy(hidx, idx, (size_t)n * 4);
         LM_HIP(ctx, hipMemcpyAsync(didx, hidx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         LM_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
-        const size_t ctw2 = (size_t)src->nl * ctx->N; // 2*nl*N u64 = nl*N ulonglong2
+        const size_t ctw2 = lm_ctw(ctx, src) / 2; // words of a ciphertext, in 16-byte units
         hipLaunchKernelGGL(k_gather, dim3(32, n), dim3(256), 0, ctx->stream, src->d, o->d, didx, ctw2);
         LM_HIP(ctx, hipGetLastError());
     }

@@ -125,5 +125,6 @@ int lm_launch_ntt(lumen_ctx *ctx, u64 *d, uint32_t npoly, const lm_modmap &map, 
 extern "C" int lumen_set_ntt(lumen_ctx *ctx, lumen_set *set, int inverse) {
     LM_CHECK(nullptr, ctx && set, "lumen_set_ntt: NULL argument");
     LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, set, "lumen_set_ntt");
     return lm_launch_ntt(ctx, set->d, set->count * 2, lm_map_q(set->nl), inverse != 0);
 }

@@ -243,6 +243,26 @@ __device__ __forceinline__ u64 lm_reduce_s(u64 x, u64 q, u64 nq, u64 qinv64) {
     return lm_csub(r, q);
 }
 
+// (2x + 3q) - s, the difference branch of the forward butterfly, as exactly three instructions.  Left
+// to the compiler the expression is re-associated into (3q - s) + 2x with the wave-uniform 3q as the
+// minuend: v_subb_co_u32 cannot take an SGPR there, so every butterfly pays a v_mov of q3's upper word
+// (94 of them in k_modup_ntt<14>) -- and each VALU instruction of these kernels costs its SIMD about
+// five cycles whatever it does (tools/ubench_bfly.hip).  q3 = 3q lives in an SGPR pair.
+__device__ __forceinline__ u64 lm_bfly_diff(u64 x, u64 q3, u64 s) {
+#if LM_ASM_SHOUP
+    u32 lo, hi;
+    asm("v_lshl_add_u64 " LM_VP(0, 1) ", %[x], 1, %[q3]\n\t"
+        "v_sub_co_u32_e32 %[lo], vcc, " LM_V(0) ", %[slo]\n\t"
+        "v_subb_co_u32_e32 %[hi], vcc, " LM_V(1) ", %[shi], vcc"
+        : [lo] "=&v"(lo), [hi] "=v"(hi)
+        : [x] "v"(x), [q3] "s"(q3), [slo] "v"((u32)s), [shi] "v"((u32)(s >> 32))
+        : LM_V(0), LM_V(1), "vcc");
+    return ((u64)hi << 32) | lo;
+#else
+    return ((x << 1) + q3) - s;
+#endif
+}
+
 struct lm_qc { // per-modulus constants of the lazy butterflies
     u64 q, nq, q3, qinv64;
 };
@@ -269,10 +289,24 @@ __device__ __forceinline__ tw_t lm_tw_load(const tw_t *__restrict__ tw, uint32_t
     return tw[idx];
 }
 
-// R forward stages on e[0 .. 2^R), first stage index s0, block index blk
+// Twiddles of R forward stages starting at stage s0 for block blk: W[(1 << st) - 1 + g], g < 2^st.
+// Loaded apart from the stages that use them so that a pass can fetch the NEXT work item's (or the next
+// pass's) twiddles before it starts computing: the per-lane table reads of the last stages are L2 round
+// trips of about a thousand cycles, and with four waves per SIMD nothing else hides them.
 template <int R, bool UW>
-__device__ __forceinline__ void lm_fwd_stages(u64 *e, uint32_t s0, uint32_t blk, const tw_t *__restrict__ tw,
-                                              const lm_qc &c) {
+struct lm_twset {
+    tw_t w[(1 << R) - 1];
+    __device__ __forceinline__ void load(const tw_t *__restrict__ tw, uint32_t s0, uint32_t blk) {
+#pragma unroll
+        for (int st = 0; st < R; st++)
+#pragma unroll
+            for (int g = 0; g < (1 << st); g++) w[(1 << st) - 1 + g] = lm_tw_load<UW>(tw, ((1u << s0) << st) + (blk << st) + g);
+    }
+};
+
+// R forward stages on e[0 .. 2^R) with preloaded twiddles
+template <int R, bool UW>
+__device__ __forceinline__ void lm_fwd_stages(u64 *e, const lm_twset<R, UW> &T, const lm_qc &c) {
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int span = (1 << R) >> st, half = span >> 1;
@@ -281,7 +315,7 @@ __device__ __forceinline__ void lm_fwd_stages(u64 *e, uint32_t s0, uint32_t blk,
         u64 sum[(1 << R) / 2];
 #pragma unroll
         for (int g = 0; g < (1 << st); g++) {
-            const tw_t W = lm_tw_load<UW>(tw, ((1u << s0) << st) + (blk << st) + g);
+            const tw_t W = T.w[(1 << st) - 1 + g];
 #pragma unroll
             for (int k = 0; k < half; k++)
                 sum[g * half + k] = lm_shoup3<UW>(e[g * span + k + half], W.w, W.wp, c.nq, e[g * span + k]);
@@ -291,7 +325,7 @@ __device__ __forceinline__ void lm_fwd_stages(u64 *e, uint32_t s0, uint32_t blk,
 #pragma unroll
             for (int k = 0; k < half; k++) {
                 u64 &x = e[g * span + k];
-                e[g * span + k + half] = ((x << 1) + c.q3) - sum[g * half + k];
+                e[g * span + k + half] = lm_bfly_diff(x, c.q3, sum[g * half + k]);
                 x = sum[g * half + k];
             }
     }
@@ -367,10 +401,15 @@ __device__ __forceinline__ void lm_wave_sync() {
 // Loader: u64 operator()(uint32_t i) -> coefficient i in [0, 7q)
 // Storer: void operator()(uint32_t i0, const u64 *v, int count) -> `count` consecutive lazy
 //         results (values < (3*logN+7)*q) starting at coefficient i0
+#ifndef LM_TW_PREFETCH
+#define LM_TW_PREFETCH 1 // fetch the next work item's twiddles before computing the current one
+#endif
 template <int LOGN, int R, bool CROSS, class Loader>
 __device__ __forceinline__ void lm_fwd_first(u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Loader &ld) {
     constexpr uint32_t log_tl = LOGN - R, items = 1u << log_tl, NT = lm_nthreads(LOGN);
     constexpr uint32_t reps = items / NT ? items / NT : 1;
+    lm_twset<R, true> T;
+    T.load(tw, 0, 0);
 #pragma unroll 1
     for (uint32_t m = 0; m < reps; m++) {
         const uint32_t w = tid + m * NT;
@@ -378,18 +417,23 @@ __device__ __forceinline__ void lm_fwd_first(u64 *s, const tw_t *tw, const lm_qc
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = ld(w + ((uint32_t)k << log_tl));
-        lm_fwd_stages<R, true>(e, 0, 0, tw, c);
+        lm_fwd_stages<R, true>(e, T, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(w + ((uint32_t)k << log_tl))] = e[k];
     }
 }
 
+// the wave-local passes: D::reps work items per lane; the twiddles of item m+1 are requested before
+// item m is computed (two sets alive: (2^R - 1) * 4 VGPRs each when they are per-lane)
 template <int LOGN, int R, int S0>
 __device__ __forceinline__ void lm_fwd_mid(u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid) {
     constexpr uint32_t log_tl = LOGN - S0 - R;
+    constexpr bool UW = log_tl >= 6;
     using D = lm_deal<LOGN, R>;
     if (!D::valid(tid)) return;
-#pragma unroll 1
+    lm_twset<R, UW> T[2];
+    T[0].load(tw, S0, D::local(tid, 0) >> log_tl);
+#pragma unroll
     for (uint32_t m = 0; m < D::reps; m++) {
         const uint32_t w = D::local(tid, m);
         const uint32_t blk = w >> log_tl, off = w & ((1u << log_tl) - 1);
@@ -397,7 +441,9 @@ __device__ __forceinline__ void lm_fwd_mid(u64 *s, const tw_t *tw, const lm_qc &
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_tl))];
-        lm_fwd_stages<R, (log_tl >= 6)>(e, S0, blk, tw, c);
+        if (LM_TW_PREFETCH && m + 1 < D::reps) T[(m + 1) & 1].load(tw, S0, D::local(tid, m + 1) >> log_tl);
+        if (!LM_TW_PREFETCH && m) T[m & 1].load(tw, S0, blk);
+        lm_fwd_stages<R, UW>(e, T[m & 1], c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_tl))] = e[k];
     }
@@ -408,14 +454,18 @@ __device__ __forceinline__ void lm_fwd_last(const u64 *s, const tw_t *tw, const 
     constexpr uint32_t s0 = LOGN - R;
     using D = lm_deal<LOGN, R>;
     if (!D::valid(tid)) return;
-#pragma unroll 1
+    lm_twset<R, false> T[2];
+    T[0].load(tw, s0, D::local(tid, 0));
+#pragma unroll
     for (uint32_t m = 0; m < D::reps; m++) {
         const uint32_t w = D::local(tid, m);
         const uint32_t base = w << R;
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + k)];
-        lm_fwd_stages<R, false>(e, s0, w, tw, c);
+        if (LM_TW_PREFETCH && m + 1 < D::reps) T[(m + 1) & 1].load(tw, s0, D::local(tid, m + 1));
+        if (!LM_TW_PREFETCH && m) T[m & 1].load(tw, s0, w);
+        lm_fwd_stages<R, false>(e, T[m & 1], c);
         st(base, e, 1 << R);
     }
 }

@@ -242,6 +242,7 @@ int lm_rescale_polys(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint
 extern "C" int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t target_limbs, lumen_set **out) {
     LM_CHECK(nullptr, ctx && in && out, "lumen_rescale: NULL argument");
     LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, in, "lumen_rescale");
     LM_CHECK(ctx, target_limbs >= 1 && target_limbs <= in->nl, "target_limbs %u out of range [1,%u]",
              target_limbs, in->nl);
     lumen_set *o = nullptr;

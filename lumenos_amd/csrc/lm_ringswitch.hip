@@ -236,6 +236,7 @@ static int ring_switch_batch(lumen_ctx *ctx, RsKey *rk, const lm_ks_view &kv, co
 extern "C" int lumen_ring_switch(lumen_ctx *ctx, const lumen_set *in, uint64_t *out) {
     LM_CHECK(nullptr, ctx && in && out, "lumen_ring_switch: NULL argument");
     LM_ENTER(ctx);
+    LM_FULL_WIDTH(ctx, in, "lumen_ring_switch");
     const std::shared_ptr<RsKey> rk_hold = lm_ext_get<RsKey>(ctx, "ringswitch_key");
     LM_CHECK(ctx, rk_hold, "no ring-switch key loaded (lumen_load_ringswitch_key)");
     RsKey *rk = rk_hold.get();

@@ -48,6 +48,12 @@ SYMBOLS = {
     "lumen_sync": (C.c_int, [_vp]),
     "lumen_mul_counter": (C.c_uint64, [_vp]),
     "lumen_set_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vpp]),
+    "lumen_set_create_lanes": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vpp]),
+    "lumen_set_log_world": (C.c_uint32, [_vp]),
+    "lumen_lanes_split": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
+    "lumen_lanes_assemble": (C.c_int, [_vp, _vp, _vpp]),
+    "lumen_leaf_digests_end_device": (C.c_int, [_vp, _vpp]),
+    "lumen_merkle_root_device": (C.c_int, [_vp, _vp, C.c_uint32, _u8p]),
     "lumen_set_destroy": (None, [_vp, _vp]),
     "lumen_set_count": (C.c_uint32, [_vp]),
     "lumen_set_limbs": (C.c_uint32, [_vp]),
@@ -153,10 +159,19 @@ class DeviceSet:
         lib = ctx.lib
         self.count = lib.lumen_set_count(handle)
         self.nl = lib.lumen_set_limbs(handle)
+        self.log_world = lib.lumen_set_log_world(handle)  # > 0: a lane shard, limbs of N >> log_world words
 
     @property
     def shape(self):
-        return (self.count, 2, self.nl, self.ctx.N)
+        return (self.count, 2, self.nl, self.ctx.N >> self.log_world)
+
+    @property
+    def device_ptr(self):
+        return self.ctx.lib.lumen_set_device_ptr(self.h)
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape)) * 8
 
     def upload(self, host, first=0):
         host = np.ascontiguousarray(host, dtype=np.uint64)
@@ -167,9 +182,16 @@ class DeviceSet:
 
     def download(self, first=0, n=None):
         n = self.count - first if n is None else n
-        out = np.empty((n, 2, self.nl, self.ctx.N), dtype=np.uint64)
+        out = np.empty((n,) + self.shape[1:], dtype=np.uint64)
         if n:
             self.ctx._ck(self.ctx.lib.lumen_set_download(self.ctx.h, self.h, first, n, _p64(out)))
+        return out
+
+    def download_into(self, out, first=0):
+        """into an existing (e.g. pinned) array of n ciphertexts"""
+        assert out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"] and out.shape[1:] == self.shape[1:]
+        if out.shape[0]:
+            self.ctx._ck(self.ctx.lib.lumen_set_download(self.ctx.h, self.h, first, out.shape[0], _p64(out)))
         return out
 
     def slice(self, first, n):
@@ -247,6 +269,13 @@ class Context:
     def sync(self):
         self._ck(self.lib.lumen_sync(self.h))
 
+    def download_into(self, s, out, first=0):
+        """download a set (possibly created by another context of this device) on THIS context's stream"""
+        assert out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"] and out.shape[1:] == s.shape[1:]
+        if out.shape[0]:
+            self._ck(self.lib.lumen_set_download(self.h, s.h, first, out.shape[0], _p64(out)))
+        return out
+
     def new_set(self, count, nl):
         h = C.c_void_p()
         self._ck(self.lib.lumen_set_create(self.h, count, nl, C.byref(h)))
@@ -256,6 +285,41 @@ class Context:
         host = np.ascontiguousarray(host, dtype=np.uint64)
         s = self.new_set(host.shape[0], host.shape[2])
         return s.upload(host)
+
+    # ---- lane shards (multi-GPU Encode)
+    def new_set_lanes(self, count, nl, log_world):
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_set_create_lanes(self.h, count, nl, log_world, C.byref(h)))
+        return DeviceSet(self, h)
+
+    def upload_lanes(self, host, log_world):
+        """host: [count][2][nl][N >> log_world]"""
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        assert host.shape[3] == self.N >> log_world
+        return self.new_set_lanes(host.shape[0], host.shape[2], log_world).upload(host)
+
+    def lanes_split(self, columns, log_world):
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_lanes_split(self.h, columns.h, log_world, C.byref(h)))
+        return DeviceSet(self, h)
+
+    def lanes_assemble(self, lanes):
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_lanes_assemble(self.h, lanes.h, C.byref(h)))
+        return DeviceSet(self, h)
+
+    def leaf_digests_end_device(self):
+        """-> (device pointer, count): the digests stay in HBM (the buffer an all-gather reads)"""
+        p = C.c_void_p()
+        n = self._pending_leaves
+        self._ck(self.lib.lumen_leaf_digests_end_device(self.h, C.byref(p)))
+        self._pending_leaves = 0
+        return p.value, n
+
+    def merkle_root_device(self, dev_ptr, n_leaves):
+        root = np.zeros(32, dtype=np.uint8)
+        self._ck(self.lib.lumen_merkle_root_device(self.h, C.c_void_p(dev_ptr), n_leaves, root.ctypes.data_as(_u8p)))
+        return root.tobytes()
 
     def set_ntt(self, s, inverse=False):
         self._ck(self.lib.lumen_set_ntt(self.h, s.h, 1 if inverse else 0))

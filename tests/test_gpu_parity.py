@@ -357,6 +357,64 @@ def test_encode_shards_cover_full_encode(oracle, small, world):
     assert np.all(seen == 1)
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_encode_lane_shard_alltoall_matches_full(oracle, small, world):
+    """SURVEY 8e, every rank played in turn on this one GPU: rank r uploads only ITS input columns, cuts
+    them into lane blocks (lumen_lanes_split), an all-to-all gives every rank the lane shard of ALL
+    columns, lumen_encode runs on the shard (the transform never mixes lanes), a second all-to-all and
+    lumen_lanes_assemble give every rank whole ciphertexts of its block of encoded columns.  Each step is
+    compared with the single-GPU fhe.Encode (itself bit-exact against the oracle): nothing is replicated
+    and a rank holds 1/W of the input."""
+    P, ctx = small
+    cols, rho, nl = 64, 2, 2
+    S, logw = cols * rho, world.bit_length() - 1
+    Nw, c, Sw = P.N >> logw, cols // world, S // world
+    roots = oracle.field_roots(T_REF, S)
+    ctx.field_set(roots)
+    m = random_cts(P, cols, nl, seed=91)
+    zero = random_cts(P, 1, nl, seed=92)[0]
+    full = ctx.encode(ctx.upload(m), zero, rho).download()
+    assert np.array_equal(full, P.ct_encode(m, rho, zero, roots))
+    # all-to-all #1: source r sends block g of its split columns to rank g
+    split = [ctx.lanes_split(ctx.upload(m[r * c:(r + 1) * c]), logw) for r in range(world)]
+    assert all(sp.log_world == logw and sp.shape == (world * c, 2, nl, Nw) for sp in split)
+    split = [sp.download() for sp in split]
+    enc_lanes = []
+    for g in range(world):
+        lanes_in = np.concatenate([split[r][g * c:(g + 1) * c] for r in range(world)])  # ct-major: all columns
+        assert np.array_equal(lanes_in, m[..., g * Nw:(g + 1) * Nw])
+        e = ctx.encode(ctx.upload_lanes(lanes_in, logw), np.ascontiguousarray(zero[..., g * Nw:(g + 1) * Nw]), rho)
+        assert e.log_world == logw and e.count == S
+        enc_lanes.append(e.download())
+        assert np.array_equal(enc_lanes[g], full[..., g * Nw:(g + 1) * Nw]), g
+    # all-to-all #2: rank h receives block h of every rank's encoded lane shard (a contiguous slice)
+    for h in range(world):
+        recv = np.concatenate([enc_lanes[g][h * Sw:(h + 1) * Sw] for g in range(world)])
+        got = ctx.lanes_assemble(ctx.upload_lanes(recv, logw))
+        assert got.log_world == 0 and np.array_equal(got.download(), full[h * Sw:(h + 1) * Sw]), h
+    # full-width entry points refuse a lane set instead of mis-reading it
+    with pytest.raises(Exception, match="lane-sharded"):
+        ctx.rescale(ctx.upload_lanes(recv, logw), 1)
+
+
+def test_device_merkle_root_and_device_digests(oracle, small):
+    """The multi-GPU tail: digests stay in HBM (lumen_leaf_digests_end_device: what the all-gather reads),
+    the Merkle root is built on the device from them; equal to the host tree for even, odd and
+    non-power-of-two leaf counts."""
+    import ctypes as C
+    P, ctx = small
+    for count in (1, 2, 37, 64, 300):
+        cts = random_cts(P, count, 2, seed=100 + count)
+        s = ctx.upload(cts)
+        dig = ctx.leaf_digests(s)
+        _, want = ctx.merkle_build(dig)
+        assert want == oracle.merkle(dig)[1]
+        ctx.leaf_digests_begin(s)
+        ptr, n = ctx.leaf_digests_end_device()
+        assert n == count
+        assert ctx.merkle_root_device(ptr, count) == want, count
+
+
 @pytest.mark.parametrize("log_n,logn_small", [(10, 10), (12, 10), (12, 8), (14, 10)])
 def test_ring_switch_matches_oracle(oracle, log_n, logn_small):
     """RingSwitchNew (fhe/ring_switch.go:106-113): bit-exact vs the oracle, and the sub-ring contract:

@@ -32,7 +32,15 @@ def load(d, counter):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    sq_dirs = sys.argv[4:]  # optional: passes with SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE
     fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    sq = {}
+    for d in sq_dirs:
+        for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS",
+                  "SQ_WAVES"):
+            for k, (v, n) in load(d, c).items():
+                if n:
+                    sq.setdefault(k, {})[c] = v / n
     res = {}
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, [0.0, 0])
@@ -44,9 +52,19 @@ def main():
         }
         if nf and nw:
             res[k]["hbm_bytes_per_launch"] = res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]
+    for k, c in sq.items():
+        e = res.setdefault(k, {})
+        e["sq_per_launch"] = c
+        if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
+            # 8 XCDs x 32 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the XCDs; an issued VALU
+            # instruction keeps its SIMD busy for 4 cycles (64 lanes over 16)
+            e["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from lumenos_amd import _build
+    res["__source_hash__"] = _build.source_hash()
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, v in res.items():
-        if v.get("hbm_bytes_per_launch"):
+        if isinstance(v, dict) and v.get("hbm_bytes_per_launch"):
             print(f"{k:40s} launches={v['launches']:6d}  HBM/launch = {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB")
 
 

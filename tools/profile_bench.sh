@@ -13,10 +13,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 
 B1="$GRAFT_REPO_ROOT/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 $B1 > "$out/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 $B1 > "$out/write.log" 2>&1
+# SQ counters of the same command (instruction counts and VALU-busy cycles), two more PMC-only passes
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/sq0" -- python3 $B1 > "$out/sq0.log" 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$out/sq1" -- python3 $B1 > "$out/sq1.log" 2>&1
 cd "$GRAFT_REPO_ROOT"
-python3 tools/collect_pmc.py "$out/fetch" "$out/write" "$out/pmc_traffic_$cfg.json"
+python3 tools/collect_pmc.py "$out/fetch" "$out/write" "$out/pmc_traffic_$cfg.json" "$out/sq0" "$out/sq1"
 f=$(ls $out/stats/*/*kernel_stats.csv | head -1)
 cp "$f" "$out/kernel_stats_$cfg.csv"
 # the raw per-dispatch traces are large: keep only the summaries
-rm -rf "$out/fetch" "$out/write" "$out/stats"
+rm -rf "$out/fetch" "$out/write" "$out/stats" "$out/sq0" "$out/sq1"
 head -20 "$out/kernel_stats_$cfg.csv"

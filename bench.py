@@ -10,11 +10,15 @@ limbs, rhoInv = 2, 309 queries).  It fits one GPU (about 75 GB of the 288 GB).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (strong scaling, fixed job): every rank holds the input matrix; the passes of
-the ciphertext-axis transform that mix all ciphertexts are replicated, its final
-pass and all per-column work (rescale + leaf hashing; ct x pt + InnerSum + rescale;
-query gather) are sharded by column over the ranks, and the one data exchange is an
-RCCL all-gather of the 32-byte leaf digests for the Merkle tree.
+N > 1 (strong scaling, fixed job; N a power of two): rank r holds ONLY its block of cols/N
+input columns.  Encode is lane-sharded (the ciphertext-axis transform never mixes
+lanes): an all-to-all over xGMI turns the ranks' column blocks into lane shards of all
+columns, every rank encodes its 1/N of the lanes, a second all-to-all hands every rank whole
+ciphertexts of its block of encoded columns.  Everything else is per column (rescale + leaf
+hashing; ct x pt + InnerSum + rescale on the rank's input columns; query gather).  The leaf
+digests are all-gathered on device buffers (RCCL) and the Merkle root is built on the device.
+Nothing is replicated.  (Other N: the round-1 path -- every rank holds the matrix and runs the
+mixing passes itself.)
 
 Rank 0 prints ONE JSON line (see the keys at the bottom of main()).
 """
@@ -127,8 +131,13 @@ class Job:
         self.ctx = ctx = Context(P.log_n, P.q, P.p, P.psi, P.T, device=device)
         ctx.field_set(np.array(lp.field_roots_forward(P.T, self.S), dtype=np.uint64))
         rng = np.random.default_rng(1)
-        # synthetic inputs: uniform residues (kernels are data-independent)
-        self.matrix = ctx.new_set(self.cols, self.L).fill_random(1)
+        # lane-sharded Encode needs a power-of-two world whose lane shards keep at least one tile
+        self.lane_path = world > 1 and (world & (world - 1)) == 0 and self.cols % world == 0 and (self.N // world) >= 64
+        self.logw = world.bit_length() - 1 if self.lane_path else 0
+        # synthetic inputs: uniform residues (kernels are data-independent); with the lane path a
+        # rank only ever holds its own block of columns
+        own = self.cols // world if self.lane_path else self.cols
+        self.matrix = ctx.new_set(own, self.L).fill_random(1 + (rank if self.lane_path else 0))
 
         def rand_limbs(mods, shape_tail):
             out = np.empty((len(mods),) + shape_tail, dtype=np.uint64)
@@ -152,6 +161,9 @@ class Job:
             ctx.load_ringswitch_key(ring_switch_logn, key)
         # column shards (input columns; encoded columns are sharded by the transform itself)
         self.col_lo, self.col_hi = self.cols * rank // world, self.cols * (rank + 1) // world
+        if self.lane_path:  # self.matrix IS the rank's block; its slice of the one Enc(0) for the lane Encode
+            nw = self.N // world
+            self.zero_lanes = np.ascontiguousarray(self.zero_ct[:, :, rank * nw:(rank + 1) * nw])
         ctx.sync()
 
     # ---- host I/O of a prover run, measured by --include-io
@@ -202,7 +214,45 @@ class Job:
             s.free()
         return t
 
+    def step_lanes(self, dist):
+        """One step on `world` ranks with the lane-sharded Encode (module docstring)."""
+        ctx, W, rank = self.ctx, self.world, self.rank
+        Sw = self.S // W
+        # ---- Commit: Encode.  own columns -> lane blocks -> all-to-all -> lane shard of ALL columns
+        blocks = ctx.lanes_split(self.matrix, self.logw)
+        lanes = ctx.new_set_lanes(self.cols, self.L, self.logw)
+        all_to_all_sets(dist, blocks, lanes, W)
+        blocks.free()
+        enc = ctx.encode(lanes, self.zero_lanes, RHO_INV)  # this rank's lanes of all S encoded columns
+        lanes.free()
+        recv = ctx.new_set_lanes(self.S, self.L, self.logw)
+        all_to_all_sets(dist, enc, recv, W)                  # block h of every shard -> rank h
+        enc.free()
+        mine = ctx.lanes_assemble(recv)                      # whole ciphertexts of columns [rank*Sw, (rank+1)*Sw)
+        recv.free()
+        # ---- Commit: leaves on this rank's encoded columns, hashed under the inner products
+        lvl1 = ctx.rescale(mine, 2)
+        mine.free()
+        ctx.leaf_digests_begin(lvl1)
+        # ---- Prove: inner products on this rank's input columns
+        mat_r = ctx.matrix_inner_sum(self.matrix, self.r_pt, self.rows)
+        mat_z = ctx.matrix_inner_sum(self.matrix, self.b_pt, self.rows)
+        if self.ring_switch_logn:
+            ctx.ring_switch(mat_r)
+            ctx.ring_switch(mat_z)
+        own = self.query_idx[(self.query_idx >= rank * Sw) & (self.query_idx < (rank + 1) * Sw)] - rank * Sw
+        q = ctx.gather(lvl1, own.astype(np.uint32))
+        # ---- Commit, concluded: all-gather of the digests on device buffers, Merkle root on the device
+        ptr, n = ctx.leaf_digests_end_device()
+        root = all_gather_root(dist, ctx, ptr, n, self.S, W)
+        ctx.sync()
+        for s in (q, mat_r, mat_z, lvl1):
+            s.free()
+        return root
+
     def step(self, dist=None):
+        if self.lane_path and dist is not None:
+            return self.step_lanes(dist)
         ctx = self.ctx
         # ---- Commit: Encode (fhe/code.go:8-34); with several ranks each keeps the encoded columns
         # its share of the transform's final pass produces
@@ -243,6 +293,56 @@ def owned_queries(query_idx, my_cols):
     pos = np.clip(pos, 0, len(my_cols) - 1)
     own = my_cols[pos] == query_idx
     return pos[own].astype(np.uint32)
+
+
+class _DeviceBytes:
+    """A span of device memory as torch sees it (CUDA array interface): lets RCCL collectives read and
+    write the library's own buffers -- no staging copy, no host round trip."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _as_tensor(ptr, nbytes):
+    import torch
+    return torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
+
+
+def all_to_all_sets(dist, send, recv, world):
+    """Block g of `send` (its g-th slice of count/world ciphertexts, contiguous: the layouts are ct-major)
+    goes to rank g; block r of `recv` comes from rank r.  RCCL all-to-all on the sets' device memory; with
+    gloo (one-GPU rehearsal) the same routing through the host."""
+    import torch
+    assert send.nbytes == recv.nbytes and send.count % world == 0
+    send.ctx.sync()  # the producing kernels ran on the library's stream, the collective runs on torch's
+    if dist.get_backend() == "nccl":
+        dist.all_to_all_single(_as_tensor(recv.device_ptr, recv.nbytes), _as_tensor(send.device_ptr, send.nbytes))
+        torch.cuda.synchronize()
+        return
+    host = torch.from_numpy(send.download().reshape(world, -1).view(np.int64))
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host)  # gloo has no all-to-all: everybody sees everything, keeps its blocks
+    rank = dist.get_rank()
+    out = np.stack([p[rank].numpy().view(np.uint64) for p in parts]).reshape(recv.shape)
+    recv.upload(out)
+
+
+def all_gather_root(dist, ctx, dev_ptr, n, S, world):
+    """All-gather of the rank's n = S/world leaf digests (contiguous column blocks, so the gathered buffer
+    is already in column order) and core.NewTree's root over them, all in device memory."""
+    import torch
+    assert n * world == S
+    if dist.get_backend() == "nccl":
+        full = torch.empty(S * 32, dtype=torch.uint8, device="cuda")
+        dist.all_gather_into_tensor(full, _as_tensor(dev_ptr, n * 32))
+        torch.cuda.synchronize()
+        return ctx.merkle_root_device(full.data_ptr(), S)
+    mine = torch.as_tensor(_DeviceBytes(dev_ptr, n * 32), device="cuda").cpu()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    full = torch.cat(parts).cuda()
+    torch.cuda.synchronize()
+    return ctx.merkle_root_device(full.data_ptr(), S)
 
 
 def all_gather_digests(dist, dig, my_cols, S, world):
@@ -459,7 +559,9 @@ def main():
             "config": {"workload": f"Encode+Commit+InnerProduct(r,b)+QueryCols {args.config} LogN={job.log_n} "
                                    f"L={job.L} K={job.K} rhoInv={RHO_INV} queries={job.queries}"
                                    + (f" +ring-switch->LogN={args.ring_switch_logn}" if args.ring_switch_logn else ""),
-                       "parallelism": f"columns sharded over {world} GPU(s); digest all-gather",
+                       "parallelism": (f"{world} GPUs: lane-sharded Encode between two xGMI all-to-alls, columns sharded "
+                                       "elsewhere, digest all-gather + Merkle root on device buffers"
+                                       if job.lane_path else f"columns sharded over {world} GPU(s); digest all-gather"),
                        "baseline_ref": "BASELINE.md: reference Go/Lattigo CPU, m7i.8xlarge 32 vCPU"},
             # limb transforms the device EXECUTES per step (sum of the NTT kernels' units: the rescale to level 1
             # runs on coefficients, 14 transforms per polynomial instead of the reference's 75) ...

@@ -70,3 +70,96 @@ def test_shards_partition_columns():
             spans = [_shard(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+# ---- lane-sharded Encode: the routing of the two all-to-alls, world 2 and 4 on CPU
+class _FakeCtx:
+    def sync(self):
+        pass
+
+
+class _FakeSet:
+    """what bench.all_to_all_sets needs of a DeviceSet, backed by numpy"""
+
+    def __init__(self, arr):
+        self.a = np.ascontiguousarray(arr, dtype=np.uint64)
+        self.ctx = _FakeCtx()
+
+    count = property(lambda self: self.a.shape[0])
+    shape = property(lambda self: self.a.shape)
+    nbytes = property(lambda self: self.a.nbytes)
+
+    def download(self):
+        return self.a.copy()
+
+    def upload(self, host):
+        self.a[...] = host
+
+
+def split_np(cols, W):
+    """lumen_lanes_split on the host: [n][2][nl][N] -> [W*n][2][nl][N/W], block g = lanes of rank g"""
+    n, _, nl, N = cols.shape
+    return np.concatenate([cols[..., g * (N // W):(g + 1) * (N // W)] for g in range(W)])
+
+
+def assemble_np(lanes, W):
+    """lumen_lanes_assemble on the host: [W*n][2][nl][N/W] -> [n][2][nl][N]"""
+    n = lanes.shape[0] // W
+    return np.concatenate([lanes[g * n:(g + 1) * n] for g in range(W)], axis=3)
+
+
+def fake_encode(lanes, rho):
+    """any lane-independent map cols -> rho*cols ciphertexts (the real one is tested on the GPU)"""
+    acc = np.cumsum(lanes, axis=0, dtype=np.uint64)
+    return np.concatenate([lanes * np.uint64(3) + np.uint64(1), acc ^ np.uint64(0x5555)])
+
+
+def _lane_worker(rank, world, port, matrix, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    cols = matrix.shape[0]
+    c = cols // world
+    own = matrix[rank * c:(rank + 1) * c]                    # the only input this rank ever holds
+    blocks = _FakeSet(split_np(own, world))
+    lanes = _FakeSet(np.zeros((cols,) + blocks.shape[1:], dtype=np.uint64))
+    bench.all_to_all_sets(dist, blocks, lanes, world)
+    enc = _FakeSet(fake_encode(lanes.a, 2))
+    recv = _FakeSet(np.zeros_like(enc.a))
+    bench.all_to_all_sets(dist, enc, recv, world)
+    out.put((rank, lanes.a.copy(), assemble_np(recv.a, world)))
+    dist.destroy_process_group()
+
+
+def _run_lane_world(world):
+    rng = np.random.default_rng(world)
+    cols, nl, N = 8, 2, 64
+    matrix = rng.integers(0, 2**63, size=(cols, 2, nl, N), dtype=np.uint64)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lane_worker, args=(r, world, port, matrix, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, lanes, mine = out.get(timeout=180)
+        res[r] = (lanes, mine)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = fake_encode(matrix, 2)                            # single-rank result, full width
+    Nw, Sw = N // world, full.shape[0] // world
+    for r in range(world):
+        lanes, mine = res[r]
+        assert np.array_equal(lanes, matrix[..., r * Nw:(r + 1) * Nw])   # lane shard of ALL input columns
+        assert np.array_equal(mine, full[r * Sw:(r + 1) * Sw])           # whole ciphertexts of ITS encoded columns
+
+
+def test_lane_sharded_exchange_world2():
+    _run_lane_world(2)
+
+
+def test_lane_sharded_exchange_world4():
+    _run_lane_world(4)

@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python3 -m pytest tests/test_gpu_parity.py -q -x -k "ntt or key_switch or encrypt or inner_sum or rescale" 2>&1 | tail -2
-for n in 14 13 12; do python3 tools/ntt_only.py $n 512 60; done
-bash tools/exp_env.sh ""
+python3 tools/check_nccl_alias.py 2>&1 | tail -3
+for n in 2 4; do
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2951$n bench.py --gpus $n --share-gpu --dist-backend gloo --config 2048x1024 --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | tail -2
+done
+python3 bench.py --config 2048x1024 --steps 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400

@@ -29,6 +29,41 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _resource_usage(text):
+    """Per-kernel register / scratch figures out of -Rpass-analysis=kernel-resource-usage remarks."""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|"
+                      r"VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return out
+
+
+def check_resources(usage, src):
+    """The hand-scheduled multiplication pins VGPRs by number and several kernels sit right under the
+    128-VGPR line that keeps four waves per SIMD: a compiler bump that spills would not fail a test, it
+    would silently halve the speed.  Refuse any kernel that uses scratch memory or spills a VGPR."""
+    bad = [f"{k}: scratch {v.get('ScratchSize [bytes/lane]', 0)} B/lane, {v.get('VGPRs Spill', 0)} VGPRs spilled"
+           for k, v in usage.items() if v.get("ScratchSize [bytes/lane]", 0) or v.get("VGPRs Spill", 0)]
+    if bad:
+        raise RuntimeError(f"{os.path.basename(src)}: kernels use scratch / spill registers:\n  " + "\n  ".join(bad))
+
+
+def resource_report():
+    """kernel -> {VGPRs, TotalSGPRs, Occupancy, ...} of the objects the library was linked from"""
+    import json
+    rep = {}
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.res.json"))):
+        rep.update(json.load(open(f)))
+    return rep
+
+
 def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link the shared library."""
     if not force and not _stale():
@@ -37,7 +72,8 @@ def build(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     objs = []
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
-             "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+             "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+             "-Rpass-analysis=kernel-resource-usage"]
     flags += os.environ.get("LUMEN_HIPCC_FLAGS", "").split()  # tuning experiments (-DLM_MAC_COLS=8 ...)
     procs = []
     for s in srcs:
@@ -51,12 +87,17 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    import json
     for s, p in procs:
         out, _ = p.communicate()
+        text = out.decode()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
-        if verbose and out:
-            print(out.decode())
+            raise RuntimeError(f"hipcc failed on {s}:\n{text}")
+        usage = _resource_usage(text)
+        check_resources(usage, s)
+        json.dump(usage, open(s[:-4] + ".res.json", "w"), indent=1, sort_keys=True)
+        if verbose:
+            print("\n".join(l for l in text.splitlines() if "remark:" not in l and not l.startswith(" ")))
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
     subprocess.check_call(cmd)
     return LIB

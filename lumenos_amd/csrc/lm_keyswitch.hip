@@ -362,31 +362,55 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
     u64 *aout = acc_out + ((size_t)pw * L + t) * N;
     const tw_t pi = pinv[t];
     auto ld = [&](uint32_t i) { return bx_apply(c, up0[i], up1[i], qc); };
-    auto st = [&](uint32_t i0, const u64 *v, int count) {
-        u64 uv[8], cv[8];
-        lm_load_run(uq, i0, uv, count);
-        if (w == 0) lm_load_run(ain, i0, cv, count);
+    // the store phase combines every finished run of 8 with the gadget product u (and c0 for w == 0): both
+    // are requested by pre() before the run's butterflies, not after them
+    constexpr int RUN = lm_fwd_run<LOGN>();
+    static_assert(RUN <= 8, "lm_load_run moves at most 8 coefficients");
+    struct storer_t {
+        const u64 *uq, *ain;
+        u64 *sm;
+        const lm_qc &qc;
+        tw_t pi;
+        uint32_t w;
+        u64 uv[RUN], cv[RUN];
+        __device__ __forceinline__ void pre(uint32_t i0) {
+            lm_load_run(uq, i0, uv, RUN);
+            if (w == 0) lm_load_run(ain, i0, cv, RUN);
+        }
+        __device__ __forceinline__ void operator()(uint32_t i0, const u64 *v, int count) {
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (k < count) {
-                // u' - lift * P^-1 (u' = u * P^-1 comes out of the gadget product, see
-                // lumen_load_galois_key); the multiplication takes the unreduced lift: < 4q
-                u64 x = uv[k] + qc.q3 - lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq);
-                x = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
-                if (w == 0) x = lm_addmod(x, cv[k], qc.q);
-                sm[LM_PAD(i0 + k)] = x; // the slots this work item just consumed
-            }
-    };
+            for (int k = 0; k < RUN; k++)
+                if (k < count) {
+                    // u' - lift * P^-1 (u' = u * P^-1 comes out of the gadget product, see
+                    // lumen_load_galois_key); the multiplication takes the unreduced lift: < 4q
+                    u64 x = uv[k] + qc.q3 - lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq);
+                    x = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
+                    if (w == 0) x = lm_addmod(x, cv[k], qc.q);
+                    sm[LM_PAD(i0 + k)] = x; // the slots this work item just consumed
+                }
+        }
+    } st{uq, ain, sm, qc, pi, w, {}, {}};
     // acc_out[j] = acc_in[j] + d[index[j]]: the automorphism is applied as a gather out of LDS, so the
-    // accumulator itself streams through HBM linearly in 16-byte vectors
+    // accumulator itself streams through HBM linearly in 16-byte vectors.  Every lane handles 8 pairs;
+    // their index and accumulator words are requested before the barrier, while the slower waves of the
+    // workgroup are still in their last pass.
     auto after = [&](uint32_t, uint32_t) {
+        constexpr uint32_t IT = N / (2 * lm_nthreads(LOGN));
+        uint2 p[IT];
+        ulonglong2 x[IT];
+#pragma unroll
+        for (uint32_t k = 0; k < IT; k++) {
+            const uint32_t j = 2 * tid + k * 2 * nthreads;
+            p[k] = *reinterpret_cast<const uint2 *>(index + j);
+            x[k] = *reinterpret_cast<const ulonglong2 *>(ain + j);
+        }
         __syncthreads();
-        for (uint32_t j = 2 * tid; j < N; j += 2 * nthreads) {
-            const uint2 p = *reinterpret_cast<const uint2 *>(index + j);
-            const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(ain + j);
+#pragma unroll
+        for (uint32_t k = 0; k < IT; k++) {
+            const uint32_t j = 2 * tid + k * 2 * nthreads;
             ulonglong2 y;
-            y.x = lm_addmod(x.x, sm[LM_PAD(p.x)], qc.q);
-            y.y = lm_addmod(x.y, sm[LM_PAD(p.y)], qc.q);
+            y.x = lm_addmod(x[k].x, sm[LM_PAD(p[k].x)], qc.q);
+            y.y = lm_addmod(x[k].y, sm[LM_PAD(p[k].y)], qc.q);
             *reinterpret_cast<ulonglong2 *>(aout + j) = y;
         }
     };

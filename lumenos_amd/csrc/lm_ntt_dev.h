@@ -21,6 +21,8 @@
 // Twiddles of stages whose block index is wave-uniform are fetched with scalar loads.
 #pragma once
 #include <cstring>
+#include <type_traits>
+#include <utility>
 
 #include "lm_common.h"
 
@@ -449,11 +451,21 @@ __device__ __forceinline__ void lm_fwd_mid(u64 *s, const tw_t *tw, const lm_qc &
     }
 }
 
+// A storer may have a member `void pre(uint32_t i0)`: it is called with the first coefficient of a run
+// BEFORE the run's butterflies are computed, so that whatever the store phase reads from global memory
+// (the gadget product and the accumulator in the ModDown kernel) is requested a whole pass body early.
+template <class S, class = void>
+struct lm_has_pre : std::false_type {};
+template <class S>
+struct lm_has_pre<S, std::void_t<decltype(std::declval<S &>().pre(0u))>> : std::true_type {};
+
 template <int LOGN, int R, class Storer>
 __device__ __forceinline__ void lm_fwd_last(const u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Storer &st) {
     constexpr uint32_t s0 = LOGN - R;
     using D = lm_deal<LOGN, R>;
     if (!D::valid(tid)) return;
+    // a storer with its own prefetch keeps its registers: no second twiddle set then
+    constexpr bool TWPF = LM_TW_PREFETCH && !lm_has_pre<Storer>::value;
     lm_twset<R, false> T[2];
     T[0].load(tw, s0, D::local(tid, 0));
 #pragma unroll
@@ -463,9 +475,10 @@ __device__ __forceinline__ void lm_fwd_last(const u64 *s, const tw_t *tw, const 
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + k)];
-        if (LM_TW_PREFETCH && m + 1 < D::reps) T[(m + 1) & 1].load(tw, s0, D::local(tid, m + 1));
-        if (!LM_TW_PREFETCH && m) T[m & 1].load(tw, s0, w);
-        lm_fwd_stages<R, false>(e, T[m & 1], c);
+        if constexpr (lm_has_pre<Storer>::value) st.pre(base);
+        if (TWPF && m + 1 < D::reps) T[(m + 1) & 1].load(tw, s0, D::local(tid, m + 1));
+        if (!TWPF && m) T[0].load(tw, s0, w);
+        lm_fwd_stages<R, false>(e, T[TWPF ? (m & 1) : 0], c);
         st(base, e, 1 << R);
     }
 }
@@ -489,6 +502,11 @@ __device__ __forceinline__ void lm_fwd_rec(u64 *sm, const tw_t *tw, const lm_qc 
         lm_fwd_rec<LOGN, P + 1, S0 + R>(sm, tw, c, tid, ld, st);
     }
 }
+// coefficients per run the forward transform hands to its storer (2^R of the last pass)
+template <int LOGN>
+__host__ __device__ constexpr int lm_fwd_run() {
+    return 1 << lm_pass_r(LOGN, lm_npasses(LOGN) - 1);
+}
 struct lm_no_after {
     __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {}
 };
@@ -510,6 +528,8 @@ template <int LOGN, int R, class Loader>
 __device__ __forceinline__ void lm_inv_first(u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Loader &ld) {
     using D = lm_deal<LOGN, R>;
     if (!D::valid(tid)) return;
+    // (requesting run m+1 while run m is computed was measured and is slower: 9.09 against 9.41 M
+    // transforms/s at N = 2^14 -- the loads of sixteen waves then bunch up in front of the first pass)
 #pragma unroll 1
     for (uint32_t m = 0; m < D::reps; m++) {
         const uint32_t w = D::local(tid, m);

@@ -1,6 +1,4 @@
 cd $GRAFT_REPO_ROOT
-V=$PWD/lumenos_amd/csrc/variants
-for v in "" ctw64 ctw64t1024 ctw16; do
-  if [ -z "$v" ]; then echo "== default (W=32, 512 thr)"; python3 tools/encode_only.py 16384x4096 3 | head -1
-  else echo "== $v"; LUMEN_HIP_LIB=$V/$v/liblumenos_hip.so python3 tools/encode_only.py 16384x4096 3 | head -1; fi
-done
+python3 -m pytest tests/test_gpu_parity.py tests/test_reference_shapes.py -q -x 2>&1 | tail -2
+for n in 14 13 12; do python3 tools/ntt_only.py $n 512 60; done
+bash tools/exp_env.sh ""

@@ -46,7 +46,9 @@ __host__ __device__ constexpr int lm_nthreads(int logN) {
                : ((1 << logN) / LM_COEFS_PER_LANE > 1024 ? 1024 : (1 << logN) / LM_COEFS_PER_LANE);
 }
 __host__ __device__ constexpr int lm_max_threads(int logN) { return lm_nthreads(logN); }
-__host__ __device__ constexpr int lm_log_epl(int logN) { return logN - lm_ilog2(lm_nthreads(logN)); } // log2 coefficients per lane
+__host__ __device__ constexpr int lm_log_epl(int logN) { // log2 coefficients a work item keeps in VGPRs: at most 16
+    return logN - lm_ilog2(lm_nthreads(logN)) > 4 ? 4 : logN - lm_ilog2(lm_nthreads(logN));
+}
 __host__ __device__ constexpr int lm_cross_r(int logN) { return lm_ilog2(lm_nthreads(logN) / 64); }   // stages of the cross-wave pass
 // Pass plan in forward order: [cross-wave pass,] then the wave-local stages in as few passes of
 // at most log2(coefficients per lane) stages as possible, bigger passes first (14 -> 4 | 4 3 3).

@@ -214,7 +214,8 @@ int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint32_t count,
 /* ---- client-side decryption of the proof's ciphertexts: EncryptedProof.Decrypt /
  * decryptBatchedParallel (fhe/ligero.go:381-502, 577-636) = Decryptor.DecryptNew + Encoder.Decode.
  * For a client that owns a GPU and for end-to-end tests: the proving server never holds sk.
- * sk: [L][N], NTT domain.  set: ciphertexts of one or two limbs (level <= 1, what Prove returns).
+ * sk: [L][N], NTT domain.  set: ciphertexts at any level (level <= 1 is what Prove returns; deeper ones,
+ * e.g. the unrescaled output of Encode that TestEncode decrypts, go through an exact mixed-radix CRT).
  * scale: the ciphertexts' Scale, i.e. the product of the dropped moduli's inverses modulo T that the
  * rescales left behind (1 if none); values: host, [count][nvalues] slot values.
  * Needs lumen_encoder_set. */

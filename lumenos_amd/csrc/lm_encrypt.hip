@@ -548,7 +548,7 @@ extern "C" int lumen_load_secret_key(lumen_ctx *ctx, const uint64_t *sk) {
 
 // phase[c][l] = INTT(c0 + c1 * s) * T   (one workgroup per (ciphertext, limb); T * N^-1 folded)
 struct dec_scale_t {
-    tw_t t[2];
+    tw_t t[LM_MAX_LIMBS];
 };
 template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_decrypt_phase(const u64 *__restrict__ ct, const tw_t *__restrict__ sk,
@@ -600,6 +600,50 @@ __global__ void k_decrypt_crt(const u64 *__restrict__ phase, u64 *__restrict__ m
     m[g] = y > (Q >> 1) ? (T - (u64)((Q - y) % T)) % T : (u64)(y % T);
 }
 
+// The same at any depth (Decryptor.DecryptNew of a ciphertext that was never rescaled: TestEncode,
+// fhe/code_test.go:87-96), exact in word arithmetic: Garner's mixed-radix digits
+//     x = d_0 + d_1 q_0 + d_2 q_0 q_1 + ...,   d_i = (y_i - d_0 - d_1 q_0 - ...) / (q_0 ... q_{i-1}) mod q_i
+// x > Q/2 decided digit by digit against the digits of floor(Q/2), x mod T = sum d_i (q_0..q_{i-1} mod T).
+struct garner_t {
+    tw_t inv[LM_MAX_LIMBS][LM_MAX_LIMBS]; // inv[i][j] = q_j^-1 mod q_i (j < i), Shoup form
+    tw_t radix_T[LM_MAX_LIMBS];          // q_0 ... q_{i-1} mod T
+    u64 half[LM_MAX_LIMBS];              // mixed-radix digits of floor(Q / 2)
+    u64 q_mod_T;
+};
+__global__ __launch_bounds__(256) void k_decrypt_garner(const u64 *__restrict__ phase, u64 *__restrict__ m, uint32_t nl,
+                                                        uint32_t logN, size_t total, lm_mods mods,
+                                                        const garner_t *__restrict__ G, mod_t modT) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const size_t c = g >> logN, k = g & (((size_t)1 << logN) - 1);
+    const u64 *p = phase + ((c * nl) << logN) + k;
+    const u64 T = modT.q;
+    // every loop is unrolled over LM_MAX_LIMBS with wave-uniform guards: the digits stay in registers
+    // (a dynamically indexed d[] would live in scratch memory, which the build refuses)
+    u64 d[LM_MAX_LIMBS];
+#pragma unroll
+    for (int i = 0; i < LM_MAX_LIMBS; i++) {
+        d[i] = 0;
+        if ((uint32_t)i < nl) {
+            const mod_t mi = mods.m[i];
+            u64 v = p[(size_t)i << logN];
+#pragma unroll
+            for (int j = 0; j < i; j++)
+                v = lm_shoup(lm_submod(v, lm_reduce(d[j], mi.q, mi.qinv64), mi.q), G->inv[i][j], mi.q);
+            d[i] = v;
+        }
+    }
+    bool above = false, decided = false; // x > floor(Q/2)?  the first differing digit from the top decides
+#pragma unroll
+    for (int i = LM_MAX_LIMBS - 1; i >= 0; i--)
+        if ((uint32_t)i < nl && !decided && d[i] != G->half[i]) above = d[i] > G->half[i], decided = true;
+    u64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < LM_MAX_LIMBS; i++)
+        if ((uint32_t)i < nl) acc = lm_addmod(acc, lm_shoup(lm_reduce(d[i], T, modT.qinv64), G->radix_T[i], T), T);
+    m[g] = above ? lm_submod(acc, G->q_mod_T, T) : acc;
+}
+
 // values[c][i] = t[c][slot[i]] * scale^-1 mod T
 __global__ void k_decrypt_slots(const u64 *__restrict__ t, const uint32_t *__restrict__ slot, u64 *__restrict__ values,
                                 uint32_t nvalues, uint32_t logN, size_t total, tw_t sinv, u64 T) {
@@ -626,7 +670,7 @@ extern "C" int lumen_decrypt(lumen_ctx *ctx, const lumen_set *set, uint64_t scal
     LM_CHECK(nullptr, ctx && set && values, "lumen_decrypt: NULL argument");
     LM_ENTER(ctx);
     LM_FULL_WIDTH(ctx, set, "lumen_decrypt");
-    LM_CHECK(ctx, set->nl >= 1 && set->nl <= 2, "lumen_decrypt takes ciphertexts of one or two limbs (have %u)", set->nl);
+    LM_CHECK(ctx, set->nl >= 1 && set->nl <= ctx->L, "lumen_decrypt: %u limbs out of range [1, %u]", set->nl, ctx->L);
     LM_CHECK(ctx, nvalues >= 1 && nvalues <= ctx->N, "nvalues=%u out of range [1, N]", nvalues);
     const std::shared_ptr<SkTable> sk_hold = lm_ext_get<SkTable>(ctx, "secret_key");
     LM_CHECK(ctx, sk_hold, "no secret key loaded (lumen_load_secret_key)");
@@ -643,7 +687,7 @@ extern "C" int lumen_decrypt(lumen_ctx *ctx, const lumen_set *set, uint64_t scal
     u64 *dv = (u64 *)lm_scratch(ctx, "dec_values", (size_t)count * nvalues * sizeof(u64));
     if (!phase || !m || !dv) return 1;
     dec_scale_t sc;
-    for (uint32_t l = 0; l < 2; l++) {
+    for (uint32_t l = 0; l < LM_MAX_LIMBS; l++) {
         const uint64_t q = ctx->mod[l < nl ? l : 0];
         sc.t[l] = h_tw(h_mulmod(ctx->ninv[l < nl ? l : 0].w, T % q, q), q);
     }
@@ -659,7 +703,35 @@ extern "C" int lumen_decrypt(lumen_ctx *ctx, const lumen_set *set, uint64_t scal
         rc = lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
     }
     if (rc) return rc;
-    {
+    if (nl > 2) { // deeper than what Prove returns: exact CRT by mixed radix
+        std::vector<garner_t> hg(1);
+        garner_t &G = hg[0];
+        memset(&G, 0, sizeof(G));
+        uint64_t r = 1 % T;
+        for (uint32_t i = 0; i < nl; i++) {
+            G.radix_T[i] = h_tw(r, T);
+            r = h_mulmod(r, ctx->mod[i] % T, T);
+            for (uint32_t j = 0; j < i; j++) G.inv[i][j] = h_tw(h_invmod(ctx->mod[j] % ctx->mod[i], ctx->mod[i]), ctx->mod[i]);
+        }
+        G.q_mod_T = r;
+        uint64_t carry = 0; // floor(Q/2) = (Q-1)/2: Q-1 has digit q_i - 1 everywhere; halve from the top
+        for (int i = (int)nl - 1; i >= 0; i--) {
+            const u128 v = (u128)carry * ctx->mod[i] + (ctx->mod[i] - 1);
+            G.half[i] = (uint64_t)(v >> 1);
+            carry = (uint64_t)(v & 1);
+        }
+        garner_t *dG = (garner_t *)lm_scratch(ctx, "dec_garner", sizeof(garner_t));
+        garner_t *hG = (garner_t *)lm_stage(ctx, sizeof(garner_t));
+        if (!dG || !hG) return 1;
+        memcpy(hG, &G, sizeof(G));
+        LM_HIP(ctx, hipMemcpyAsync(dG, hG, sizeof(garner_t), hipMemcpyHostToDevice, ctx->stream));
+        LM_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+        lm_prof_scope ps(ctx, "decrypt_crt", count);
+        const size_t total = (size_t)count * N;
+        hipLaunchKernelGGL(k_decrypt_garner, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, phase, m, nl,
+                           ctx->logN, total, ctx->mods, dG, enc->modT);
+        LM_HIP(ctx, hipGetLastError());
+    } else {
         lm_prof_scope ps(ctx, "decrypt_crt", count);
         const size_t total = (size_t)count * N;
         const uint64_t q0 = ctx->mod[0], q1 = ctx->mod[nl > 1 ? 1 : 0];

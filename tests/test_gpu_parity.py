@@ -684,6 +684,28 @@ def test_gpu_only_round_trip_encrypt_prove_decrypt(oracle):
 
 
 # ------------------------------------------------------------------ error convention
+@pytest.mark.parametrize("nl", [3, 5, 6])
+def test_decrypt_at_any_level_matches_oracle(oracle, nl):
+    """lumen_decrypt deeper than level 1 (TestEncode decrypts ciphertexts that were never rescaled): Garner's
+    mixed-radix CRT on the device == the oracle's, on real encryptions and on uniformly random ciphertexts
+    (phases on both sides of Q/2)."""
+    from lumenos_amd import params as lp
+    P = make_params(oracle, 10, 6)
+    P.seed(30 + nl)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    ctx = make_context(P)
+    ctx.load_secret_key(sk)
+    ctx.encoder_set(lp.encoder_psi(T_REF, P.logN))
+    rng = np.random.default_rng(nl)
+    vals = rng.integers(0, T_REF, size=(2, P.N), dtype=np.uint64)
+    cts = np.stack([P.encrypt(pk, P.encode(vals[i], nl), nl) for i in range(2)] + list(random_cts(P, 2, nl, seed=5)))
+    got = ctx.decrypt(ctx.upload(cts), P.N, 7)
+    assert np.array_equal(got, P.decrypt_batch(sk, cts, P.N, 7))
+    assert np.array_equal(ctx.decrypt(ctx.upload(cts[:2]), P.N), vals)
+    ctx.close()
+
+
 def test_error_paths_report_status_and_message(oracle, small):
     """Every entry point returns non-zero and leaves a message (the cgo convention of the reference,
     vdec/prover.go:121-232): misuse must never reach a kernel with operands it does not expect."""
@@ -717,7 +739,7 @@ def test_error_paths_report_status_and_message(oracle, small):
     fresh.encoder_set(lp.encoder_psi(T_REF, P.logN))
     fails(lambda: fresh.decrypt(fresh.new_set(1, 2), 1), "no secret key")
     fresh.load_secret_key(np.zeros((P.L, P.N), dtype=np.uint64))
-    fails(lambda: fresh.decrypt(fresh.new_set(1, 3), 1), "one or two limbs")
+    fails(lambda: fresh.decrypt(fresh.upload_lanes(np.zeros((1, 2, 2, P.N // 2), dtype=np.uint64), 1), 1), "lane-sharded")
     bad = np.full((2, P.L + P.K, P.N), 2**63, dtype=np.uint64)
     fails(lambda: fresh.load_public_key(bad), "out of range")
     # one asynchronous leaf job at a time

@@ -76,9 +76,12 @@ def test_encode_reference_shape_every_column_decrypts(oracle):
     assert enc.count == S and enc.nl == P.L  # Encode does not rescale
     assert ctx.mul_counter() == 9217         # ct x scalar multiplications of S = 2048
     want = plain_encode_rows(oracle, matrix, rho, roots)  # [rows][S]
+    ctx.load_secret_key(sk)
     bad = []
     for first in range(0, S, 256):
         got = P.decrypt_batch(sk, enc.download(first, 256), rows)  # Decryptor + Encoder.Decode at level 9
+        dev = ctx.decrypt(enc.slice(first, 256), rows)             # the same on the device (mixed-radix CRT)
+        assert np.array_equal(dev, got), first
         for j in range(256):
             if not np.array_equal(got[j], want[:, first + j]):
                 bad.append(first + j)

@@ -222,6 +222,15 @@ int lumen_encrypt_pk(lumen_ctx *ctx, const uint64_t *plaintexts, uint32_t count,
 int lumen_load_secret_key(lumen_ctx *ctx, const uint64_t *sk);
 int lumen_decrypt(lumen_ctx *ctx, const lumen_set *set, uint64_t scale, uint32_t nvalues, uint64_t *values);
 
+/* ---- the plain prover on the same kernels: LigeroProveReference (fhe/ligero.go:799-953),
+ * what the client runs to check a decrypted proof.  A plain matrix over F_T is a set of a context whose
+ * ONE modulus is T (num_q = 1, num_p = 0, 2N = rows): column j is one "ciphertext" of 2 x 1 x N words.
+ * Then core.Encode of every row = lumen_encode (zero_ct all zero), the Merkle leaves = lumen_leaf_digests
+ * with an empty serialisation format (non-NULL strings of length 0: the leaf is the column's bytes,
+ * ligero.go:866-872), queries = lumen_gather, and the two inner products (ligero.go:886-897, 909-918):
+ * out[j] = sum_i columns[j][i] * vec[i] mod q_0, vec: host, 2N raw u64 words (reduced here). */
+int lumen_plain_inner_products(lumen_ctx *ctx, const lumen_set *columns, const uint64_t *vec, uint64_t *out);
+
 /* ---- Galois keys: rlwe.EvaluationKeySet entries used by InnerSum.
  * evk host layout [digit(beta)][b|a][limb(L+K)][N], NTT domain, standard form
  * (the Go shim converts from Lattigo's Montgomery-form GadgetCiphertext). */

@@ -87,6 +87,7 @@ SYMBOLS = {
     "lumen_mul_plain": (C.c_int, [_vp, _vp, _u64p, _vpp]),
     "lumen_inner_sum": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
     "lumen_gather": (C.c_int, [_vp, _vp, _u32p, C.c_uint32, _vpp]),
+    "lumen_plain_inner_products": (C.c_int, [_vp, _vp, _u64p, _u64p]),
     "lumen_ringswitch_digits": (C.c_uint32, [_vp, C.c_uint32]),
     "lumen_load_ringswitch_key": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _u64p]),
     "lumen_ring_switch": (C.c_int, [_vp, _vp, _u64p]),
@@ -467,6 +468,14 @@ class Context:
         h = C.c_void_p()
         self._ck(self.lib.lumen_matrix_inner_sum(self.h, matrix.h, _p64(pt), rows, C.byref(h)))
         return DeviceSet(self, h)
+
+    def plain_inner_products(self, s, vec):
+        """out[j] = sum_i s[j][i] * vec[i] mod q_0 for a one-limb set (the plain prover, ligero.go:886-918)"""
+        vec = np.ascontiguousarray(vec, dtype=np.uint64)
+        assert vec.size == 2 * self.N
+        out = np.zeros(s.count, dtype=np.uint64)
+        self._ck(self.lib.lumen_plain_inner_products(self.h, s.h, _p64(vec), _p64(out)))
+        return out
 
     def gather(self, s, idx):
         idx = np.ascontiguousarray(idx, dtype=np.uint32)

@@ -486,6 +486,75 @@ EncryptedProof LigeroProver::Prove(core::Element point, ServerBFV &backend, core
     return proof;
 }
 
+Proof LigeroProveReference(const LigeroCommitter &c, const std::vector<uint64_t> &matrix, core::Element point,
+                           core::PrimeField &field, core::Transcript &transcript, int device) {
+    const int rows = c.Metadata.Rows, cols = c.Metadata.Cols, rhoInv = c.Metadata.RhoInv, S = cols * rhoInv;
+    const uint64_t T = field.Modulus();
+    if ((size_t)rows * cols != matrix.size()) throw std::invalid_argument("LigeroProveReference: matrix size mismatch");
+    if (rows < 512 || (rows & (rows - 1))) throw std::invalid_argument("LigeroProveReference: rows must be a power of two >= 512");
+    // the plain backend: ring degree rows/2, the one modulus T
+    int logN = 0;
+    while ((2 << logN) < rows) logN++;
+    lumen_params_desc d;
+    memset(&d, 0, sizeof(d));
+    d.abi_version = LUMEN_ABI_VERSION, d.log_n = (uint32_t)logN, d.num_q = 1, d.num_p = 0, d.plaintext_modulus = T;
+    d.moduli[0] = T, d.psi[0] = PowMod(core::PrimitiveRoot(T), (T - 1) / (uint64_t)rows, T), d.device = device;
+    lumen_ctx *ctx = nullptr;
+    if (lumen_ctx_create(&d, &ctx)) throw std::runtime_error(std::string("lumen_ctx_create: ") + lumen_last_error(nullptr));
+    struct Closer {
+        lumen_ctx *c;
+        std::vector<lumen_set *> sets;
+        ~Closer() {
+            for (lumen_set *s : sets) lumen_set_destroy(c, s);
+            lumen_ctx_destroy(c);
+        }
+    } guard{ctx, {}};
+    auto ck = [&](int rc, const char *what) {
+        if (rc) throw std::runtime_error(std::string(what) + ": " + lumen_last_error(ctx));
+    };
+    ck(lumen_field_set(ctx, field.RootsForward().data(), (uint32_t)field.N()), "lumen_field_set");
+    // Commit: columns as lanes, core.Encode of every row (ligero.go:806-857), leaves = column bytes (866-872)
+    std::vector<uint64_t> columns((size_t)cols * rows);
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < cols; j++) columns[(size_t)j * rows + i] = matrix[(size_t)i * cols + j];
+    lumen_set *m = nullptr, *enc = nullptr, *q = nullptr;
+    ck(lumen_set_create(ctx, (uint32_t)cols, 1, &m), "lumen_set_create");
+    guard.sets.push_back(m);
+    ck(lumen_set_upload(ctx, m, 0, (uint32_t)cols, columns.data()), "lumen_set_upload");
+    const std::vector<uint64_t> zero((size_t)rows, 0);
+    ck(lumen_encode(ctx, m, zero.data(), (uint32_t)rhoInv, &enc), "lumen_encode");
+    guard.sets.push_back(enc);
+    const uint8_t none = 0;
+    ck(lumen_leaf_format_set(ctx, &none, 0, &none, 0, &none, 0), "lumen_leaf_format_set");
+    std::vector<core::Digest> leaves((size_t)S);
+    ck(lumen_leaf_digests(ctx, enc, leaves[0].data()), "lumen_leaf_digests");
+    core::MerkleTree tree = core::MerkleTree::FromLeafDigests(std::move(leaves));
+    // Prove (ligero.go:880-918): r sampled as field elements (raw words, reduced by the multiplication), b_i = (z^cols)^i
+    Proof proof;
+    proof.Metadata = c.Metadata;
+    std::vector<uint64_t> r((size_t)rows), b((size_t)rows);
+    transcript.SampleUints("r", r);
+    const core::Element zPow = field.Pow((uint64_t)cols, point);
+    core::Element powB = 1;
+    for (uint64_t &bi : b) bi = powB, powB = field.Mul(powB, zPow);
+    proof.MatR.resize((size_t)cols), proof.MatZ.resize((size_t)cols);
+    ck(lumen_plain_inner_products(ctx, m, r.data(), proof.MatR.data()), "lumen_plain_inner_products");
+    ck(lumen_plain_inner_products(ctx, m, b.data(), proof.MatZ.data()), "lumen_plain_inner_products");
+    transcript.AppendField("point", point);
+    proof.QueryIndices = sampleQueryIndices(transcript, c.Metadata.Queries, S);
+    const std::vector<uint32_t> idx(proof.QueryIndices.begin(), proof.QueryIndices.end());
+    ck(lumen_gather(ctx, enc, idx.data(), (uint32_t)idx.size(), &q), "lumen_gather");
+    guard.sets.push_back(q);
+    std::vector<uint64_t> opened(idx.size() * (size_t)rows);
+    if (!idx.empty()) ck(lumen_set_download(ctx, q, 0, (uint32_t)idx.size(), opened.data()), "lumen_set_download");
+    for (size_t k = 0; k < idx.size(); k++) {
+        proof.QueriedCols.emplace_back(opened.begin() + (long)(k * rows), opened.begin() + (long)((k + 1) * rows));
+        proof.MerklePaths.push_back(tree.GetMerklePath((unsigned)proof.QueryIndices[k]));
+    }
+    proof.Root = tree.MerkleRoot();
+    return proof;
+}
+
 static void write_cts(std::vector<uint8_t> &buf, const Ciphertexts &c) {
     // ct.WriteTo(buf) for every ciphertext of the slice, in the backend's current serialisation format
     const int count = c.Len();

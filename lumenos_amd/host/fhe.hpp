@@ -195,6 +195,21 @@ class LigeroCommitter { // fhe/ligero.go:27-29, 40-63
                                                          core::Span *ctx) const;
 };
 
+// fhe.Proof (ligero.go:372-379) as LigeroProveReference fills it: the plain prover's output
+struct Proof {
+    LigeroMetadata Metadata;
+    std::vector<uint8_t> Root;
+    std::vector<uint64_t> MatR, MatZ;                  // one field element per column
+    std::vector<std::vector<uint64_t>> QueriedCols;     // `rows` values of every opened encoded column
+    std::vector<std::vector<core::Digest>> MerklePaths;
+    std::vector<int> QueryIndices;
+};
+// LigeroCommitter.LigeroProveReference (ligero.go:799-953): the prover without encryption, on the device
+// through the same C ABI -- a context whose one modulus is T holds the matrix column by column
+// (lumen_plain_inner_products's header comment).  matrix: row-major [rows][cols].
+Proof LigeroProveReference(const LigeroCommitter &c, const std::vector<uint64_t> &matrix, core::Element point,
+                           core::PrimeField &field, core::Transcript &transcript, int device = 0);
+
 // matrixInnerSumEval (ligero.go:299-370), without the ring switch
 Ciphertexts matrixInnerSumEval(const Ciphertexts &matrix, const Plaintext &plaintext, int rows, ServerBFV &backend);
 std::vector<int> sampleQueryIndices(core::Transcript &transcript, int queries, int extCols); // ligero.go:638-644

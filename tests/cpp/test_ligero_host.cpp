@@ -161,6 +161,18 @@ int main(int argc, char **argv) {
         REQUIRE(MatZ[j] == sz, "MatZ differs at [%d]", j);
     }
 
+    // ---- the same equality against the plain prover run on the device (LigeroProveReference through the C ABI:
+    // a context whose one modulus is T), as ligero_test.go:150-174 does with the Go one
+    if (rows >= 512) {
+        core::Transcript plainT("test");
+        fhe::Proof ref = fhe::LigeroProveReference(ligero, matrix, z, ptField, plainT);
+        REQUIRE(ref.MatR == MatR, "MatR differs from LigeroProveReference on the device");
+        REQUIRE(ref.MatZ == MatZ, "MatZ differs from LigeroProveReference on the device");
+        REQUIRE(ref.QueryIndices == proof.QueryIndices, "plain and encrypted provers open different columns");
+        for (size_t qi = 0; qi < ref.QueriedCols.size(); qi++)
+            REQUIRE(ref.QueriedCols[qi] == decrypt(hQ, (int)qi, rows), "opened column %zu differs from the plain prover's", qi);
+    }
+
     // ---- Proof.Verify (ligero.go:517-574)
     std::vector<uint64_t> encR(S), encZ(S);
     lo_plain_encode(MatR.data(), cols, rhoInv, Modulus, ptField.RootsForward().data(), S, encR.data());

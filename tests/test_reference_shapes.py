@@ -204,3 +204,49 @@ def test_config_ring_switch_to_logn10(oracle, config):
     got = ctx.ring_switch(ctx.upload(cts))
     for c in range(2):
         assert np.array_equal(got[c], P.ring_switch(cts[c], key, 10)), c
+
+
+@pytest.mark.parametrize("rows,cols", [(2048, 64), (2048, 1024)])
+def test_plain_prover_on_the_device(oracle, rows, cols):
+    """LigeroProveReference (fhe/ligero.go:799-953), the plain prover the client checks a decrypted proof
+    against, on the same kernels: a context whose one modulus is T, column j of the plain matrix = one
+    2 x 1 x (rows/2) "ciphertext".  core.Encode of every row, the byte-for-byte leaves
+    (binary.Write of the column, ligero.go:866-872), the Merkle root, MatR / MatZ and the queried columns
+    against the oracle's plain field code.  (2048 x 1024 is TestLigeroE2E's shape.)"""
+    from lumenos_amd import params as lp
+    from lumenos_amd.hip import Context
+    from oracle.loader import Transcript
+    rho, log_n = 2, (rows // 2).bit_length() - 1
+    S = cols * rho
+    psi = pow(lp.primitive_root(T_REF), (T_REF - 1) // (2 << log_n), T_REF)
+    ctx = Context(log_n, [T_REF], [], [psi], T_REF)
+    matrix = oracle.witness(rows, cols, T_REF)                                   # [rows][cols]
+    columns = np.ascontiguousarray(matrix.T).reshape(cols, 2, 1, rows // 2)      # column j as lanes
+    roots = oracle.field_roots(T_REF, S)
+    ctx.field_set(roots)
+    m = ctx.upload(columns)
+    enc = ctx.encode(m, np.zeros((2, 1, rows // 2), dtype=np.uint64), rho)       # zero padding of core.Encode
+    got = enc.download().reshape(S, rows)
+    want = np.stack([oracle.plain_encode(matrix[i], rho, T_REF, roots) for i in range(rows)])  # [rows][S]
+    assert np.array_equal(got, want.T), "core.Encode of the rows"
+    ctx.leaf_format_set(b"", b"", b"")                                           # leaf = the column's bytes
+    dig = ctx.leaf_digests(enc)
+    for j in (0, 1, S // 2, S - 1):
+        assert dig[j].tobytes() == oracle.sha256(want[:, j].astype("<u8").tobytes()), j
+    _, root = ctx.merkle_build(dig)
+    assert root == oracle.merkle(np.stack([np.frombuffer(oracle.sha256(want[:, j].astype("<u8").tobytes()), dtype=np.uint8)
+                                           for j in range(S)]))[1]
+    t = Transcript(oracle, "test")
+    r = np.array([t.sample_u64("r") for _ in range(rows)], dtype=np.uint64)       # raw u64 words (SampleFields)
+    mat_r = ctx.plain_inner_products(m, r)
+    M, R = matrix.astype(object), r.astype(object) % T_REF
+    assert [int(x) for x in mat_r[:64]] == [int(sum(M[:, j] * R) % T_REF) for j in range(min(cols, 64))], "MatR"
+    b = np.array([pow(1, i, T_REF) for i in range(rows)], dtype=np.uint64)       # z = 1: b_i = (z^cols)^i = 1
+    mat_z = ctx.plain_inner_products(m, b)
+    assert [int(x) for x in mat_z[:16]] == [int(sum(M[:, j]) % T_REF) for j in range(16)], "MatZ"
+    assert int(sum(int(x) for x in mat_z) % T_REF) == int(M.sum() % T_REF)       # P(1) of the witness polynomial
+    if (rows, cols) == (2048, 1024):
+        assert int(M.sum() % T_REF) == 59828798142202325                          # results/baseline/client/bench_2048x1024_12.txt:22
+    idx = np.array([3, S - 1, 3, 0], dtype=np.uint32)
+    assert np.array_equal(ctx.gather(enc, idx).download().reshape(4, rows), want.T[idx])
+    ctx.close()

@@ -83,10 +83,6 @@ struct lumen_ctx {
     hipStream_t stream = nullptr;  // where every entry point enqueues (may be swapped to stream2 internally)
     hipStream_t stream2 = nullptr; // second lane for independent column batches (key-switch pipeline)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // low-priority streams, one per lane, for the HBM-bound gadget product of a key switch: it runs in
-    // the gaps the VALU-bound transforms of the other lane leave (LUMEN_KS_OVERLAP, lm_keyswitch.hip)
-    hipStream_t stream_lo[2] = {nullptr, nullptr};
-    hipEvent_t ev_lo_a[2] = {nullptr, nullptr}, ev_lo_b[2] = {nullptr, nullptr};
     hipStream_t stream_aux = nullptr; // side jobs that overlap the main stream (leaf hashing)
     hipEvent_t ev_aux = nullptr;
     uint32_t aux_digests = 0;         // leaves of the lumen_leaf_digests_begin job in flight

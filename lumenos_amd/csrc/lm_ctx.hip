@@ -57,8 +57,6 @@ lm_shared::~lm_shared() {
 void lm_sync_all(lumen_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
-    for (int i = 0; i < 2; i++)
-        if (ctx->stream_lo[i]) hipStreamSynchronize(ctx->stream_lo[i]);
     if (ctx->stream_aux) hipStreamSynchronize(ctx->stream_aux);
 }
 
@@ -262,11 +260,6 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
         for (int i = 0; i < 2; i++) {
             if (ctx->io_host[i]) hipHostFree(ctx->io_host[i]);
             if (ctx->ev_io[i]) hipEventDestroy(ctx->ev_io[i]);
-        }
-        for (int i = 0; i < 2; i++) {
-            if (ctx->ev_lo_a[i]) hipEventDestroy(ctx->ev_lo_a[i]);
-            if (ctx->ev_lo_b[i]) hipEventDestroy(ctx->ev_lo_b[i]);
-            if (ctx->stream_lo[i]) hipStreamDestroy(ctx->stream_lo[i]);
         }
         if (ctx->ev_stage) hipEventDestroy(ctx->ev_stage);
         if (ctx->ev_aux) hipEventDestroy(ctx->ev_aux);

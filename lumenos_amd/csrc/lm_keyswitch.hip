@@ -652,29 +652,6 @@ static uint32_t ks_lanes() {
     }();
     return n;
 }
-// LUMEN_KS_OVERLAP=1 (with two lanes): the gadget product -- the one HBM-bound step of a rotation,
-// 17 % of a step at the copy bandwidth -- leaves its lane's stream for a low-priority stream, so that it
-// is dispatched into whatever the other lane's VALU-bound transforms (one 144 KB workgroup per CU, 352 of
-// a SIMD's 512 VGPRs) leave free instead of competing with them for whole CUs.
-static bool ks_overlap() {
-    static const bool v = [] {
-        const char *e = getenv("LUMEN_KS_OVERLAP");
-        return e && atoi(e) == 1;
-    }();
-    return v;
-}
-static int lo_streams(lumen_ctx *ctx) {
-    if (ctx->stream_lo[0]) return 0;
-    int least = 0, greatest = 0;
-    LM_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    for (int i = 0; i < 2; i++) {
-        LM_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_lo[i], hipStreamNonBlocking, least));
-        LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_lo_a[i], hipEventDisableTiming));
-        LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_lo_b[i], hipEventDisableTiming));
-    }
-    return 0;
-}
-
 struct LaneGuard {
     lumen_ctx *ctx;
     hipStream_t saved;
@@ -722,26 +699,10 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
     }
     // 3. gadget product
     {
-        hipStream_t lane_stream = ctx->stream;
-        const int lane = lane_stream == ctx->stream2 ? 1 : 0;
-        const bool lo = ks_overlap() && ks_lanes() > 1;
-        if (lo) { // hand over to the low-priority stream of this lane, behind the extension
-            if (int rc = lo_streams(ctx)) return rc;
-            LM_HIP(ctx, hipEventRecord(ctx->ev_lo_a[lane], lane_stream));
-            LM_HIP(ctx, hipStreamWaitEvent(ctx->stream_lo[lane], ctx->ev_lo_a[lane], 0));
-            ctx->stream = ctx->stream_lo[lane]; // the profiling events of the scope belong there too
-        }
-        {
-            lm_prof_scope ps(ctx, "ks_mac", (uint64_t)B);
-            dim3 grid(((N / LM_MAC_VEC + 255) / 256) * LK * ((B + LM_MAC_COLS - 1) / LM_MAC_COLS));
-            hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, s.ext, acc, gk.d_key, s.u, B, L, K, beta,
-                               ctx->logN, ctx->mods);
-        }
-        if (lo) {
-            ctx->stream = lane_stream;
-            LM_HIP(ctx, hipEventRecord(ctx->ev_lo_b[lane], ctx->stream_lo[lane]));
-            LM_HIP(ctx, hipStreamWaitEvent(lane_stream, ctx->ev_lo_b[lane], 0));
-        }
+        lm_prof_scope ps(ctx, "ks_mac", (uint64_t)B);
+        dim3 grid(((N / LM_MAC_VEC + 255) / 256) * LK * ((B + LM_MAC_COLS - 1) / LM_MAC_COLS));
+        hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, s.ext, acc, gk.d_key, s.u, B, L, K, beta,
+                           ctx->logN, ctx->mods);
         LM_HIP(ctx, hipGetLastError());
     }
     // 4a. P limbs of u -> coefficient domain (in place)

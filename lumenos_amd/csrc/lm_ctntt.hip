@@ -42,6 +42,9 @@
 #define LM_CT_ILP 2 // ops a thread row has in flight per layer (1: 59.6 ms, 2: 55.1, 4: 64.6, 8: 92.3 per Encode at D)
 #endif
 #define LM_NOSLOT 0xFFFFFFFFu
+#define LM_MOP_WORDS 16 // words of a work item of the register-blocked kernel: n | slots[2] | - | pre[8] | pad
+#define LM_CB_W 64      // its lane tile: one wave per slot row, so a work item is wave-uniform
+#define LM_CB_THREADS 512
 
 // ------------------------------------------------------------ schedule compiler
 namespace {
@@ -52,14 +55,37 @@ struct Op {
     int32_t tw;    // table index, -1 = RootForward(8)^3
 };
 
+// The same walk at the granularity the register-blocked kernel works at: the hard-coded base cases of
+// nttInner (2, 4 and 8 ciphertexts: ntt.go:24-244) are ONE item each, a six-step twiddle (ntt.go:268) is
+// an item of its own.  first_op: index of the item's first primitive op.
+struct Item {
+    uint8_t n;        // 2 / 4 / 8: base case on slot[0..n); 1: twiddle multiplication of slot[0] by table entry tw
+    uint32_t slot[8]; // physical slots, in the order of the Go slice when the base case starts
+    int32_t tw;
+    size_t first_op;
+};
+
 struct Walker {
     // state of the Go slice `v`: logical position -> physical slot
     std::vector<uint32_t> v;
     std::vector<Op> ops;
+    std::vector<Item> items;
     uint32_t fieldN;
 
     void bfly(uint32_t i, uint32_t j) { ops.push_back({0, v[i], v[j], 0}); }
     void mul(uint32_t i, int32_t tw) { ops.push_back({1, v[i], 0, tw}); }
+    void block(uint32_t i, uint8_t n) {
+        Item it{};
+        it.n = n, it.first_op = ops.size();
+        for (uint8_t k = 0; k < n; k++) it.slot[k] = v[i + k];
+        items.push_back(it);
+    }
+    void twiddle(uint32_t i, int32_t tw) {
+        Item it{};
+        it.n = 1, it.slot[0] = v[i], it.tw = tw, it.first_op = ops.size();
+        items.push_back(it);
+        mul(i, tw);
+    }
     void transpose(uint32_t start, uint32_t rows, uint32_t cols) { // core/math.go:38-60
         std::vector<uint32_t> t(v.begin() + start, v.begin() + start + (size_t)rows * cols);
         for (uint32_t i = 0; i < rows; i++)
@@ -72,9 +98,10 @@ struct Walker {
     void walk(uint32_t start, uint32_t len, uint32_t size) {
         if (size <= 1) return;
         if (size == 2) { // ntt.go:24-35
-            for (uint32_t i = start; i < start + len; i += 2) bfly(i, i + 1);
+            for (uint32_t i = start; i < start + len; i += 2) block(i, 2), bfly(i, i + 1);
         } else if (size == 4) { // ntt.go:36-89
             for (uint32_t i = start; i < start + len; i += 4) {
+                block(i, 4);
                 bfly(i, i + 2), bfly(i + 1, i + 3);
                 mul(i + 3, 4);
                 bfly(i, i + 1), bfly(i + 2, i + 3);
@@ -82,6 +109,7 @@ struct Walker {
             }
         } else if (size == 8) { // ntt.go:90-244
             for (uint32_t i = start; i < start + len; i += 8) {
+                block(i, 8);
                 for (uint32_t k = 0; k < 4; k++) bfly(i + k, i + k + 4);
                 mul(i + 5, 8), mul(i + 6, 4), mul(i + 7, -1);
                 bfly(i, i + 2), bfly(i + 1, i + 3);
@@ -104,7 +132,7 @@ struct Walker {
                     uint64_t idx = step;
                     for (uint32_t j = 1; j < n2; j++) {
                         idx %= fieldN;
-                        mul(cs + i * n2 + j, (int32_t)idx);
+                        twiddle(cs + i * n2 + j, (int32_t)idx);
                         idx += step;
                     }
                 }
@@ -120,9 +148,19 @@ struct Layer {
     std::vector<uint32_t> mul;  // a | tw_id << 8
 };
 
+// one work item of the register-blocked kernel: a base case with the six-step twiddles that precede it
+// folded into its load (pre[k] = table entry slot k is multiplied by first, LM_NOSLOT = none), or a
+// twiddle multiplication nothing follows in this transform (n == 1)
+struct MOp {
+    uint8_t n;
+    uint8_t slot[8]; // local slot ids
+    uint32_t pre[8];
+};
+
 struct Group {
     std::vector<uint32_t> slots;
     std::vector<Layer> layers;
+    std::vector<std::vector<MOp>> mlayers;
 };
 
 struct Pass {
@@ -140,6 +178,10 @@ struct Plan {
         uint32_t *d_ops = nullptr;   // [ngroups][total]
         uint32_t *d_layer = nullptr; // [nlayers][3]: offset, nb, nm (padded counts)
         uint32_t total = 0;
+        // the same pass for the register-blocked kernel
+        uint32_t *d_mops = nullptr;   // [ngroups][mtotal][LM_MOP_WORDS]
+        uint32_t *d_mlayer = nullptr; // [mlayers][2]: offset, count (padded)
+        uint32_t mtotal = 0, mlayers = 0;
     };
     std::vector<Dev> dev;
     uint32_t *d_out_pos = nullptr;
@@ -149,6 +191,8 @@ struct Plan {
             hipFree(d.d_slots);
             hipFree(d.d_ops);
             hipFree(d.d_layer);
+            hipFree(d.d_mops);
+            hipFree(d.d_mlayer);
         }
         hipFree(d_out_pos);
     }
@@ -163,8 +207,11 @@ struct UF {
     }
 };
 
+// items[ilo, ihi) are the work items of ops[lo, hi); pending[slot]: the twiddle a six-step multiplication
+// left on the slot for the next base case that loads it (carried across passes); last: flush what is left
 void close_pass(const std::vector<Op> &ops, size_t lo, size_t hi, UF &uf, uint32_t fieldN,
-                uint32_t count, Plan &plan) {
+                uint32_t count, Plan &plan, const std::vector<Item> &items, size_t ilo, size_t ihi,
+                std::vector<uint32_t> &pending, bool last_pass) {
     if (lo == hi) return;
     // components touched by ops[lo,hi)
     std::map<uint32_t, uint32_t> gid;
@@ -210,6 +257,47 @@ void close_pass(const std::vector<Op> &ops, size_t lo, size_t hi, UF &uf, uint32
             last[g][a] = last[g][b] = lay + 1;
         }
     }
+    // the same ops as work items of the register-blocked kernel
+    {
+        std::vector<std::vector<uint32_t>> mlast;
+        auto emit = [&](uint32_t g, const MOp &m) {
+            if (mlast.size() <= g) mlast.resize(g + 1);
+            if (mlast[g].size() < pass.groups[g].slots.size()) mlast[g].resize(pass.groups[g].slots.size(), 0);
+            uint32_t lay = 0;
+            for (uint8_t k = 0; k < m.n; k++) lay = std::max(lay, mlast[g][m.slot[k]]);
+            Group &G = pass.groups[g];
+            if (G.mlayers.size() <= lay) G.mlayers.resize(lay + 1);
+            G.mlayers[lay].push_back(m);
+            for (uint8_t k = 0; k < m.n; k++) mlast[g][m.slot[k]] = lay + 1;
+        };
+        auto lone = [&](uint32_t slot) { // the pending twiddle of `slot` as a work item of its own
+            MOp m{};
+            const uint32_t g = group_of(slot);
+            m.n = 1, m.slot[0] = (uint8_t)local_of(g, slot), m.pre[0] = pending[slot];
+            pending[slot] = LM_NOSLOT;
+            emit(g, m);
+        };
+        for (size_t i = ilo; i < ihi; i++) {
+            const Item &it = items[i];
+            if (it.n == 1) {
+                if (pending[it.slot[0]] != LM_NOSLOT) lone(it.slot[0]);
+                pending[it.slot[0]] = it.tw < 0 ? fieldN : (uint32_t)it.tw;
+                continue;
+            }
+            MOp m{};
+            m.n = it.n;
+            const uint32_t g = group_of(it.slot[0]);
+            for (uint8_t k = 0; k < it.n; k++) {
+                m.slot[k] = (uint8_t)local_of(g, it.slot[k]);
+                m.pre[k] = pending[it.slot[k]];
+                pending[it.slot[k]] = LM_NOSLOT;
+            }
+            emit(g, m);
+        }
+        if (last_pass)
+            for (uint32_t sl = 0; sl < count; sl++)
+                if (pending[sl] != LM_NOSLOT) lone(sl);
+    }
     // every slot must cross the pass (the next pass reads the pass's output
     // buffer): slots no op touched become op-less single-slot components
     {
@@ -239,6 +327,12 @@ void close_pass(const std::vector<Op> &ops, size_t lo, size_t hi, UF &uf, uint32
             for (uint32_t op : g.layers[l].bfly) bin.layers[l].bfly.push_back(op + base + (base << 16));
             for (uint32_t op : g.layers[l].mul) bin.layers[l].mul.push_back(op + base);
         }
+        if (bin.mlayers.size() < g.mlayers.size()) bin.mlayers.resize(g.mlayers.size());
+        for (size_t l = 0; l < g.mlayers.size(); l++)
+            for (MOp m : g.mlayers[l]) {
+                for (uint8_t k = 0; k < m.n; k++) m.slot[k] = (uint8_t)(m.slot[k] + base);
+                bin.mlayers[l].push_back(m);
+            }
     }
     plan.passes.push_back(std::move(packed));
 }
@@ -252,30 +346,38 @@ Plan *build_plan(uint32_t count, uint32_t size, uint32_t fieldN) {
     Plan *plan = new Plan();
     plan->out_pos.assign(count, 0);
     for (uint32_t k = 0; k < count; k++) plan->out_pos[w.v[k]] = k;
-    // cut into passes: a pass ends when a butterfly would merge two
-    // components into more than LM_CT_GROUP slots
+    for (const Op &o : w.ops) (o.is_mul ? plan->n_mul : plan->n_bfly)++;
+    // cut into passes: a pass ends when a base case would merge components into more than LM_CT_GROUP
+    // slots (a base case is never split: its ops are one work item of the register-blocked kernel)
     UF uf(count);
-    size_t lo = 0;
-    for (size_t i = 0; i < w.ops.size(); i++) {
-        const Op &o = w.ops[i];
-        if (o.is_mul) {
-            plan->n_mul++;
-            continue;
+    std::vector<uint32_t> pending(count, LM_NOSLOT);
+    size_t ilo = 0;
+    for (size_t i = 0; i < w.items.size(); i++) {
+        const Item &it = w.items[i];
+        if (it.n == 1) continue;
+        uint32_t roots[8], nr = 0, total = 0;
+        for (uint8_t k = 0; k < it.n; k++) {
+            const uint32_t r = uf.find(it.slot[k]);
+            if (std::find(roots, roots + nr, r) == roots + nr) roots[nr++] = r, total += uf.sz[r];
         }
-        plan->n_bfly++;
-        uint32_t ra = uf.find(o.a), rb = uf.find(o.b);
-        if (ra == rb) continue;
-        if (uf.sz[ra] + uf.sz[rb] > LM_CT_GROUP) {
-            close_pass(w.ops, lo, i, uf, fieldN, count, *plan);
-            lo = i;
+        if (nr > 1 && total > LM_CT_GROUP) {
+            close_pass(w.ops, w.items[ilo].first_op, it.first_op, uf, fieldN, count, *plan, w.items, ilo, i, pending, false);
+            ilo = i;
             uf = UF(count);
-            ra = o.a, rb = o.b;
+            nr = 0;
+            for (uint8_t k = 0; k < it.n; k++) roots[nr++] = it.slot[k];
         }
-        if (uf.sz[ra] < uf.sz[rb]) std::swap(ra, rb);
-        uf.p[rb] = ra;
-        uf.sz[ra] += uf.sz[rb];
+        for (uint32_t k = 1; k < nr; k++) {
+            uint32_t ra = uf.find(roots[0]), rb = uf.find(roots[k]);
+            if (ra == rb) continue;
+            if (uf.sz[ra] < uf.sz[rb]) std::swap(ra, rb);
+            uf.p[rb] = ra;
+            uf.sz[ra] += uf.sz[rb];
+        }
     }
-    close_pass(w.ops, lo, w.ops.size(), uf, fieldN, count, *plan);
+    if (!w.items.empty())
+        close_pass(w.ops, w.items[ilo].first_op, w.ops.size(), uf, fieldN, count, *plan, w.items, ilo, w.items.size(),
+                   pending, true);
     return plan;
 }
 
@@ -313,6 +415,32 @@ int upload_plan(lumen_ctx *ctx, Plan *plan, uint32_t count) {
                 std::copy(g.layers[l].mul.begin(), g.layers[l].mul.end(), o + layer[3 * l + 1]);
             }
         }
+        // work items of the register-blocked kernel, layer by layer, padded with empty items (n = 0)
+        for (Group &g : pass.groups) d.mlayers = std::max<uint32_t>(d.mlayers, (uint32_t)g.mlayers.size());
+        std::vector<uint32_t> mlayer(2 * d.mlayers, 0);
+        for (uint32_t l = 0; l < d.mlayers; l++) {
+            uint32_t n = 0;
+            for (Group &g : pass.groups)
+                if (l < g.mlayers.size()) n = std::max<uint32_t>(n, (uint32_t)g.mlayers[l].size());
+            mlayer[2 * l] = d.mtotal, mlayer[2 * l + 1] = n;
+            d.mtotal += n;
+        }
+        std::vector<uint32_t> mops((size_t)d.ngroups * d.mtotal * LM_MOP_WORDS, 0);
+        for (uint32_t gi = 0; gi < d.ngroups; gi++) {
+            Group &g = pass.groups[gi];
+            for (uint32_t l = 0; l < g.mlayers.size(); l++)
+                for (size_t i = 0; i < g.mlayers[l].size(); i++) {
+                    const MOp &m = g.mlayers[l][i];
+                    uint32_t *o = mops.data() + ((size_t)gi * d.mtotal + mlayer[2 * l] + i) * LM_MOP_WORDS;
+                    o[0] = m.n;
+                    for (int k = 0; k < 8; k++) o[1 + k / 4] |= (uint32_t)m.slot[k] << (8 * (k % 4));
+                    for (int k = 0; k < 8; k++) o[4 + k] = k < m.n ? m.pre[k] : LM_NOSLOT;
+                }
+        }
+        LM_HIP(ctx, hipMalloc((void **)&d.d_mops, std::max<size_t>(mops.size(), 1) * 4));
+        LM_HIP(ctx, hipMalloc((void **)&d.d_mlayer, std::max<size_t>(mlayer.size(), 1) * 4));
+        if (!mops.empty()) LM_HIP(ctx, hipMemcpy(d.d_mops, mops.data(), mops.size() * 4, hipMemcpyHostToDevice));
+        if (!mlayer.empty()) LM_HIP(ctx, hipMemcpy(d.d_mlayer, mlayer.data(), mlayer.size() * 4, hipMemcpyHostToDevice));
         LM_HIP(ctx, hipMalloc((void **)&d.d_slots, slots.size() * 4));
         LM_HIP(ctx, hipMalloc((void **)&d.d_ops, std::max<size_t>(ops.size(), 1) * 4));
         LM_HIP(ctx, hipMalloc((void **)&d.d_layer, std::max<size_t>(layer.size(), 1) * 4));
@@ -444,6 +572,144 @@ __global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mo
     }
 }
 
+
+// ------------------------------------------------- register-blocked kernel
+// The interpreter above spends 39 VALU instructions per ciphertext-level op and lane (SQ counters, D):
+// op words, two LDS round trips and a barrier layer per butterfly.  But nttInner only ever does three
+// things to a lane: the hard-coded transforms of 2, 4 and 8 ciphertexts and the six-step twiddles between
+// them.  Here a WAVE owns a work item: it loads the item's 2/4/8 slot rows (64 lanes each, so the item,
+// its slots and its twiddles are wave-uniform: descriptor and scalars come through the scalar cache into
+// SGPRs), multiplies by the twiddles that precede the base case, runs the base case in registers and
+// writes the rows back -- one LDS round trip and one barrier per base case instead of one per butterfly
+// layer, no per-lane op decoding.  Values stay in [0, 2q) in LDS, as above.
+struct ct_blocks_args {
+    const u64 *srcA, *srcB;
+    u64 *dst;
+    const uint32_t *slots;   // [ngroups][gsize]
+    const uint32_t *mops;    // [ngroups][mtotal][LM_MOP_WORDS]
+    const uint32_t *mlayer;  // [mlayers][2]
+    const uint32_t *out_pos; // slot -> destination index, or NULL for identity
+    const tw_t *scal;        // [nl_table][fieldN+1]
+    uint32_t splitA, gsize, mtotal, mlayers, fieldN1, logN, nl, group0;
+    // the buffer between two passes is tile-major, [lane tile][slot][64]: what a workgroup writes in one pass
+    // and another reads in the next lies within count * 512 bytes instead of being strewn over the whole
+    // buffer at the pitch of a ciphertext (3 MB at D)
+    uint32_t src_tiled, dst_tiled, count;
+    size_t ctw;
+};
+struct cb_consts {
+    u64 q2, n2q, nq;
+    tw_t c4, c8, c83; // RootForward(4), RootForward(8), RootForward(8)^3 for this limb
+};
+__device__ __forceinline__ void cb_bfly(u64 &x, u64 &y, const cb_consts &c) { // Evaluator.Add / Sub
+    const u64 s = ct_csub2q(x + y, c.n2q);
+    y = ct_csub2q(x + c.q2 - y, c.n2q);
+    x = s;
+}
+__device__ __forceinline__ u64 cb_mul(u64 x, const tw_t &w, const cb_consts &c) { // Evaluator.Mul(ct, uint64): < 3q -> < 2q
+    return ct_csub2q(lm_shoup3<true>(x, w.w, w.wp, c.nq), c.n2q);
+}
+template <int n>
+__device__ __forceinline__ void cb_base(u64 *e, const cb_consts &c) {
+    if (n == 2) { // ntt.go:24-35
+        cb_bfly(e[0], e[1], c);
+    } else if (n == 4) { // ntt.go:36-89
+        cb_bfly(e[0], e[2], c), cb_bfly(e[1], e[3], c);
+        e[3] = cb_mul(e[3], c.c4, c);
+        cb_bfly(e[0], e[1], c), cb_bfly(e[2], e[3], c);
+    } else { // ntt.go:90-244
+#pragma unroll
+        for (int k = 0; k < 4; k++) cb_bfly(e[k], e[k + 4], c);
+        e[5] = cb_mul(e[5], c.c8, c), e[6] = cb_mul(e[6], c.c4, c), e[7] = cb_mul(e[7], c.c83, c);
+        cb_bfly(e[0], e[2], c), cb_bfly(e[1], e[3], c);
+        e[3] = cb_mul(e[3], c.c4, c);
+        cb_bfly(e[0], e[1], c), cb_bfly(e[2], e[3], c), cb_bfly(e[4], e[6], c), cb_bfly(e[5], e[7], c);
+        e[7] = cb_mul(e[7], c.c4, c);
+        cb_bfly(e[4], e[5], c), cb_bfly(e[6], e[7], c);
+    }
+}
+// one work item: d = its descriptor (wave-uniform, in SGPRs)
+template <int n>
+__device__ __forceinline__ void cb_item(u64 *buf, const uint32_t *d, const tw_t *scal, uint32_t l, const cb_consts &c) {
+    u64 e[n];
+    uint32_t at[n];
+#pragma unroll
+    for (int k = 0; k < n; k++) {
+        at[k] = ((d[1 + k / 4] >> (8 * (k % 4))) & 0xFF) * LM_CB_W + l;
+        e[k] = buf[at[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < n; k++)
+        if (d[4 + k] != LM_NOSLOT) e[k] = cb_mul(e[k], scal[d[4 + k]], c); // uniform branch, scalar load
+    if (n > 1) cb_base<n>(e, c);
+#pragma unroll
+    for (int k = 0; k < n; k++) buf[at[k]] = e[k];
+}
+__global__ __launch_bounds__(LM_CB_THREADS) void k_ct_blocks(ct_blocks_args a, lm_mods mods) {
+    extern __shared__ __attribute__((aligned(16))) u64 buf[]; // [gsize][64]
+    constexpr uint32_t NW = LM_CB_THREADS / 64;
+    const uint32_t l = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t group = blockIdx.y + a.group0;
+    const size_t lane = (size_t)blockIdx.x * LM_CB_W + l;
+    // tiles are aligned runs of 64 <= N lanes: the limb is uniform in the workgroup
+    const uint32_t limb = (uint32_t)(((size_t)blockIdx.x * LM_CB_W) >> a.logN) % a.nl;
+    const tw_t *__restrict__ scal = a.scal + (size_t)limb * a.fieldN1;
+    cb_consts c;
+    {
+        const u64 q = mods.m[limb].q;
+        c.q2 = 2 * q, c.n2q = 0 - c.q2, c.nq = 0 - q;
+        c.c4 = scal[a.fieldN1 > 4 ? 4 : 0], c.c8 = scal[a.fieldN1 > 8 ? 8 : 0], c.c83 = scal[a.fieldN1 - 1];
+    }
+    const uint32_t *__restrict__ slots = a.slots + (size_t)group * a.gsize;
+    for (uint32_t s = wave; s < a.gsize; s += NW) {
+        const uint32_t slot = slots[s];
+        if (slot == LM_NOSLOT) continue;
+        if (a.src_tiled) {
+            buf[s * LM_CB_W + l] = a.srcA[((size_t)blockIdx.x * a.count + slot) * LM_CB_W + l];
+        } else {
+            const u64 *src = slot < a.splitA ? a.srcA + (size_t)slot * a.ctw : a.srcB;
+            buf[s * LM_CB_W + l] = src[lane];
+        }
+    }
+    __syncthreads();
+    const uint32_t *__restrict__ mops = a.mops + (size_t)group * a.mtotal * LM_MOP_WORDS;
+    for (uint32_t ly = 0; ly < a.mlayers; ly++) {
+        const uint32_t off = a.mlayer[2 * ly], cnt = a.mlayer[2 * ly + 1];
+        for (uint32_t i = wave; i < cnt; i += NW) {
+            const uint32_t *d = mops + (size_t)(off + i) * LM_MOP_WORDS;
+            switch (d[0]) { // wave-uniform
+            case 8: cb_item<8>(buf, d, scal, l, c); break;
+            case 4: cb_item<4>(buf, d, scal, l, c); break;
+            case 2: cb_item<2>(buf, d, scal, l, c); break;
+            case 1: cb_item<1>(buf, d, scal, l, c); break;
+            default: break; // padding
+            }
+        }
+        __syncthreads();
+    }
+    const u64 q = c.q2 >> 1;
+    for (uint32_t s = wave; s < a.gsize; s += NW) {
+        const uint32_t slot = slots[s];
+        if (slot == LM_NOSLOT) continue;
+        const uint32_t pos = a.out_pos ? a.out_pos[slot] : slot;
+        if (pos == LM_NOSLOT) continue; // a slot this rank's share of the next pass never reads
+        const u64 v = lm_csub(buf[s * LM_CB_W + l], q);
+        if (a.dst_tiled)
+            a.dst[((size_t)blockIdx.x * a.count + pos) * LM_CB_W + l] = v;
+        else
+            a.dst[(size_t)pos * a.ctw + lane] = v;
+    }
+}
+
+static bool ct_blocks_enabled() { // LUMEN_CT_BLOCKS=0: the op-by-op interpreter everywhere (A/B switch)
+    static const bool v = [] {
+        const char *e = getenv("LUMEN_CT_BLOCKS");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
+
 // final_g0/final_ng: groups of the final pass to run (all when final_ng == 0); final_pos: device
 // table slot -> output position for that pass (the plan's own permutation when NULL)
 // keep_pos: for a sharded run, device table slot -> slot (or LM_NOSLOT) applied to the stores of the
@@ -474,6 +740,22 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
         a.gsize = d.gsize, a.total = d.total, a.nlayers = d.nlayers;
         a.fieldN1 = ctx->fieldN + 1, a.logN = ctx->logN - logw, a.nl = nl, a.ctw = ctw; // logN: limb width of THESE sets
         const uint32_t ng = final_pass && final_ng ? final_ng : d.ngroups;
+        if (ct_blocks_enabled() && ((ctx->N >> logw) % LM_CB_W) == 0) { // a tile must not straddle two limbs
+            ct_blocks_args b;
+            b.srcA = a.srcA, b.srcB = a.srcB, b.dst = a.dst, b.slots = a.slots, b.out_pos = a.out_pos, b.scal = a.scal;
+            b.mops = d.d_mops, b.mlayer = d.d_mlayer, b.mtotal = d.mtotal, b.mlayers = d.mlayers;
+            b.splitA = a.splitA, b.gsize = a.gsize, b.fieldN1 = a.fieldN1, b.logN = a.logN, b.nl = a.nl;
+            b.group0 = a.group0, b.ctw = a.ctw;
+            b.src_tiled = p > 0, b.dst_tiled = !final_pass, b.count = count;
+            dim3 grid((uint32_t)(ctw / LM_CB_W), ng);
+            const size_t lds = (size_t)d.gsize * LM_CB_W * sizeof(u64);
+            LM_LDS_ATTR(ctx, k_ct_blocks, lds);
+            lm_prof_scope ps(ctx, "ct_axis_pass", (uint64_t)ng * d.gsize);
+            hipLaunchKernelGGL(k_ct_blocks, grid, dim3(LM_CB_THREADS), lds, ctx->stream, b, ctx->mods);
+            LM_HIP(ctx, hipGetLastError());
+            cur = tmp, split = count, curB = nullptr;
+            continue;
+        }
         dim3 grid((uint32_t)(ctw / LM_CT_W), ng);
         size_t lds = (size_t)d.gsize * LM_CT_W * sizeof(u64) + ((size_t)d.total + 3 * d.nlayers) * sizeof(uint32_t);
         LM_LDS_ATTR(ctx, k_ct_pass, lds);

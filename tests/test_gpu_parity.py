@@ -356,6 +356,26 @@ def test_encode_shards_cover_full_encode(oracle, small, world):
         seen[idx] += 1
     assert np.all(seen == 1)
 
+def test_encode_narrow_lane_shard_runs_the_interpreter(oracle, small):
+    """A lane shard narrower than the 64-lane tile of the register-blocked kernel (N/W = 32 coefficients per
+    limb: a world of 32 ranks at N = 1024) takes the op-by-op interpreter (k_ct_pass): both kernels replay
+    the same schedule, so the shard must still equal the corresponding lanes of the full-width Encode."""
+    P, ctx = small
+    cols, rho, nl, logw = 32, 2, 2, 5
+    Nw = P.N >> logw
+    assert Nw == 32
+    roots = oracle.field_roots(T_REF, cols * rho)
+    ctx.field_set(roots)
+    m = random_cts(P, cols, nl, seed=191)
+    zero = random_cts(P, 1, nl, seed=192)[0]
+    full = ctx.encode(ctx.upload(m), zero, rho).download()
+    assert np.array_equal(full, P.ct_encode(m, rho, zero, roots))
+    for g in (0, 13, 31):
+        lanes = np.ascontiguousarray(m[..., g * Nw:(g + 1) * Nw])
+        e = ctx.encode(ctx.upload_lanes(lanes, logw), np.ascontiguousarray(zero[..., g * Nw:(g + 1) * Nw]), rho)
+        assert np.array_equal(e.download(), full[..., g * Nw:(g + 1) * Nw]), g
+
+
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_encode_lane_shard_alltoall_matches_full(oracle, small, world):

@@ -702,12 +702,11 @@ __global__ __launch_bounds__(LM_CB_THREADS) void k_ct_blocks(ct_blocks_args a, l
     }
 }
 
-static bool ct_blocks_enabled() { // LUMEN_CT_BLOCKS=0: the op-by-op interpreter everywhere (A/B switch)
-    static const bool v = [] {
-        const char *e = getenv("LUMEN_CT_BLOCKS");
-        return !(e && atoi(e) == 0);
-    }();
-    return v;
+// LUMEN_CT_BLOCKS=0: the op-by-op interpreter instead (A/B switch, read at every call so that a test can
+// run both kernels on the same input in one process)
+static bool ct_blocks_enabled() {
+    const char *e = getenv("LUMEN_CT_BLOCKS");
+    return !(e && atoi(e) == 0);
 }
 
 // final_g0/final_ng: groups of the final pass to run (all when final_ng == 0); final_pos: device
@@ -740,7 +739,9 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
         a.gsize = d.gsize, a.total = d.total, a.nlayers = d.nlayers;
         a.fieldN1 = ctx->fieldN + 1, a.logN = ctx->logN - logw, a.nl = nl, a.ctw = ctw; // logN: limb width of THESE sets
         const uint32_t ng = final_pass && final_ng ? final_ng : d.ngroups;
-        if (ct_blocks_enabled() && ((ctx->N >> logw) % LM_CB_W) == 0) { // a tile must not straddle two limbs
+        // (a tile must not straddle two limbs: every supported width, N >= 256 and lane shards of >= 64
+        // coefficients, is a multiple of the 64-lane tile)
+        if (ct_blocks_enabled() && ((ctx->N >> logw) % LM_CB_W) == 0) {
             ct_blocks_args b;
             b.srcA = a.srcA, b.srcB = a.srcB, b.dst = a.dst, b.slots = a.slots, b.out_pos = a.out_pos, b.scal = a.scal;
             b.mops = d.d_mops, b.mlayer = d.d_mlayer, b.mtotal = d.mtotal, b.mlayers = d.mlayers;

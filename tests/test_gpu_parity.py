@@ -356,25 +356,25 @@ def test_encode_shards_cover_full_encode(oracle, small, world):
         seen[idx] += 1
     assert np.all(seen == 1)
 
-def test_encode_narrow_lane_shard_runs_the_interpreter(oracle, small):
-    """A lane shard narrower than the 64-lane tile of the register-blocked kernel (N/W = 32 coefficients per
-    limb: a world of 32 ranks at N = 1024) takes the op-by-op interpreter (k_ct_pass): both kernels replay
-    the same schedule, so the shard must still equal the corresponding lanes of the full-width Encode."""
+def test_encode_interpreter_matches_register_blocked_kernel(oracle, small, monkeypatch):
+    """LUMEN_CT_BLOCKS=0 selects the op-by-op interpreter (k_ct_pass) the register-blocked kernel
+    (k_ct_blocks) replaced: both replay the same schedule, so Encode and the in-place transform must come
+    out identical -- and equal to the oracle -- either way."""
     P, ctx = small
-    cols, rho, nl, logw = 32, 2, 2, 5
-    Nw = P.N >> logw
-    assert Nw == 32
-    roots = oracle.field_roots(T_REF, cols * rho)
+    cols, rho, nl = 64, 2, 3
+    roots = oracle.field_roots(T_REF, 256)
     ctx.field_set(roots)
     m = random_cts(P, cols, nl, seed=191)
     zero = random_cts(P, 1, nl, seed=192)[0]
-    full = ctx.encode(ctx.upload(m), zero, rho).download()
-    assert np.array_equal(full, P.ct_encode(m, rho, zero, roots))
-    for g in (0, 13, 31):
-        lanes = np.ascontiguousarray(m[..., g * Nw:(g + 1) * Nw])
-        e = ctx.encode(ctx.upload_lanes(lanes, logw), np.ascontiguousarray(zero[..., g * Nw:(g + 1) * Nw]), rho)
-        assert np.array_equal(e.download(), full[..., g * Nw:(g + 1) * Nw]), g
-
+    want = P.ct_encode(m, rho, zero, roots)
+    cts = random_cts(P, 256, 2, seed=193)
+    want_ntt = P.ct_ntt(cts, 256, roots)
+    for blocks in ("1", "0"):
+        monkeypatch.setenv("LUMEN_CT_BLOCKS", blocks)
+        assert np.array_equal(ctx.encode(ctx.upload(m), zero, rho).download(), want), blocks
+        s = ctx.upload(cts)
+        ctx.ct_ntt(s, 256)
+        assert np.array_equal(s.download(), want_ntt), blocks
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

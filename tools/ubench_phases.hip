@@ -44,7 +44,21 @@ __device__ __forceinline__ void fwd_first_write(u64 *s, const u64 *e, uint32_t t
     for (int k = 0; k < (1 << R); k++) s[LM_PAD(tid + ((uint32_t)k << log_tl))] = e[k];
 }
 
-template <int LOGN, bool PERSIST, bool OVERLAP = false>
+// wave-local pass of R stages starting at stage S0 on one work item, twiddles given
+template <int LOGN, int R, int S0, bool UW>
+__device__ __forceinline__ void mid_item(u64 *s, const lm_twset<R, UW> &T, const lm_qc &c, uint32_t w) {
+    constexpr uint32_t log_tl = LOGN - S0 - R;
+    const uint32_t blk = w >> log_tl, off = w & ((1u << log_tl) - 1);
+    const uint32_t base = (blk << (log_tl + R)) + off;
+    u64 e[1 << R];
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_tl))];
+    lm_fwd_stages<R, UW>(e, T, c);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_tl))] = e[k];
+}
+
+template <int LOGN, bool PERSIST, bool OVERLAP = false, bool PREFETCH = false, bool TWPIPE = false>
 __global__ __launch_bounds__(1024) void k_fwd(const u64 *src, u64 *dst, uint32_t nlimbs, u64 q, u64 qinv64,
                                               const tw_t *__restrict__ tw, rec_t *rec) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
@@ -52,6 +66,11 @@ __global__ __launch_bounds__(1024) void k_fwd(const u64 *src, u64 *dst, uint32_t
     const uint32_t tid0 = threadIdx.x;
     lm_qc c;
     c.q = q, c.nq = 0 - q, c.q3 = 3 * q, c.qinv64 = qinv64;
+    u64 pf[16]; // PREFETCH: the next transform's coefficients, requested while the current one is in its wave-local passes
+    if (PREFETCH) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) pf[k] = src[(size_t)blockIdx.x * N + tid0 + ((uint32_t)k << (LOGN - 4))];
+    }
     for (uint32_t item = blockIdx.x; item < nlimbs; item += PERSIST ? gridDim.x : nlimbs) {
         // per-iteration copy of the lane index the compiler cannot see through: otherwise every LDS
         // address and twiddle index of the transform is hoisted out of the loop and spilled
@@ -68,7 +87,16 @@ __global__ __launch_bounds__(1024) void k_fwd(const u64 *src, u64 *dst, uint32_t
                 if (k < count) r[k] = lm_reduce_s(v[k], c.q, c.nq, c.qinv64);
             lm_store_run(o, i0, r, count);
         };
-        if (OVERLAP) {
+        if (PREFETCH) {
+            u64 e[16];
+            lm_twset<4, true> T;
+            T.load(tw, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) e[k] = pf[k];
+            lm_fwd_stages<4, true>(e, T, c);
+            __syncthreads(); // the previous item's last pass still reads the LDS
+            fwd_first_write<LOGN, 4>(sm, e, tid);
+        } else if (OVERLAP) {
             u64 e[16];
             fwd_first_regs<LOGN, 4>(e, tw, c, tid, ld);
             __syncthreads(); // the previous item's last pass still reads the LDS
@@ -78,8 +106,54 @@ __global__ __launch_bounds__(1024) void k_fwd(const u64 *src, u64 *dst, uint32_t
             lm_fwd_first<LOGN, 4, true>(sm, tw, c, tid, ld);
         }
         STAMP(1);
+        if (TWPIPE) {
+            // every twiddle set is requested a whole work item (or a barrier wait) before its butterflies:
+            // pass 1's (wave-uniform, SGPRs) before the barrier, pass 2's two per-lane sets under pass 1,
+            // pass 3's under pass 2 -- in the registers pass 2 frees item by item
+            using D4 = lm_deal<LOGN, 4>;
+            using D3 = lm_deal<LOGN, 3>;
+            lm_twset<4, true> T1;
+            T1.load(tw, 4, D4::local(tid, 0) >> (LOGN - 8));
+            __syncthreads();
+            STAMP(2);
+            lm_twset<3, false> A, B;
+            A.load(tw, 8, D3::local(tid, 0) >> (LOGN - 11));
+            B.load(tw, 8, D3::local(tid, 1) >> (LOGN - 11));
+            mid_item<LOGN, 4, 4, true>(sm, T1, c, D4::local(tid, 0));
+            lm_wave_sync();
+            STAMP(3);
+            mid_item<LOGN, 3, 8, false>(sm, A, c, D3::local(tid, 0));
+            A.load(tw, 11, D3::local(tid, 0));
+            mid_item<LOGN, 3, 8, false>(sm, B, c, D3::local(tid, 1));
+            B.load(tw, 11, D3::local(tid, 1));
+            lm_wave_sync();
+            STAMP(4);
+#pragma unroll
+            for (uint32_t m = 0; m < 2; m++) {
+                const uint32_t base = D3::local(tid, m) << 3;
+                u64 e[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) e[k] = sm[LM_PAD(base + k)];
+                lm_fwd_stages<3, false>(e, m ? B : A, c);
+                st(base, e, 8);
+            }
+            STAMP(5);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(6);
+            if ((tid & 63) == 0 && rec) {
+                rec_t &r = rec[(size_t)item * 16 + (tid >> 6)];
+                r.hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+                r.xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+            }
+            continue;
+        }
         __syncthreads();
         STAMP(2);
+        if (PREFETCH && item + gridDim.x < nlimbs) {
+            const u64 *pn = src + (size_t)(item + gridDim.x) * N;
+#pragma unroll
+            for (int k = 0; k < 16; k++) pf[k] = pn[tid + ((uint32_t)k << (LOGN - 4))];
+        }
 #ifdef UB_SETPRIO // waves that lag get the VALU first: the waves of a SIMD finish together instead of one by one
         __builtin_amdgcn_s_setprio(3);
 #endif
@@ -118,23 +192,23 @@ static u64 powmod(u64 a, u64 e, u64 q) {
     return r;
 }
 
-template <bool PERSIST, bool OVERLAP = false>
+template <bool PERSIST, bool OVERLAP = false, bool PREFETCH = false, bool TWPIPE = false>
 static void run(const char *name, const u64 *src, u64 *dst, uint32_t nlimbs, u64 q, const tw_t *tw, rec_t *drec,
                 uint32_t grid) {
     const size_t lds = lm_fwd_lds(14);
-    hipFuncSetAttribute((const void *)k_fwd<14, PERSIST, OVERLAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void *)k_fwd<14, PERSIST, OVERLAP, PREFETCH, TWPIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b;
     hipEventCreate(&a), hipEventCreate(&b);
-    k_fwd<14, PERSIST, OVERLAP><<<grid, 1024, lds>>>(src, dst, nlimbs, q, ~0ull / q, tw, nullptr);
+    k_fwd<14, PERSIST, OVERLAP, PREFETCH, TWPIPE><<<grid, 1024, lds>>>(src, dst, nlimbs, q, ~0ull / q, tw, nullptr);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    k_fwd<14, PERSIST, OVERLAP><<<grid, 1024, lds>>>(src, dst, nlimbs, q, ~0ull / q, tw, nullptr);
+    k_fwd<14, PERSIST, OVERLAP, PREFETCH, TWPIPE><<<grid, 1024, lds>>>(src, dst, nlimbs, q, ~0ull / q, tw, nullptr);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms0;
     hipEventElapsedTime(&ms0, a, b);
     hipEventRecord(a);
-    k_fwd<14, PERSIST, OVERLAP><<<grid, 1024, lds>>>(src, dst, nlimbs, q, ~0ull / q, tw, drec);
+    k_fwd<14, PERSIST, OVERLAP, PREFETCH, TWPIPE><<<grid, 1024, lds>>>(src, dst, nlimbs, q, ~0ull / q, tw, drec);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
@@ -235,5 +309,10 @@ int main() {
     run<true>("persistent, 256 workgroups", src, dst, nlimbs, q, dtw, drec, 256);
     run<true, true>("persistent, 256 workgroups, barrier between pass-0 butterflies and LDS write", src, dst, nlimbs, q, dtw,
                     drec, 256);
+    run<true, false, true>("persistent, 256 workgroups, next transform's loads issued after the barrier", src, dst, nlimbs, q,
+                           dtw, drec, 256);
+    run<false, false, false, true>("one workgroup per transform, twiddles requested a work item ahead across passes", src, dst,
+                                   nlimbs, q, dtw, drec, nlimbs);
+    run<false>("one workgroup per transform (again)", src, dst, nlimbs, q, dtw, drec, nlimbs);
     return 0;
 }

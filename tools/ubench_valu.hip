@@ -54,6 +54,14 @@ typedef unsigned int u32;
 #define A_CMP64(k) asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(acc[k]), "v"(acc[(k + 1) & 7]) : "vcc");
 #define A_SUB64(k) asm volatile("v_sub_co_u32_e32 %0, vcc, %0, %1" : "+v"(((u32 *)&acc[k])[0]) : "v"(b) : "vcc");
 #define A_DOT4(k) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(((u32 *)&acc[k])[0]) : "v"(a), "v"(b));
+#define A_CND64(k) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(((u32 *)&acc[k])[0]) : "v"(b) : "s22", "s23");
+#define A_CMPCND(k) asm volatile("v_cmp_lt_u32_e32 vcc, %1, %0\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(((u32 *)&acc[k])[0]) : "v"(b) : "vcc");
+#define A_SUBCND(k) asm volatile("v_sub_co_u32_e32 %0, vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(((u32 *)&acc[k])[0]) : "v"(b) : "vcc");
+#define A_CSUB64(k) asm volatile("v_sub_co_u32_e32 v80, vcc, %0, %2\n\tv_subb_co_u32_e32 v81, vcc, %1, %3, vcc\n\tv_cndmask_b32_e32 %0, v80, %0, vcc\n\tv_cndmask_b32_e32 %1, v81, %1, vcc" : "+v"(((u32 *)&acc[k])[0]), "+v"(((u32 *)&acc[k])[1]) : "v"(a), "v"(b) : "vcc", "v80", "v81");
+#define A_CSUB64M(k) asm volatile("v_sub_co_u32_e32 v80, vcc, %0, %2\n\tv_subb_co_u32_e32 v81, vcc, %1, %3, vcc\n\tv_ashrrev_i32_e32 v82, 31, v81\n\tv_and_b32_e32 v83, v82, %2\n\tv_and_b32_e32 v82, v82, %3\n\tv_add_co_u32_e32 %0, vcc, v80, v83\n\tv_addc_co_u32_e32 %1, vcc, v81, v82, vcc" : "+v"(((u32 *)&acc[k])[0]), "+v"(((u32 *)&acc[k])[1]) : "v"(a), "v"(b) : "vcc", "v80", "v81", "v82", "v83");
+#define A_AND(k) asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(((u32 *)&acc[k])[0]) : "v"(b));
+#define A_ASHR(k) asm volatile("v_ashrrev_i32_e32 %0, 3, %0" : "+v"(((u32 *)&acc[k])[0]));
+#define A_MIN(k) asm volatile("v_min_u32_e32 %0, %0, %1" : "+v"(((u32 *)&acc[k])[0]) : "v"(b));
 #define A_MADI64(k) asm volatile("v_mad_i64_i32 %0, s[20:21], %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b) : "s20", "s21");
 
 KERNEL(k_mad64, A_MAD64)
@@ -82,6 +90,14 @@ KERNEL(k_mov, A_MOV)
 KERNEL(k_cndmask, A_CNDMASK)
 KERNEL(k_cmp64, A_CMP64)
 KERNEL(k_dot4, A_DOT4)
+KERNEL(k_cnd64, A_CND64)
+KERNEL(k_cmpcnd, A_CMPCND)
+KERNEL(k_subcnd, A_SUBCND)
+KERNEL(k_csub64, A_CSUB64)
+KERNEL(k_csub64m, A_CSUB64M)
+KERNEL(k_and, A_AND)
+KERNEL(k_ashr, A_ASHR)
+KERNEL(k_min, A_MIN)
 
 typedef void (*kern_t)(u64 *, u32, int);
 static void run(const char *name, kern_t k, int threads, u64 *out) {
@@ -108,7 +124,7 @@ int main() {
 #define RUN(K) run(#K, K, 1024, out);
     RUN(k_mad64) RUN(k_mad64s) RUN(k_mad64z) RUN(k_mad64one) RUN(k_madi64) RUN(k_mullo) RUN(k_mulhi) RUN(k_add32) RUN(k_add3)
     RUN(k_addco) RUN(k_addc) RUN(k_lshladd64) RUN(k_mad24) RUN(k_mul24) RUN(k_mulhi24) RUN(k_madu16) RUN(k_fma64)
-    RUN(k_mulf64) RUN(k_addf64) RUN(k_fma32) RUN(k_pkfma32) RUN(k_lshr64) RUN(k_mov) RUN(k_cndmask) RUN(k_cmp64) RUN(k_dot4)
+    RUN(k_mulf64) RUN(k_addf64) RUN(k_fma32) RUN(k_pkfma32) RUN(k_lshr64) RUN(k_mov) RUN(k_cndmask) RUN(k_cnd64) RUN(k_cmpcnd) RUN(k_subcnd) RUN(k_csub64) RUN(k_csub64m) RUN(k_and) RUN(k_ashr) RUN(k_min) RUN(k_cmp64) RUN(k_dot4)
     run("k_mad64 (1 wave/SIMD)", k_mad64, 256, out);
     run("k_add32 (1 wave/SIMD)", k_add32, 256, out);
     run("k_fma64 (1 wave/SIMD)", k_fma64, 256, out);

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_enc_down(const int8_t 
             }
         lm_store_run(o, i0, a, n);
     };
-    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)l * N, qc, tid, nthreads, ld, st);
+    lm_ntt_forward<LOGN, false>(sm, tw_all + (size_t)l * N, qc, tid, nthreads, ld, st); // 111 VGPRs as it is
 }
 
 struct PkTable {

@@ -515,11 +515,73 @@ struct lm_no_after {
 
 // Forward transform.  `after(i0, n)` runs once the storer has seen coefficients [i0, i0+n) (the
 // whole transform) -- NOT behind a barrier: other waves may still be in their last pass.
-template <int LOGN, class Loader, class Storer, class After = lm_no_after>
+// N = 2^14 (pass plan 4 | 4 3 3) with every twiddle set requested a whole work item -- or a barrier wait --
+// before its butterflies, ACROSS the passes: pass 1's wave-uniform set (SGPRs) before the barrier, the two
+// per-lane sets of pass 2 under pass 1's butterflies, those of pass 3 in the registers pass 2 frees item
+// by item.  (The generic passes only look one item ahead inside a pass: the first item of every pass
+// waits a whole L2 round trip for its table words.)
+#ifndef LM_TW_XPASS
+#define LM_TW_XPASS 1
+#endif
+template <int LOGN, int R, int S0, bool UW>
+__device__ __forceinline__ void lm_fwd_mid_item(u64 *s, const lm_twset<R, UW> &T, const lm_qc &c, uint32_t w) {
+    constexpr uint32_t log_tl = LOGN - S0 - R;
+    const uint32_t blk = w >> log_tl, off = w & ((1u << log_tl) - 1);
+    const uint32_t base = (blk << (log_tl + R)) + off;
+    u64 e[1 << R];
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_tl))];
+    lm_fwd_stages<R, UW>(e, T, c);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_tl))] = e[k];
+}
+template <class Loader, class Storer>
+__device__ __forceinline__ void lm_fwd14_xpass(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid, Loader &ld,
+                                               Storer &st) {
+    constexpr int LOGN = 14;
+    static_assert(lm_npasses(LOGN) == 4 && lm_pass_r(LOGN, 0) == 4 && lm_pass_r(LOGN, 1) == 4 &&
+                      lm_pass_r(LOGN, 2) == 3 && lm_pass_r(LOGN, 3) == 3,
+                  "written for the pass plan 4 | 4 3 3");
+    using D4 = lm_deal<LOGN, 4>;
+    using D3 = lm_deal<LOGN, 3>;
+    static_assert(D4::reps == 1 && D3::reps == 2, "one item in pass 1, two in passes 2 and 3");
+    lm_fwd_first<LOGN, 4, true>(sm, tw, c, tid, ld);
+    lm_twset<4, true> T1;
+    T1.load(tw, 4, D4::local(tid, 0) >> (LOGN - 8));
+    __syncthreads();
+    lm_twset<3, false> A, B;
+    A.load(tw, 8, D3::local(tid, 0) >> (LOGN - 11));
+    B.load(tw, 8, D3::local(tid, 1) >> (LOGN - 11));
+    lm_fwd_mid_item<LOGN, 4, 4, true>(sm, T1, c, D4::local(tid, 0));
+    lm_wave_sync();
+    lm_fwd_mid_item<LOGN, 3, 8, false>(sm, A, c, D3::local(tid, 0));
+    A.load(tw, 11, D3::local(tid, 0));
+    lm_fwd_mid_item<LOGN, 3, 8, false>(sm, B, c, D3::local(tid, 1));
+    B.load(tw, 11, D3::local(tid, 1));
+    lm_wave_sync();
+#pragma unroll
+    for (uint32_t m = 0; m < 2; m++) {
+        const uint32_t base = D3::local(tid, m) << 3;
+        u64 e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = sm[LM_PAD(base + k)];
+        lm_fwd_stages<3, false>(e, m ? B : A, c);
+        st(base, e, 8);
+    }
+}
+
+// XPASS = false: the generic passes also at N = 2^14 (a kernel whose storer needs the registers the second
+// twiddle set of the last pass would take)
+template <int LOGN, bool XPASS = true, class Loader, class Storer, class After = lm_no_after>
 __device__ __forceinline__ void lm_ntt_forward(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid, uint32_t,
                                                Loader &ld, Storer &st, After after = After()) {
     static_assert(lm_npasses(LOGN) >= 2, "a transform needs a loading and a storing pass");
-    lm_fwd_rec<LOGN, 0, 0>(sm, tw, c, tid, ld, st);
+    // (not with a storer that prefetches for itself -- ModDown: its pre() words and two live twiddle sets
+    // make 119 VGPRs and the kernel 3 % slower, measured)
+    if constexpr (LOGN == 14 && XPASS && LM_TW_XPASS && LM_COEFS_PER_LANE == 16 && !lm_has_pre<Storer>::value)
+        lm_fwd14_xpass(sm, tw, c, tid, ld, st);
+    else
+        lm_fwd_rec<LOGN, 0, 0>(sm, tw, c, tid, ld, st);
     after(0u, 1u << LOGN);
 }
 

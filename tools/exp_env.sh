@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs bench.py (headline config, no CPU baseline) once per environment setting given as arguments and
 # prints one line per run: the setting, seconds per step and the per-kernel milliseconds.
-#   bash tools/exp_env.sh "" "LUMEN_KS_LANES=2" "LUMEN_KS_LANES=2 LUMEN_KS_OVERLAP=1"
+#   bash tools/exp_env.sh "" "LUMEN_KS_LANES=2" "LUMEN_KS_BATCH=32"
 cd "$GRAFT_REPO_ROOT"
 for e in "$@"; do
   out=$(env $e python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 ${BENCH_ARGS} 2>/dev/null | tail -1)

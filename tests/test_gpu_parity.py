@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import T_REF, make_context, make_params, random_cts
+from helpers import T_REF, gen_primes, make_context, make_params, random_cts
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,28 @@ def test_ct_ntt_matches_oracle(oracle, small, S):
     s = ctx.upload(cts)
     ctx.ct_ntt(s, S)
     assert np.array_equal(s.download(), P.ct_ntt(cts, S, roots))
+
+
+def test_ct_ntt_three_passes(oracle):
+    """size = 32768 > 128 * 128: the schedule needs a third pass, whose middle one runs IN PLACE on the
+    tile-major buffer between the passes.  T_REF - 1 is divisible by 2^14 only, so this runs over another
+    plaintext prime (T = 1 mod 2^16); N = 256, one limb: 134 MB of ciphertexts."""
+    S = 32768
+    T = gen_primes(oracle, 40, 1, 2 * S, exclude=())[0]
+    assert T % (2 * S) == 1
+    P = make_params(oracle, 8, 1, num_p=1, T=T)
+    ctx = make_context(P)
+    try:
+        roots = oracle.field_roots(T, S)
+        ctx.field_set(roots)
+        cts = random_cts(P, S, 1, seed=77)
+        s = ctx.upload(cts)
+        ctx.ct_ntt(s, S)
+        got = s.download()
+        s.free()
+    finally:
+        ctx.close()
+    assert np.array_equal(got, P.ct_ntt(cts, S, roots))
 
 
 def test_ct_ntt_multi_chunk(oracle, small):

@@ -63,6 +63,17 @@ __device__ __forceinline__ u32 bx_v(u128 A, u128 M, u64 y0, u64 y1, u64 m0, u64 
     return (u32)(u64)vf;
 }
 
+// (y0, y1) -> (hi, lo) of W = y0*m1 + y1*m0 + (2 - v)*M  (lm_ks_dev.h); M = m0*m1
+__device__ __forceinline__ void pack_pair(u64 a, u64 b, u64 m0, u64 m1, u128 M, u64 &hi, u64 &lo) {
+    u64 l1, h1, l2, h2;
+    mul128(a, m1, l1, h1);
+    mul128(b, m0, l2, h2);
+    const u128 A = (((u128)h1 << 64) | l1) + (((u128)h2 << 64) | l2);
+    const u32 v = bx_v(A, M, a, b, m0, m1);
+    const u128 W = A + (v == 0 ? 2 * M : (v == 1 ? M : (u128)0)); // + (2 - v) * M, v <= 2
+    hi = (u64)(W >> LM_W_SPLIT), lo = (u64)W & ((1ull << LM_W_SPLIT) - 1);
+}
+
 // (y0, y1)[b][i] -> (hi, lo) of W = y0*m1 + y1*m0 + (2 - v)*M for every two-limb source group
 // (lm_ks_dev.h).  y: [npoly][stride] with the group's two limbs at limb offsets lo, lo+1.
 // One thread per PAIR of coefficients (16-byte accesses); the group is uniform per workgroup row.
@@ -87,18 +98,101 @@ __global__ __launch_bounds__(256) void k_pack_v(u64 *__restrict__ y, size_t poly
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const u64 a = e ? av.y : av.x, b = e ? bv.y : bv.x;
-            u64 l1, h1, l2, h2;
-            mul128(a, m1, l1, h1);
-            mul128(b, m0, l2, h2);
-            const u128 A = (((u128)h1 << 64) | l1) + (((u128)h2 << 64) | l2);
-            const u32 v = bx_v(A, M, a, b, m0, m1);
-            const u128 W = A + (v == 0 ? 2 * M : (v == 1 ? M : (u128)0)); // + (2 - v) * M, v <= 2
-            const u64 hi = (u64)(W >> LM_W_SPLIT), lo = (u64)W & ((1ull << LM_W_SPLIT) - 1);
+            u64 hi, lo;
+            pack_pair(a, b, m0, m1, M, hi, lo);
             if (e) hv.y = hi, lv.y = lo;
             else hv.x = hi, lv.x = lo;
         }
         *reinterpret_cast<ulonglong2 *>(y0) = hv;
         *reinterpret_cast<ulonglong2 *>(y0 + N) = lv;
+    }
+}
+
+// ---- step 1, partly fused: c1 to the coefficient domain, and for the first `nf` two-limb digits the
+// (hi, lo) packing as well.  Workgroups [0, B * nf): one per (column, digit), both limbs' inverse
+// transforms back to back; the lane that wrote y0[i] reads it back (from L2) when y1[i] leaves its
+// registers -- in the cross-wave last pass every lane sees the same coefficient indices whatever the limb --
+// and the pair skips k_pack_v's round trip through HBM.  Workgroups behind them: one inverse transform
+// each, for the limbs of the remaining digits (packed by k_pack_v as before).
+// Why not fuse all digits: B * beta pairs are 1.5 rounds of the 256 CUs at B = 64 (measured: 246 ms per
+// step against 152 + 60).  With nf = 4 the fused pairs are exactly one round and the 256 single
+// transforms fill in behind them as the pairs finish -- the launch is as long as three rounds of single
+// transforms, and two thirds of the packing pass are gone.
+template <int LOGN>
+__global__ __launch_bounds__(lm_max_threads(LOGN)) void k_intt_pack(const u64 *__restrict__ acc, u64 *coef, uint32_t B,
+                                                                  uint32_t L, uint32_t nf, lm_mods mods,
+                                                                  lm_ninv_t yscale, const tw_t *__restrict__ tw_all) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm[];
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    if (blockIdx.x >= B * nf) { // a limb of an unfused digit: limb-major, as k_limb_ntt
+        const uint32_t k = blockIdx.x - B * nf, l = 2 * nf + k / B, b = k % B;
+        const u64 *p = acc + (((size_t)b * 2 + 1) * L + l) * N;
+        u64 *o = coef + ((size_t)b * L + l) * N;
+        const lm_qc q = lm_make_qc(mods.m[l]);
+        const tw_t sc = yscale.t[l];
+        auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
+        auto st = [&](uint32_t i, u64 v) { o[i] = lm_shoup_cs(v, sc, q.q, q.nq); };
+        lm_ntt_inverse<LOGN>(sm, tw_all + (size_t)l * N, q, tid, nthreads, ld, st);
+        return;
+    }
+    const uint32_t d = blockIdx.x / B, b = blockIdx.x % B; // digit-major: two twiddle tables hot per XCD
+    const uint32_t l0 = 2 * d, l1 = l0 + 1;
+    const u64 *c1 = acc + ((size_t)b * 2 + 1) * L * N; // c1 of column b
+    u64 *o0 = coef + ((size_t)b * L + l0) * N;
+    const lm_qc q0 = lm_make_qc(mods.m[l0]);
+    const tw_t s0 = yscale.t[l0];
+    { // first limb: y0 to its place in coef
+        const u64 *p = c1 + (size_t)l0 * N;
+        auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
+        auto st = [&](uint32_t i, u64 v) { o0[i] = lm_shoup_cs(v, s0, q0.q, q0.nq); };
+        lm_ntt_inverse<LOGN>(sm, tw_all + (size_t)l0 * N, q0, tid, nthreads, ld, st);
+    }
+    __syncthreads(); // the second transform reuses the LDS
+    {
+        const lm_qc q1 = lm_make_qc(mods.m[l1]);
+        const tw_t s1 = yscale.t[l1];
+        const u64 *p = c1 + (size_t)l1 * N;
+        u64 Ml, Mh;
+        mul128(q0.q, q1.q, Ml, Mh);
+        // the product is uniform but comes out of the vector multiplier: back to SGPRs, or it sits in
+        // eight VGPRs through the whole transform
+        auto uni = [](u64 x) {
+            return (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) |
+                   (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32;
+        };
+        const u128 M = ((u128)uni(Mh) << 64) | uni(Ml);
+        auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
+        // the y0 words of a work item of the last pass are read back before its butterflies (pre) and are
+        // there when the y1 words come out of them
+        constexpr int R_LAST = lm_pass_r(LOGN, 0), LOG_T0 = LOGN - R_LAST;
+        constexpr int PF = (1 << R_LAST) * 5 / 8; // words requested ahead: 16 of 16 spill 14 VGPRs, 12 of 16 two
+        struct pack_t {
+            u64 *o0;
+            const lm_qc &q0, &q1;
+            tw_t s1;
+            u128 M;
+            u64 y0[PF];
+            __device__ __forceinline__ void pre(uint32_t w) {
+#pragma unroll
+                for (int k = 0; k < PF; k++) y0[k] = o0[w + ((uint32_t)k << LOG_T0)];
+            }
+            __device__ __forceinline__ void operator()(uint32_t i, u64 v, int k) {
+                const u64 y1 = lm_shoup_cs(v, s1, q1.q, q1.nq);
+                // the index is made opaque so that the addresses of the pass are formed one pair at a time
+                // (computed ahead, beside the y0 words, they spill)
+                uint32_t j = i;
+                asm volatile("" : "+v"(j));
+                const u64 a = k < PF ? y0[k < PF ? k : 0] : o0[j];
+                u64 hi, lo;
+                pack_pair(a, y1, q0.q, q1.q, M, hi, lo);
+                o0[j] = hi, o0[j + N] = lo;
+                if (k >= PF && (k & 1)) asm volatile("" ::: "memory"); // two late read-backs in flight
+            }
+        } st{o0, q0, q1, s1, M, {}};
+        uint32_t tid1 = tid; // nothing derived from the lane index is carried over from the first limb
+        asm volatile("" : "+v"(tid1));
+        lm_ntt_inverse<LOGN>(sm, tw_all + (size_t)l1 * N, q1, tid1, nthreads, ld, st);
     }
 }
 
@@ -652,6 +746,23 @@ static uint32_t ks_lanes() {
     }();
     return n;
 }
+// digits whose packing is fused into the c1 inverse transform (k_intt_pack): the largest count whose
+// B * nf two-transform workgroups are whole rounds of the device's CUs (4 of 6 at B = 64 on 256 CUs), so
+// that no CU waits for a straggling pair; LUMEN_KS_FUSED_DIGITS overrides (0 = k_pack_v for all)
+static uint32_t ks_fused_digits(lumen_ctx *ctx, uint32_t B, uint32_t L) {
+    const char *e = getenv("LUMEN_KS_FUSED_DIGITS"); // read at every call: a test runs several settings in one process
+    const long forced = e ? atol(e) : -1l;
+    static const uint32_t cus = [&] {
+        hipDeviceProp_t prop;
+        return hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 256u;
+    }();
+    const uint32_t pairs = L / 2; // digits with two limbs
+    if (forced >= 0) return std::min<uint32_t>((uint32_t)forced, pairs);
+    for (uint32_t nf = pairs; nf >= 1; nf--)
+        if (((uint64_t)B * nf) % cus == 0) return nf;
+    return 0;
+}
+
 struct LaneGuard {
     lumen_ctx *ctx;
     hipStream_t saved;
@@ -667,14 +778,35 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
     const uint32_t N = ctx->N, L = ctx->L, K = ctx->K, LK = L + K, beta = tb->beta;
     const size_t lds = lm_fwd_lds(ctx->logN);
     const uint32_t threads = lm_fwd_threads(ctx->logN);
-    // 1. c1 -> coefficient domain
-    if (int rc = lm_launch_ntt_strided(ctx, acc + (size_t)L * N, (size_t)2 * L * N, s.coef, (size_t)L * N, B,
-                                       lm_map_q(L), true, "ks_intt_c1", &tb->yscale))
-        return rc;
-    if (K == 2) {
+    // 1. c1 -> coefficient domain, scaled for the basis extension, and the (hi, lo) packing of the two-limb
+    // digits: fused into the transform for the first nf digits, k_pack_v for the others
+    const uint32_t nf = K == 2 ? ks_fused_digits(ctx, B, L) : 0;
+    if (nf) {
+        const size_t lds_i = lm_inv_lds(ctx->logN);
+        const uint32_t grid = B * nf + B * (L - 2 * nf);
+        lm_prof_scope ps(ctx, "ks_intt_c1", (uint64_t)B * L);
+        switch (ctx->logN) {
+#define LM_CASE(n)                                                                                              \
+    case n:                                                                                                     \
+        LM_LDS_ATTR(ctx, k_intt_pack<n>, lds_i);                                                                \
+        hipLaunchKernelGGL(k_intt_pack<n>, dim3(grid), dim3(lm_inv_threads(ctx->logN)), lds_i, ctx->stream, acc, \
+                           s.coef, B, L, nf, ctx->mods, tb->yscale, ctx->d_tw_inv);                             \
+        break;
+            LM_FOR_EACH_LOGN(LM_CASE)
+#undef LM_CASE
+        default:
+            return lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
+        }
+        LM_HIP(ctx, hipGetLastError());
+    } else {
+        if (int rc = lm_launch_ntt_strided(ctx, acc + (size_t)L * N, (size_t)2 * L * N, s.coef, (size_t)L * N, B,
+                                           lm_map_q(L), true, "ks_intt_c1", &tb->yscale))
+            return rc;
+    }
+    if (K == 2 && nf < beta) { // the digits the transform did not pack
         lm_prof_scope ps(ctx, "ks_pack_v", (uint64_t)B);
-        hipLaunchKernelGGL(k_pack_v, dim3(2048), dim3(256), 0, ctx->stream, s.coef, (size_t)L * N, B, beta, K, 0u,
-                           L, ctx->logN, ctx->mods);
+        hipLaunchKernelGGL(k_pack_v, dim3(2048), dim3(256), 0, ctx->stream, s.coef + (size_t)2 * nf * N, (size_t)L * N,
+                           B, beta - nf, K, 2 * nf, L - 2 * nf, ctx->logN, ctx->mods);
         LM_HIP(ctx, hipGetLastError());
     }
     // 2. digit extension + NTT

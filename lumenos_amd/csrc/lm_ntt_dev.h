@@ -624,6 +624,13 @@ __device__ __forceinline__ void lm_inv_mid(u64 *s, const tw_t *tw, const lm_qc &
     }
 }
 
+// a storer may take a third argument: the position k < 2^R of the value in its work item (a compile-time
+// constant at every call site, so that it can index what pre() fetched without a dynamic register index)
+template <class S, class = void>
+struct lm_has_slot : std::false_type {};
+template <class S>
+struct lm_has_slot<S, std::void_t<decltype(std::declval<S &>()(0u, (u64)0, 0))>> : std::true_type {};
+
 template <int LOGN, int R, class Storer>
 __device__ __forceinline__ void lm_inv_last(const u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Storer &st) {
     constexpr uint32_t log_t0 = LOGN - R, items = 1u << log_t0, NT = lm_nthreads(LOGN);
@@ -635,9 +642,17 @@ __device__ __forceinline__ void lm_inv_last(const u64 *s, const tw_t *tw, const 
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(w + ((uint32_t)k << log_t0))];
+        // a storer with a member pre(w) is told the work item before its butterflies run: whatever it
+        // reads from global memory for coefficients w + (k << log_t0), k < 2^R, is then in flight under them
+        if constexpr (lm_has_pre<Storer>::value) st.pre(w);
         lm_inv_stages<R, true, true>(e, LOGN, log_t0, 0, tw, c);
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) st(w + ((uint32_t)k << log_t0), e[k]);
+        for (int k = 0; k < (1 << R); k++) {
+            if constexpr (lm_has_slot<Storer>::value)
+                st(w + ((uint32_t)k << log_t0), e[k], k);
+            else
+                st(w + ((uint32_t)k << log_t0), e[k]);
+        }
     }
 }
 

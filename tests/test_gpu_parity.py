@@ -223,6 +223,24 @@ def test_inner_sum_matches_oracle(oracle, keyed, n):
         assert np.array_equal(got[c], P.inner_sum(cts[c], n, evks)), c
 
 
+@pytest.mark.parametrize("nf", [0, 1, 2])
+def test_inner_sum_fused_digit_packing(oracle, keyed, nf, monkeypatch):
+    """k_intt_pack: the (hi, lo) packing of the first nf two-limb digits is fused into the c1 inverse
+    transform, the others go through k_pack_v.  The library picks nf from the batch size (4 of 6 digits at
+    64 columns); here every split of L = 5 limbs -- digits (0,1) (2,3) (4) -- is forced in turn."""
+    P, ctx, sk = keyed
+    n = 64
+    gl = P.inner_sum_galois_elements(n)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    cts = random_cts(P, 3, 5, seed=640 + nf)
+    monkeypatch.setenv("LUMEN_KS_FUSED_DIGITS", str(nf))
+    got = ctx.inner_sum(ctx.upload(cts), n).download()
+    for c in range(3):
+        assert np.array_equal(got[c], P.inner_sum(cts[c], n, evks)), c
+
+
 def test_matrix_inner_sum_matches_oracle_and_decrypts(oracle, keyed):
     """matrixInnerSumEval (ligero.go:299-370): bit-exact vs oracle, and slot 0 decrypts to sum_i pt_i*M[i][j]."""
     P, ctx, sk = keyed

@@ -747,19 +747,39 @@ static uint32_t ks_lanes() {
     return n;
 }
 // digits whose packing is fused into the c1 inverse transform (k_intt_pack): the largest count whose
-// B * nf two-transform workgroups are whole rounds of the device's CUs (4 of 6 at B = 64 on 256 CUs), so
-// that no CU waits for a straggling pair; LUMEN_KS_FUSED_DIGITS overrides (0 = k_pack_v for all)
+// B * nf two-transform workgroups are whole rounds of the device's workgroup slots (CUs x resident
+// workgroups per CU: 256 x 1 at N = 2^14, so 4 of 6 digits at B = 64), so that no slot waits for a
+// straggling pair; none when a launch does not even fill the slots once (small rings: every workgroup
+// runs at once and a two-transform workgroup would just make the launch twice as long).
+// LUMEN_KS_FUSED_DIGITS overrides (0 = k_pack_v for all).
+template <int LOGN>
+static uint32_t intt_pack_slots(lumen_ctx *ctx) {
+    static const uint32_t v = [&] {
+        hipDeviceProp_t prop;
+        int per_cu = 1;
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return 256u;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_intt_pack<LOGN>, lm_nthreads(LOGN),
+                                                         lm_lds_for(1u << LOGN)) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        return (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    }();
+    return v;
+}
 static uint32_t ks_fused_digits(lumen_ctx *ctx, uint32_t B, uint32_t L) {
     const char *e = getenv("LUMEN_KS_FUSED_DIGITS"); // read at every call: a test runs several settings in one process
     const long forced = e ? atol(e) : -1l;
-    static const uint32_t cus = [&] {
-        hipDeviceProp_t prop;
-        return hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 256u;
-    }();
     const uint32_t pairs = L / 2; // digits with two limbs
     if (forced >= 0) return std::min<uint32_t>((uint32_t)forced, pairs);
+    uint32_t slots = 0;
+    switch (ctx->logN) {
+#define LM_CASE(n) \
+    case n: slots = intt_pack_slots<n>(ctx); break;
+        LM_FOR_EACH_LOGN(LM_CASE)
+#undef LM_CASE
+    default: return 0;
+    }
     for (uint32_t nf = pairs; nf >= 1; nf--)
-        if (((uint64_t)B * nf) % cus == 0) return nf;
+        if (((uint64_t)B * nf) % slots == 0) return nf;
     return 0;
 }
 

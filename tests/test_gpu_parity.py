@@ -374,6 +374,28 @@ def test_full_size_matrix_inner_sum(oracle, full_d):
     assert int(P.decrypt(sk, got[0], 1, P.rescale_scale(P.L, 2))[0]) == want
 
 
+def test_full_size_inner_sum_batch_of_64_fused_packing(oracle, full_d, monkeypatch):
+    """The headline geometry of step 1 of a rotation: 64 columns at N = 2^14, L = 12 -- the batch size at
+    which k_intt_pack fuses the packing of 4 of the 6 digits into the c1 transform (256 two-transform
+    workgroups + 256 single ones).  Same 64 random ciphertexts through the fused launch (the library's
+    choice) and with the fusion forced off; two of the columns against the oracle."""
+    P, ctx = full_d
+    n = 16384
+    sk = P.keygen_secret()
+    gl = P.inner_sum_galois_elements(n)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    cts = random_cts(P, 64, P.L, seed=6464)
+    monkeypatch.delenv("LUMEN_KS_FUSED_DIGITS", raising=False)
+    fused = ctx.inner_sum(ctx.upload(cts), n).download()
+    monkeypatch.setenv("LUMEN_KS_FUSED_DIGITS", "0")
+    plain = ctx.inner_sum(ctx.upload(cts), n).download()
+    assert np.array_equal(fused, plain)
+    for c in (0, 63):
+        assert np.array_equal(fused[c], P.inner_sum(cts[c], n, evks)), c
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_encode_shards_cover_full_encode(oracle, small, world):
     """Multi-GPU Commit: the union of the per-rank shards (run one after the other on this one GPU)

@@ -728,7 +728,7 @@ __global__ __launch_bounds__(LM_CB_THREADS) void k_ct_blocks(ct_blocks_args a, l
 // run both kernels on the same input in one process)
 static bool ct_blocks_enabled() {
     const char *e = getenv("LUMEN_CT_BLOCKS");
-    return !(e && atoi(e) == 0);
+    return !(e && *e && atoi(e) == 0);
 }
 
 // final_g0/final_ng: groups of the final pass to run (all when final_ng == 0); final_pos: device

@@ -756,18 +756,27 @@ template <int LOGN>
 static uint32_t intt_pack_slots(lumen_ctx *ctx) {
     static const uint32_t v = [&] {
         hipDeviceProp_t prop;
-        int per_cu = 1;
+        int per_cu = 0;
         if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return 256u;
+        // (the query answers 0 for more than 64 KB of dynamic LDS until the kernel is allowed that much)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intt_pack<LOGN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_intt_pack<LOGN>, lm_nthreads(LOGN),
-                                                         lm_lds_for(1u << LOGN)) != hipSuccess || per_cu < 1)
-            per_cu = 1;
+                                                         lm_lds_for(1u << LOGN)) != hipSuccess || per_cu < 1) {
+            // by hand: LDS (160 KB per CU) and the 2048 lanes of a CU
+            per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lm_lds_for(1u << LOGN), 2048 / lm_nthreads(LOGN)));
+        }
+        (void)hipGetLastError();
+        if (getenv("LUMEN_DEBUG"))
+            fprintf(stderr, "[lumenos_hip] k_intt_pack<%d>: %d workgroup(s) per CU, %d CUs\n", LOGN, per_cu,
+                    prop.multiProcessorCount);
         return (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }();
     return v;
 }
 static uint32_t ks_fused_digits(lumen_ctx *ctx, uint32_t B, uint32_t L) {
     const char *e = getenv("LUMEN_KS_FUSED_DIGITS"); // read at every call: a test runs several settings in one process
-    const long forced = e ? atol(e) : -1l;
+    const long forced = e && *e ? atol(e) : -1l;
     const uint32_t pairs = L / 2; // digits with two limbs
     if (forced >= 0) return std::min<uint32_t>((uint32_t)forced, pairs);
     uint32_t slots = 0;

@@ -156,8 +156,10 @@ class Job:
         self.query_idx = rng.integers(0, self.S, size=self.queries).astype(np.uint32)
         self.ring_switch_logn = ring_switch_logn
         if ring_switch_logn:
-            nd = ctx.lib.lumen_ringswitch_digits(ctx.h, 13)
-            key = np.ascontiguousarray(rand_limbs(P.q[:1] + P.p, (nd, 2, self.N)).transpose(1, 2, 0, 3))
+            # the whole evaluation key a client posts (cmd/client/main.go:124-131): [rns][pw2][2][L+K][N]; with
+            # two special primes that is one Galois key's size (no power-of-two digits)
+            rns, pw2 = ctx.ringswitch_key_shape(13)[:2]
+            key = np.ascontiguousarray(rand_limbs(P.q + P.p, (rns, pw2, 2, self.N)).transpose(1, 2, 3, 0, 4))
             ctx.load_ringswitch_key(ring_switch_logn, key)
         # column shards (input columns; encoded columns are sharded by the transform itself)
         self.col_lo, self.col_hi = self.cols * rank // world, self.cols * (rank + 1) // world

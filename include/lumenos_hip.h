@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LUMEN_ABI_VERSION 2
+#define LUMEN_ABI_VERSION 3
 #define LUMEN_MAX_LIMBS 24
 
 typedef struct lumen_ctx lumen_ctx;
@@ -250,11 +250,22 @@ int lumen_mul_plain(lumen_ctx *ctx, const lumen_set *in, const uint64_t *pt, lum
 int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, lumen_set **out);
 
 /* ---- fhe.RingSwitchServer (fhe/ring_switch.go:93-113): Evaluator.ApplyEvaluationKey of every
- * ciphertext of `in` into the ring of degree 2^log_n_small with the single modulus q_0.
- * key: rlwe.EvaluationKey of NewRingSwitchClient (ring_switch.go:43-56), only the entries level 0
- * uses: host layout [digit(lumen_ringswitch_digits)][b|a][limb {q_0, p_0..p_{K-1}}][N], NTT domain,
- * standard form; base_two_w = BaseTwoDecomposition (13).  out: host, [count][2][2^log_n_small]
- * residues mod q_0 in the small ring's NTT domain. */
+ * ciphertext of `in` into the ring of degree 2^log_n_small with the single modulus q_0, at level 0.
+ * key: the rlwe.EvaluationKey of NewRingSwitchClient (ring_switch.go:43-56) as the client posts it
+ * (cmd/client/main.go:124-131): GadgetCiphertext.Value flattened
+ *     [rns digit][power-of-two digit][b|a][limb: q_0..q_{L-1}, p_0..p_{K-1}][N],  NTT domain, standard form
+ * with lumen_ringswitch_rns_digits() x lumen_ringswitch_digits(w) entries.  Level 0 reads RNS digit 0
+ * only, so a caller may pass just that first block (evk.Value[0]).
+ * base_two_w = BaseTwoDecomposition (13).  Which gadget product runs follows the key's LevelP, as in
+ * rlwe.Evaluator.GadgetProductLazy [LATTIGO-RECALL]:
+ *   K >= 2 special primes (what GenerateBGVParamsForNTT always produces, fhe/bfv.go:172-178): the hybrid
+ *     key switch with RNS digits only; base_two_w is ignored and lumen_ringswitch_digits() = 1 -- the
+ *     reference's "Marshaled keys length" logs show the key is exactly one Galois key's size
+ *     (results/experimental/client/bench_*.txt:20 against results/baseline/client/bench_*.txt:19);
+ *   K <= 1 (TestRingSwitch's LogQ = [58] without P, fhe/ring_switch_test.go:14-18): unsigned base-2^w
+ *     digits, lumen_ringswitch_digits() = ceil(bits(q_0) / w); no ModDown when K = 0.
+ * out: host, [count][2][2^log_n_small] residues mod q_0 in the small ring's NTT domain. */
+uint32_t lumen_ringswitch_rns_digits(const lumen_ctx *ctx);
 uint32_t lumen_ringswitch_digits(const lumen_ctx *ctx, uint32_t base_two_w);
 int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, uint32_t base_two_w,
                               const uint64_t *key);

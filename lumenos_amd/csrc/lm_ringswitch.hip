@@ -1,10 +1,17 @@
 // fhe.RingSwitchServer.RingSwitchNew (fhe/ring_switch.go:93-113): Evaluator.ApplyEvaluationKey of a
 // level-1 ciphertext into a ring of smaller degree n = 2^logn with the single modulus q_0
-// [LATTIGO-RECALL]:
+// [LATTIGO-RECALL] (restated in oracle/lo_ringswitch.c):
 //   1. work at min(level) = 0: only the q_0 residues of the input take part
-//   2. c1 -> coefficient domain; unsigned base-2^w digits (w = 13), each a small polynomial that is
-//      the same integer modulo q_0 and the special primes; NTT every digit on {q_0, p_0..}
-//   3. (u0,u1) = sum_j digit_j (.) evk_j on {q_0, P}; ModDown by P; add c0
+//   2. the gadget product Lattigo runs depends on the key's LevelP (rlwe.Evaluator.GadgetProductLazy):
+//        K >= 2 special primes (every configuration of GenerateBGVParamsForNTT, fhe/bfv.go:172-178):
+//          the ordinary hybrid key switch, RNS digits only -- BaseTwoDecomposition = 13
+//          (ring_switch.go:45-55) is ignored, and the reference's own key-size logs show the key has no
+//          power-of-two entries (tests/test_oracle_kat.py).  Level 0 has ONE digit, {q_0}: its own limb
+//          keeps the NTT values it came with, the P limbs take NTT(c1 mod p) of the coefficient form.
+//        K <= 1 (TestRingSwitch: LogQ = [58], no P, ring_switch_test.go:14-18): unsigned base-2^w
+//          digits of the non-centred coefficients, each a small polynomial that is the same integer
+//          modulo q_0 and the special prime; NTT every digit on {q_0, p_0}
+//   3. (u0,u1) = sum_j digit_j (.) evk[0][j] on {q_0, P}; ModDown by P (nothing without P); add c0
 //   4. SwitchCiphertextRingDegreeNTT: coefficient domain, keep the coefficients of X^(i*N/n),
 //      NTT in the small ring (psi_small = psi_{q_0}^(N/n)).
 // Built from the same pieces as the Galois key switch (LDS-resident limb transform with fused
@@ -16,9 +23,9 @@
 namespace {
 
 struct RsKey {
-    u64 *d_key = nullptr; // [nd][2][1+K][N], Montgomery form
+    u64 *d_key = nullptr; // [nd][2][1+K][N], Montgomery form: RNS digit 0 of the key, limbs {q_0, P}
     tw_t *d_tw_small = nullptr, *d_tw_small_inv = nullptr;
-    uint32_t nd = 0, w = 0, logn = 0;
+    uint32_t nd = 0, w = 0, logn = 0; // nd power-of-two digits of w bits (nd = 1, w = 0: the hybrid path)
     tw_t ninv_small;
     ~RsKey() {
         hipFree(d_key);
@@ -29,8 +36,11 @@ struct RsKey {
 
 } // namespace
 
-// digit j of c (coefficient domain, mod q_0) -> NTT on modulus t (0 = q_0, 1.. = P limbs)
-template <int LOGN>
+// digit j of c (coefficient domain, mod q_0) -> NTT on modulus t (0 = q_0, 1.. = P limbs).
+// HYB: the one RNS digit {q_0} of the hybrid path -- the whole coefficient, reduced modulo the P limb in
+// the load (q_0 has three bits more than a special prime); targets start at t0 = 1, the digit's own limb
+// needs no transform (k_rs_mac reads c1 itself).
+template <int LOGN, bool HYB>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rs_digit_ntt(const u64 *__restrict__ coef,
                                                                        u64 *__restrict__ ext, uint32_t B,
                                                                        uint32_t nd, uint32_t nt, uint32_t L,
@@ -38,18 +48,22 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rs_digit_ntt(const u64
                                                                        const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
     constexpr uint32_t N = 1u << LOGN;
+    constexpr uint32_t t0 = HYB ? 1 : 0;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t r = blockIdx.x;
     const uint32_t b = r % B;
     r /= B;
-    const uint32_t j = r % nd, t = r / nd;
+    const uint32_t j = r % nd, t = t0 + r / nd;
     const uint32_t mi = t == 0 ? 0 : L + (t - 1);
     const lm_qc qc = lm_make_qc(mods.m[mi]);
     const u64 *c = coef + (size_t)b * N;
     u64 *o = ext + (((size_t)b * nd + j) * nt + t) * N;
     const u64 mask = (1ull << w) - 1;
     const uint32_t sh = w * j;
-    auto ld = [&](uint32_t i) { return (c[i] >> sh) & mask; };
+    auto ld = [&](uint32_t i) {
+        if (HYB) return lm_shoup3<true>(c[i], 1ull, qc.qinv64, qc.nq); // c mod p, lazily (< 3p)
+        return (c[i] >> sh) & mask;
+    };
     auto st = [&](uint32_t i0, const u64 *v, int count) {
         u64 rr[8];
 #pragma unroll
@@ -61,16 +75,18 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_rs_digit_ntt(const u64
 }
 
 // u[b][pw][t][i] = sum_j ext[b][j][t][i] * key[j][pw][t][i]
+// c1 != NULL (hybrid path): the digit's own limb t = 0 is the input's c1 (limb 0, NTT domain) itself
 __global__ __launch_bounds__(256) void k_rs_mac(const u64 *__restrict__ ext, const u64 *__restrict__ key,
                                                 u64 *__restrict__ u, uint32_t B, uint32_t nd, uint32_t nt,
-                                                uint32_t L, uint32_t logN, lm_mods mods) {
+                                                uint32_t L, uint32_t logN, lm_mods mods,
+                                                const u64 *__restrict__ c1, size_t in_ctw) {
     const uint32_t N = 1u << logN;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y, b = blockIdx.z;
     if (i >= N || b >= B) return;
     const mod_t md = mods.m[t == 0 ? 0 : L + (t - 1)];
     u128 a0 = 0, a1 = 0;
     for (uint32_t j = 0; j < nd; j++) {
-        const u64 x = ext[(((size_t)b * nd + j) * nt + t) * N + i];
+        const u64 x = (c1 && t == 0) ? c1[(size_t)b * in_ctw + i] : ext[(((size_t)b * nd + j) * nt + t) * N + i];
         a0 += (u128)x * key[(((size_t)j * 2 + 0) * nt + t) * N + i];
         a1 += (u128)x * key[(((size_t)j * 2 + 1) * nt + t) * N + i];
     }
@@ -128,8 +144,32 @@ __global__ void k_rs_project(const u64 *__restrict__ big, u64 *__restrict__ smal
     }
 }
 
+// without special primes there is no ModDown: big[b][pw] = u[b][pw] (+ c0 for pw = 0)
+__global__ __launch_bounds__(256) void k_rs_add_c0(const u64 *__restrict__ u, const u64 *__restrict__ in,
+                                                   size_t in_ctw, u64 *__restrict__ big, uint32_t B, uint32_t logN,
+                                                   lm_mods mods) {
+    const uint32_t N = 1u << logN;
+    const size_t total = (size_t)B * 2 * N, stride = (size_t)gridDim.x * blockDim.x;
+    const u64 q = mods.m[0].q;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint32_t i = (uint32_t)(g & (N - 1));
+        const size_t pw = g >> logN;
+        u64 x = u[g];
+        if ((pw & 1) == 0) x = lm_addmod(x, in[(pw >> 1) * in_ctw + i], q);
+        big[g] = x;
+    }
+}
+
+// dimensions of rlwe.GadgetCiphertext.Value for an evaluation key of this context's parameters at
+// (LevelQ = L-1, LevelP = K-1, BaseTwoDecomposition = w) [LATTIGO-RECALL]
+extern "C" uint32_t lumen_ringswitch_rns_digits(const lumen_ctx *ctx) {
+    if (!ctx) return 0;
+    const uint32_t alpha = ctx->K ? ctx->K : 1;
+    return (ctx->L + alpha - 1) / alpha;
+}
 extern "C" uint32_t lumen_ringswitch_digits(const lumen_ctx *ctx, uint32_t base_two_w) {
-    if (!ctx || !base_two_w) return 0;
+    if (!ctx) return 0;
+    if (ctx->K >= 2 || !base_two_w) return 1; // LevelP > 0: the power-of-two decomposition is not used
     uint32_t bits = 0;
     while (bits < 64 && (ctx->mod[0] >> bits)) bits++;
     return (bits + base_two_w - 1) / base_two_w;
@@ -139,26 +179,30 @@ extern "C" int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, u
                                          const uint64_t *key) {
     LM_CHECK(nullptr, ctx && key, "lumen_load_ringswitch_key: NULL argument");
     LM_ENTER(ctx);
-    LM_CHECK(ctx, ctx->K >= 1 && ctx->K <= 2, "ring switch needs 1 or 2 special primes");
+    LM_CHECK(ctx, ctx->K <= 2, "ring switch supports at most 2 special primes (have %u)", ctx->K);
     LM_CHECK(ctx, log_n_small <= ctx->logN && lm_logn_supported(log_n_small),
              "target ring degree 2^%u is not supported (need <= 2^%u and one of the instantiated sizes)",
              log_n_small, ctx->logN);
-    LM_CHECK(ctx, base_two_w >= 1 && base_two_w <= 32, "BaseTwoDecomposition %u out of range", base_two_w);
-    const uint32_t N = ctx->N, K = ctx->K, nt = 1 + K, L = ctx->L;
+    const uint32_t N = ctx->N, K = ctx->K, nt = 1 + K, L = ctx->L, LK = L + K;
+    const bool hybrid = K >= 2;
+    LM_CHECK(ctx, hybrid || (base_two_w >= 1 && base_two_w <= 32), "BaseTwoDecomposition %u out of range", base_two_w);
     const uint32_t nd = lumen_ringswitch_digits(ctx, base_two_w);
     auto sp = std::make_shared<RsKey>();
-    sp->nd = nd, sp->w = base_two_w, sp->logn = log_n_small;
+    sp->nd = nd, sp->w = hybrid ? 0 : base_two_w, sp->logn = log_n_small;
+    // RNS digit 0 of the key ([rns][pw2][2][L+K][N]: its first pw2 * 2 * (L+K) * N words), limbs {q_0, P}
     const size_t words = (size_t)nd * 2 * nt * N;
     std::vector<u64> mont(words);
     for (uint32_t j = 0; j < nd; j++)
         for (uint32_t pw = 0; pw < 2; pw++)
             for (uint32_t t = 0; t < nt; t++) {
-                const uint64_t q = ctx->mod[t == 0 ? 0 : L + (t - 1)];
+                const uint32_t mi = t == 0 ? 0 : L + (t - 1);
+                const uint64_t q = ctx->mod[mi];
                 const uint64_t r = (uint64_t)((((u128)1) << 64) % q);
+                const uint64_t *src = key + (((size_t)j * 2 + pw) * LK + mi) * N;
                 const size_t off = (((size_t)j * 2 + pw) * nt + t) * N;
                 for (uint32_t k = 0; k < N; k++) {
-                    if (key[off + k] >= q) return lm_fail(ctx, "ring-switch key residue out of range (digit %u limb %u)", j, t);
-                    mont[off + k] = h_mulmod(key[off + k], r, q);
+                    if (src[k] >= q) return lm_fail(ctx, "ring-switch key residue out of range (digit %u limb %u)", j, mi);
+                    mont[off + k] = h_mulmod(src[k], r, q);
                 }
             }
     LM_HIP(ctx, hipMalloc((void **)&sp->d_key, words * 8));
@@ -191,23 +235,30 @@ static int ring_switch_batch(lumen_ctx *ctx, RsKey *rk, const lm_ks_view &kv, co
     // 1. c1 (limb 0) -> coefficient domain
     if (int rc = lm_launch_ntt_strided(ctx, in + (size_t)nl * N, in_ctw, coef, N, B, lm_map_q(1), true, "rs_intt_c1"))
         return rc;
-    // 2. digits + NTT
-    {
+    // 2. digits + NTT (hybrid path: the one digit's P limbs only; its own limb is c1 itself)
+    const bool hybrid = rk->w == 0;
+    if (hybrid) {
+        lm_prof_scope ps(ctx, "rs_digit_ntt", (uint64_t)B * K);
+        LM_LDS_ATTR(ctx, (k_rs_digit_ntt<LOGN, true>), lds);
+        hipLaunchKernelGGL((k_rs_digit_ntt<LOGN, true>), dim3(B * K), dim3(threads), lds, ctx->stream, coef, ext, B, 1u,
+                           nt, L, 0u, ctx->mods, ctx->d_tw_fwd);
+        LM_HIP(ctx, hipGetLastError());
+    } else {
         lm_prof_scope ps(ctx, "rs_digit_ntt", (uint64_t)B * nd * nt);
-        LM_LDS_ATTR(ctx, k_rs_digit_ntt<LOGN>, lds);
-        hipLaunchKernelGGL(k_rs_digit_ntt<LOGN>, dim3(B * nd * nt), dim3(threads), lds, ctx->stream, coef, ext, B, nd,
-                           nt, L, rk->w, ctx->mods, ctx->d_tw_fwd);
+        LM_LDS_ATTR(ctx, (k_rs_digit_ntt<LOGN, false>), lds);
+        hipLaunchKernelGGL((k_rs_digit_ntt<LOGN, false>), dim3(B * nd * nt), dim3(threads), lds, ctx->stream, coef, ext,
+                           B, nd, nt, L, rk->w, ctx->mods, ctx->d_tw_fwd);
         LM_HIP(ctx, hipGetLastError());
     }
     // 3. gadget product
     {
         lm_prof_scope ps(ctx, "rs_mac", (uint64_t)B);
         hipLaunchKernelGGL(k_rs_mac, dim3((N + 255) / 256, nt, B), dim3(256), 0, ctx->stream, ext, rk->d_key, u, B, nd,
-                           nt, L, ctx->logN, ctx->mods);
+                           nt, L, ctx->logN, ctx->mods, hybrid ? in + (size_t)nl * N : (const u64 *)nullptr, in_ctw);
         LM_HIP(ctx, hipGetLastError());
     }
-    // 4. P limbs -> coefficient domain with the source-side lift factors, correction bit
-    {
+    if (K) {
+        // 4. P limbs -> coefficient domain with the source-side lift factors, correction bit
         lm_modmap mp;
         mp.period = K;
         for (uint32_t i = 0; i < LM_MAX_LIMBS; i++) mp.idx[i] = (uint8_t)(L + (i < K ? i : 0));
@@ -216,13 +267,16 @@ static int ring_switch_batch(lumen_ctx *ctx, RsKey *rk, const lm_ks_view &kv, co
             return rc;
         if (K == 2)
             if (int rc = lm_launch_pack_v(ctx, u + N, (size_t)nt * N, B * 2, 1u, K, L, K)) return rc;
-    }
-    // 5. ModDown, add c0 -> level-0 ciphertext of the big ring under the embedded small key
-    {
+        // 5. ModDown, add c0 -> level-0 ciphertext of the big ring under the embedded small key
         lm_prof_scope ps(ctx, "rs_moddown", (uint64_t)B * 2);
         LM_LDS_ATTR(ctx, k_rs_moddown<LOGN>, lds);
         hipLaunchKernelGGL(k_rs_moddown<LOGN>, dim3(B * 2), dim3(threads), lds, ctx->stream, u, in, in_ctw, big,
                            kv.d_bxp, kv.d_pinv, nt, K, ctx->mods, ctx->d_tw_fwd);
+        LM_HIP(ctx, hipGetLastError());
+    } else {
+        // no special prime: the gadget product is the result; add c0
+        hipLaunchKernelGGL(k_rs_add_c0, dim3(1024), dim3(256), 0, ctx->stream, u, in, in_ctw, big, B, ctx->logN,
+                           ctx->mods);
         LM_HIP(ctx, hipGetLastError());
     }
     // 6. SwitchCiphertextRingDegreeNTT
@@ -240,8 +294,9 @@ extern "C" int lumen_ring_switch(lumen_ctx *ctx, const lumen_set *in, uint64_t *
     const std::shared_ptr<RsKey> rk_hold = lm_ext_get<RsKey>(ctx, "ringswitch_key");
     LM_CHECK(ctx, rk_hold, "no ring-switch key loaded (lumen_load_ringswitch_key)");
     RsKey *rk = rk_hold.get();
-    lm_ks_view kv;
-    if (int rc = lm_ks_tables_view(ctx, &kv)) return rc;
+    lm_ks_view kv = {nullptr, nullptr, nullptr};
+    if (ctx->K)
+        if (int rc = lm_ks_tables_view(ctx, &kv)) return rc;
     const uint32_t N = ctx->N, K = ctx->K, nt = 1 + K, nd = rk->nd, nl = in->nl;
     const size_t n = (size_t)1 << rk->logn, in_ctw = (size_t)2 * nl * N;
     const uint32_t Bmax = std::min<uint32_t>(256, std::max(in->count, 1u));

@@ -15,7 +15,7 @@ _u64p = C.POINTER(C.c_uint64)
 _u32p = C.POINTER(C.c_uint32)
 _u8p = C.POINTER(C.c_uint8)
 LUMEN_MAX_LIMBS = 24
-LUMEN_ABI_VERSION = 2
+LUMEN_ABI_VERSION = 3
 
 
 class LumenError(RuntimeError):
@@ -88,6 +88,7 @@ SYMBOLS = {
     "lumen_inner_sum": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
     "lumen_gather": (C.c_int, [_vp, _vp, _u32p, C.c_uint32, _vpp]),
     "lumen_plain_inner_products": (C.c_int, [_vp, _vp, _u64p, _u64p]),
+    "lumen_ringswitch_rns_digits": (C.c_uint32, [_vp]),
     "lumen_ringswitch_digits": (C.c_uint32, [_vp, C.c_uint32]),
     "lumen_load_ringswitch_key": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _u64p]),
     "lumen_ring_switch": (C.c_int, [_vp, _vp, _u64p]),
@@ -483,8 +484,17 @@ class Context:
         self._ck(self.lib.lumen_gather(self.h, s.h, idx.ctypes.data_as(_u32p), len(idx), C.byref(h)))
         return DeviceSet(self, h)
 
+    def ringswitch_key_shape(self, w=13):
+        """(rns, pw2, 2, L+K, N): rlwe.GadgetCiphertext.Value of the ring-switch key, flattened"""
+        return (int(self.lib.lumen_ringswitch_rns_digits(self.h)), int(self.lib.lumen_ringswitch_digits(self.h, w)),
+                2, self.L + self.K, self.N)
+
     def load_ringswitch_key(self, log_n_small, key, w=13):
+        """key: the whole evaluation key [rns][pw2][2][L+K][N], or just its RNS digit 0 [pw2][2][L+K][N]"""
         key = np.ascontiguousarray(key, dtype=np.uint64)
+        shape = self.ringswitch_key_shape(w)
+        if key.shape not in (shape, shape[1:]):
+            raise ValueError(f"ring-switch key has shape {key.shape}, expected {shape} or {shape[1:]}")
         self._ck(self.lib.lumen_load_ringswitch_key(self.h, log_n_small, w, _p64(key)))
         self._rs_logn = log_n_small
 

@@ -1,6 +1,7 @@
 // Host-side mirror of the reference's `fhe` package, server half (see fhe.hpp).
 #include "fhe.hpp"
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -80,16 +81,38 @@ Parameters Parameters::FromLiteral(const ParametersLiteral &lit) {
     return FromModuli(lit.LogN, q, p, lit.PlaintextModulus);
 }
 
-std::vector<uint64_t> Parameters::GaloisElementsForInnerSum(int batch, int n) const {
-    std::vector<uint64_t> out;
+uint64_t Parameters::GaloisElement(int k) const {
+    // [LATTIGO-RECALL] rlwe.Parameters.GaloisElement: GaloisGen^(k mod 2N) mod 2N, GaloisGen = 5
     const uint64_t two_n = 2ull << LogN;
-    const int span = (n * batch == N()) ? n / 2 : n;
-    uint64_t g = PowMod(5, (uint64_t)batch, two_n);
-    for (int r = 1; r < span; r <<= 1) {
-        out.push_back(g);
-        g = (g * g) & (two_n - 1);
+    return PowMod(5, (uint64_t)k & (two_n - 1), two_n);
+}
+
+std::vector<uint64_t> Parameters::GaloisElementsForInnerSum(int batch, int n) const {
+    // [LATTIGO-RECALL] rlwe.GaloisElementsForInnerSum: rotations {i*batch, (n - (n & (2i-1)))*batch} for
+    // i = 1, 2, 4, ... < n, collected in a map (Go's iteration order is undefined; ascending here) -- for a
+    // power of two {1, 2, ..., n/2, n}*batch; bgv.Parameters appends GaloisElementForRowRotation() when
+    // n > N/2.  Rotations by N/2 and by N both give the element 1 (5 has order N/2 modulo 2N): the client
+    // really generates and posts keys for them.  Count pinned by the reference's key-size logs
+    // (tests/test_oracle_kat.py): 12 / 14 / 15 / 16 for the four configurations.
+    std::vector<int> rots;
+    for (int i = 1; i < n; i <<= 1) {
+        rots.push_back(i * batch);
+        rots.push_back((n - (n & ((i << 1) - 1))) * batch);
     }
-    if (n * batch == N()) out.push_back(two_n - 1);
+    std::sort(rots.begin(), rots.end());
+    rots.erase(std::unique(rots.begin(), rots.end()), rots.end());
+    std::vector<uint64_t> out;
+    for (int r : rots) out.push_back(GaloisElement(r));
+    if (n > N() / 2) out.push_back((2ull << LogN) - 1);
+    return out;
+}
+
+std::vector<uint64_t> Parameters::GaloisElementsUsedByInnerSum(int n) const {
+    const uint64_t two_n = 2ull << LogN;
+    std::vector<uint64_t> out;
+    const int span = (n == N()) ? n / 2 : n;
+    for (int r = 1; r < span; r <<= 1) out.push_back(GaloisElement(r));
+    if (n == N()) out.push_back(two_n - 1);
     return out;
 }
 

@@ -39,8 +39,13 @@ struct Parameters {
     static Parameters FromLiteral(const ParametersLiteral &lit);
     // explicit moduli (what a Go host passes: Lattigo's own)
     static Parameters FromModuli(int logN, std::vector<uint64_t> q, std::vector<uint64_t> p, uint64_t T);
-    // params.GaloisElementsForInnerSum(1, n) in the order InnerSum uses them
+    uint64_t GaloisElement(int k) const; // 5^k mod 2N
+    // params.GaloisElementsForInnerSum(batch, n) (fhe/ligero_test.go:53, cmd/client/main.go:81): the elements
+    // the CLIENT generates keys for -- rotations {1, 2, ..., n/2, n}*batch plus the row swap iff n > N/2
+    // (12 / 14 / 15 / 16 keys at the four reference configurations, as their key-size logs show)
     std::vector<uint64_t> GaloisElementsForInnerSum(int batch, int n) const;
+    // the subset InnerSum(ct, 1, n) applies, in the order it applies them (lumen_inner_sum_galois_elements)
+    std::vector<uint64_t> GaloisElementsUsedByInnerSum(int n) const;
 };
 
 struct Plaintext { // *rlwe.Plaintext: one polynomial, NTT domain, [level+1][N]
@@ -142,7 +147,8 @@ void OsRandom(uint8_t *out, size_t n);
 class RingSwitchServer {
   public:
     // NewRingSwitchServer(ringSwitchEvk, paramsLit): paramsLit.LogN is the target degree, its single
-    // modulus is q_0 (ring_switch.go:30-38); the key arrives in the layout of lumen_load_ringswitch_key
+    // modulus is q_0 (ring_switch.go:30-38); ringSwitchEvk is the whole evaluation key the client posts,
+    // flattened [rns][pw2][b|a][L+K][N] (lumen_load_ringswitch_key; RNS digit 0 alone is accepted too)
     RingSwitchServer(ServerBFV &backend, const std::vector<uint64_t> &ringSwitchEvk, int logN,
                      int baseTwoDecomposition = 13);
     // RingSwitchNew for every ciphertext of the slice: host result [len][2][2^logN] (level 0, small ring)

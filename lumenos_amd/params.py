@@ -164,3 +164,46 @@ def calculate_queries(security_bits: float, rho_inv: int) -> int:
     if 1.0 - t <= 0:
         return 0
     return int(math.ceil(security_bits / (1.0 - t)))
+
+
+def galois_element(log_n: int, k: int) -> int:
+    """params.GaloisElement(k) = 5^k mod 2N ([LATTIGO-RECALL]: the exponent is taken modulo 2N, the order
+    of 5 is N/2, so rotations by N/2 and N both give the identity element 1)."""
+    two_n = 2 << log_n
+    return pow(5, k & (two_n - 1), two_n)
+
+
+def galois_elements_for_inner_sum(log_n: int, batch: int, n: int) -> List[int]:
+    """bgv.Parameters.GaloisElementsForInnerSum(batch, n) -- the list the CLIENT generates keys for
+    (fhe/ligero_test.go:53, cmd/client/main.go:81) [LATTIGO-RECALL]: rlwe's rotations
+    {i*batch, (n - (n & (2i - 1)))*batch : i = 1, 2, 4, ... < n} -- for n a power of two that is
+    {1, 2, ..., n/2, n}*batch, log2(n) + 1 of them -- plus the row-swap element 2N - 1 iff n > N/2.
+    Pinned by the reference's own logs: "Marshaled keys length" 69 / 103 / 237 / 504 MB
+    (results/baseline/client/bench_*.txt:19) is pk + rlk + exactly 12 / 14 / 15 / 16 Galois keys
+    (tests/test_oracle_kat.py).  Go builds the list from a map, so its order is not defined; here ascending
+    rotation.  InnerSum itself never uses rotation n (nor N/2 when n = N): see
+    galois_elements_used_by_inner_sum."""
+    rots = set()
+    i = 1
+    while i < n:
+        rots.add(i * batch)
+        rots.add((n - (n & ((i << 1) - 1))) * batch)
+        i <<= 1
+    out = [galois_element(log_n, r) for r in sorted(rots)]
+    if n > (1 << log_n) >> 1:
+        out.append((2 << log_n) - 1)
+    return out
+
+
+def galois_elements_used_by_inner_sum(log_n: int, n: int) -> List[int]:
+    """The keys InnerSum(ct, 1, n) actually applies, in order (lumen_inner_sum_galois_elements): rotations
+    1, 2, ..., span/2 with span = min(n, N/2), then the row swap when n = N."""
+    N = 1 << log_n
+    span = n >> 1 if n == N else n
+    out, r = [], 1
+    while r < span:
+        out.append(galois_element(log_n, r))
+        r <<= 1
+    if n == N:
+        out.append(2 * N - 1)
+    return out

@@ -227,13 +227,16 @@ int lo_decrypt_decode_batch(const lo_params *p, const uint64_t *sk, const uint64
 uint64_t lo_rescale_scale(const lo_params *p, uint32_t nl_from, uint32_t nl_to);
 
 /* --------------------------------------------------------------- ring switch */
-/* fhe/ring_switch.go:16-57,93-113 [LATTIGO-RECALL]: key-switch sk -> skNew (a secret of the ring of
- * degree n = 2^logn_small, embedded as skNew(X^(N/n))) with a base-2^w gadget (w = 13), at level 0
- * (only q_0), then projection onto the sub-ring: keep the coefficients of X^(i*N/n).
- * Key layout: [npw2][b|a][limb {q_0, p_0..p_{K-1}}][N], NTT domain, standard form,
- * npw2 = ceil(bits(q_0)/w).  Output: [2][n] residues mod q_0, NTT domain of the small ring
+/* fhe/ring_switch.go:16-57,93-113 [LATTIGO-RECALL]: key switch sk -> skNew (a secret of the ring of
+ * degree n = 2^logn_small, embedded as skNew(X^(N/n))) at level 0 (only q_0), then projection onto the
+ * sub-ring: keep the coefficients of X^(i*N/n).  The gadget follows the key's LevelP (lo_ringswitch.c):
+ * two or more special primes -> hybrid RNS digits only (BaseTwoDecomposition ignored, pw2 = 1);
+ * one or none -> unsigned base-2^w digits (w = 13), no ModDown without a special prime.
+ * Key layout: rlwe.GadgetCiphertext.Value flattened, [rns][pw2][b|a][limb(L+K)][N], NTT domain, standard
+ * form; (rns, pw2) = lo_rs_key_shape.  Output: [2][n] residues mod q_0, NTT domain of the small ring
  * (psi_small = psi_{q_0}^(N/n)). */
-uint32_t lo_rs_num_digits(const lo_params *p, uint32_t w);
+void lo_rs_key_shape(const lo_params *p, uint32_t w, uint32_t *rns, uint32_t *pw2);
+uint32_t lo_rs_num_digits(const lo_params *p, uint32_t w); /* pw2 of lo_rs_key_shape */
 size_t lo_rs_key_words(const lo_params *p, uint32_t w);
 void lo_keygen_secret_small(const lo_params *p, lo_rng *r, uint32_t logn_small, int64_t *sk_small_coeffs);
 void lo_keygen_ringswitch(const lo_params *p, lo_rng *r, const uint64_t *sk, const int64_t *sk_small_coeffs,

@@ -109,6 +109,7 @@ class Oracle:
             "lo_decrypt_decode": (C.c_int, [vp, u64p, u64p, C.c_uint32, C.c_uint64, u64p, C.c_uint32]),
             "lo_decrypt_decode_batch": (C.c_int, [vp, u64p, u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, C.c_uint32]),
             "lo_rs_num_digits": (C.c_uint32, [vp, C.c_uint32]),
+            "lo_rs_key_shape": (None, [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
             "lo_rs_key_words": (C.c_size_t, [vp, C.c_uint32]),
             "lo_keygen_secret_small": (None, [vp, vp, C.c_uint32, C.POINTER(C.c_int64)]),
             "lo_keygen_ringswitch": (None, [vp, vp, u64p, C.POINTER(C.c_int64), C.c_uint32, C.c_uint32, u64p]),
@@ -446,13 +447,19 @@ class Params:
     def rs_num_digits(self, w=13):
         return int(self.o.lib.lo_rs_num_digits(self.h, w))
 
+    def rs_key_shape(self, w=13):
+        """(rns, pw2) of the ring-switch key's GadgetCiphertext.Value (lo_rs_key_shape)"""
+        rns, pw2 = C.c_uint32(), C.c_uint32()
+        self.o.lib.lo_rs_key_shape(self.h, w, C.byref(rns), C.byref(pw2))
+        return rns.value, pw2.value
+
     def keygen_secret_small(self, logn_small):
         c = np.zeros(1 << logn_small, dtype=np.int64)
         self.o.lib.lo_keygen_secret_small(self.h, self._r(), logn_small, c.ctypes.data_as(C.POINTER(C.c_int64)))
         return c
 
     def keygen_ringswitch(self, sk, sk_small, logn_small, w=13):
-        key = np.zeros((self.rs_num_digits(w), 2, 1 + self.K, self.N), dtype=np.uint64)
+        key = np.zeros((*self.rs_key_shape(w), 2, self.L + self.K, self.N), dtype=np.uint64)
         self.o.lib.lo_keygen_ringswitch(self.h, self._r(), _p64(sk), sk_small.ctypes.data_as(C.POINTER(C.c_int64)),
                                         logn_small, w, _p64(key))
         return key

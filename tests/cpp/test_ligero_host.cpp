@@ -2,6 +2,7 @@
 // lumenos_amd/host: the server side runs on the GPU through the C ABI, the client side
 // (keys, decryption) and the plain verifier arithmetic come from the CPU oracle (test infra).
 //   usage: test_ligero_host <logN> <rows> <cols> <numQ>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -53,6 +54,17 @@ int main(int argc, char **argv) {
     lo_keygen_secret(op, &rng, sk.data());
     lo_keygen_public(op, &rng, sk.data(), pk.data());
     std::map<uint64_t, std::vector<uint64_t>> evk;
+    {
+        // ligero_test.go:53: the client generates a key for EVERY element of GaloisElementsForInnerSum(1, rows)
+        // -- rotations 1..rows/2 and rows, plus the row swap when rows > N/2 (12 / 14 / 15 keys at the three
+        // reference shapes; results/baseline/client/bench_*.txt:19) -- of which InnerSum uses a subset
+        const std::vector<uint64_t> gen = params.GaloisElementsForInnerSum(1, rows), used = params.GaloisElementsUsedByInnerSum(rows);
+        int log_rows = 0;
+        while ((1 << log_rows) < rows) log_rows++;
+        REQUIRE((int)gen.size() == log_rows + 1 + (rows > N / 2 ? 1 : 0), "GaloisElementsForInnerSum returns %zu elements", gen.size());
+        for (uint64_t g : used) REQUIRE(std::find(gen.begin(), gen.end(), g) != gen.end(), "InnerSum uses a key the client never generates");
+        printf("Galois keys generated: %zu, used by InnerSum: %zu\n", gen.size(), used.size());
+    }
     for (uint64_t g : params.GaloisElementsForInnerSum(1, rows)) {
         evk[g].resize(lo_evk_words(op));
         lo_keygen_galois(op, &rng, sk.data(), g, evk[g].data());

@@ -497,14 +497,17 @@ def test_device_merkle_root_and_device_digests(oracle, small):
         assert ctx.merkle_root_device(ptr, count) == want, count
 
 
-@pytest.mark.parametrize("log_n,logn_small", [(10, 10), (12, 10), (12, 8), (14, 10)])
-def test_ring_switch_matches_oracle(oracle, log_n, logn_small):
-    """RingSwitchNew (fhe/ring_switch.go:106-113): bit-exact vs the oracle, and the sub-ring contract:
-    the small-ring ciphertext decrypts (under skNew) to the coefficients X^(i*N/n) of the input's
-    plaintext.  T as in TestRingSwitch (ring_switch_test.go:17): with T ~ 2^57 a single 58-bit limb
-    leaves no room for noise."""
+@pytest.mark.parametrize("log_n,logn_small,num_p", [(10, 10, 2), (12, 10, 2), (12, 8, 2), (14, 10, 2),
+                                                    (12, 10, 1), (13, 11, 1), (12, 10, 0), (11, 8, 0)])
+def test_ring_switch_matches_oracle(oracle, log_n, logn_small, num_p):
+    """RingSwitchNew (fhe/ring_switch.go:106-113): bit-exact vs the oracle on the three gadget paths Lattigo
+    takes by the key's LevelP (2 special primes: one hybrid RNS digit, the reference's configurations;
+    1: base-2^13 digits + ModDown; 0: base-2^13 digits, no ModDown), and the sub-ring contract: the
+    small-ring ciphertext decrypts (under skNew) to the coefficients X^(i*N/n) of the input's plaintext.
+    T as in TestRingSwitch (ring_switch_test.go:17): with T ~ 2^57 a single 58-bit limb leaves no room for
+    noise.  The library is handed the WHOLE key the client posts and reads RNS digit 0 of it."""
     T = 0x3EE0001
-    P = make_params(oracle, log_n, 3, T=T)
+    P = make_params(oracle, log_n, 3, num_p=num_p, T=T)
     P.seed(log_n * 100 + logn_small)
     sk, ctx = P.keygen_secret(), make_context(P)
     pk = P.keygen_public(sk)
@@ -513,7 +516,8 @@ def test_ring_switch_matches_oracle(oracle, log_n, logn_small):
                     for _ in range(3)])
     sk_small = P.keygen_secret_small(logn_small)
     key = P.keygen_ringswitch(sk, sk_small, logn_small)
-    assert ctx.lib.lumen_ringswitch_digits(ctx.h, 13) == P.rs_num_digits() == 5
+    assert ctx.ringswitch_key_shape() == key.shape == (*P.rs_key_shape(), 2, P.L + P.K, P.N)
+    assert ctx.lib.lumen_ringswitch_digits(ctx.h, 13) == P.rs_num_digits() == (1 if num_p == 2 else 5)
     ctx.load_ringswitch_key(logn_small, key)
     got = ctx.ring_switch(ctx.upload(cts))
     gap = P.N >> logn_small
@@ -521,6 +525,31 @@ def test_ring_switch_matches_oracle(oracle, log_n, logn_small):
         assert np.array_equal(got[c], P.ring_switch(cts[c], key, logn_small)), c
         assert np.array_equal(P.decrypt_small_coeffs(sk_small, logn_small, got[c]),
                               P.decrypt_big_coeffs_l0(sk, cts[c])[::gap])
+    # RNS digit 0 alone is enough (ApplyEvaluationKey works at level 0)
+    ctx.load_ringswitch_key(logn_small, key[0])
+    assert np.array_equal(ctx.ring_switch(ctx.upload(cts[:1]))[0], got[0])
+    ctx.close()
+
+
+def test_ring_switch_reference_test_twin(oracle):
+    """TestRingSwitch (fhe/ring_switch_test.go:13-77) through the C ABI: LogN = 12 -> 12, LogQ = [58], no
+    special prime, T = 0x3ee0001; m = [1, 1] encrypted under pk at level 0; RingSwitch; decrypt under skNew
+    and decode: mCheck == m.  (Keys, encryption and decryption are the oracle's -- the client side of the
+    test; the switch is the device's and bit-equal to the oracle's.)"""
+    T = 0x3EE0001
+    P = make_params(oracle, 12, 1, num_p=0, T=T)
+    P.seed(13)
+    sk, ctx = P.keygen_secret(), make_context(P)
+    pk = P.keygen_public(sk)
+    m = np.array([1, 1], dtype=np.uint64)
+    ct = P.encrypt(pk, P.encode(m))
+    sk_new = P.keygen_secret_small(12)
+    key = P.keygen_ringswitch(sk, sk_new, 12)
+    assert ctx.ringswitch_key_shape() == key.shape == (1, 5, 2, 1, P.N)
+    ctx.load_ringswitch_key(12, key)
+    ct2 = ctx.ring_switch(ctx.upload(ct[None]))[0]
+    assert np.array_equal(ct2, P.ring_switch(ct, key, 12))
+    assert np.array_equal(P.decode_coeffs(P.decrypt_small_coeffs(sk_new, 12, ct2), 1, 2), m)
     ctx.close()
 
 

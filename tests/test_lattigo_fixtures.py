@@ -68,12 +68,11 @@ def galois_key(rec, name, moduli, montgomery):
 
 
 def ringswitch_key(rec, name, moduli, L, K, montgomery):
-    """ring-switch key [D*D2*2][L+K][N] -> [digit_pow2][b|a][q0, p_0..p_{K-1}][N] of RNS digit 0
-    (level 0 only uses q_0: lumen_load_ringswitch_key)"""
+    """ring-switch key record [D*D2*2][L+K][N] -> the ABI's [rns][pw2][b|a][L+K][N]: the WHOLE
+    GadgetCiphertext.Value as the client posts it (lumen_load_ringswitch_key reads RNS digit 0 of it)"""
     d, d2, _base = (int(x) for x in rec[name + ".shape"])
     k = rec[name].reshape(d, d2, 2, len(moduli), -1)
-    k = from_montgomery(k, moduli) if montgomery else k
-    return np.ascontiguousarray(k[0][:, :, [0] + list(range(L, L + K)), :])
+    return from_montgomery(k, moduli) if montgomery else np.ascontiguousarray(k)
 
 
 def leaf_format(blob, ct):
@@ -196,13 +195,10 @@ def synthesize(oracle, out_dir, log_n=10, cols=16):
 
     small = 8
     sk_small = P.keygen_secret_small(small)
-    key = P.keygen_ringswitch(sk, sk_small, small)  # [npw2][2][1+K][N], RNS digit 0, limbs {q0, P}
-    nd2 = key.shape[0]
-    beta = P.beta()
-    full = np.zeros((beta, nd2, 2, L + K, N), dtype=np.uint64)
-    full[0][:, :, [0] + list(range(L, L + K)), :] = key
-    d = {"logN_small": np.array([small], dtype=np.uint64), "key": to_montgomery(full, mods).reshape(-1, L + K, N),
-         "key.shape": np.array([beta, nd2, 13], dtype=np.uint64), "keys_montgomery": np.array([1], dtype=np.uint64)}
+    key = P.keygen_ringswitch(sk, sk_small, small)  # [rns][pw2][2][L+K][N]: GadgetCiphertext.Value
+    rns, pw2 = key.shape[:2]
+    d = {"logN_small": np.array([small], dtype=np.uint64), "key": to_montgomery(key, mods).reshape(-1, L + K, N),
+         "key.shape": np.array([rns, pw2, 13], dtype=np.uint64), "keys_montgomery": np.array([1], dtype=np.uint64)}
     ct_rec(d, "in", l1, P.rescale_scale(L, 2))
     out = P.ring_switch(l1, key, small)
     d["out"] = out[:, None, :]
@@ -383,10 +379,13 @@ def test_ring_switch(oracle, fx):
     rec = load("ringswitch.lmfx")
     small = int(rec["logN_small"][0])
     key = ringswitch_key(rec, "key", P.moduli, P.L, P.K, int(rec["keys_montgomery"][0]))
-    assert key.shape[0] == P.rs_num_digits(int(rec["key.shape"][2]) or 13)
+    # the shape decides which gadget product Lattigo ran: [beta][1] with LevelP >= 1 (no power-of-two digits,
+    # as the reference's key-size logs say), [L][ceil(bits/13)] with LevelP <= 0
+    assert key.shape[:2] == P.rs_key_shape(int(rec["key.shape"][2]) or 13), \
+        f"Lattigo's ring-switch key is {key.shape[:2]}, the restatement expects {P.rs_key_shape(13)}"
     ct = std_ct(rec, "in")
     assert np.array_equal(P.ring_switch(ct, key, small), rec["out"][:, 0, :]), \
-        "ApplyEvaluationKey into the small ring (unsigned base-2^13 digits, sub-ring extraction)"
+        "ApplyEvaluationKey into the small ring (level-0 gadget product, ModDown, sub-ring extraction)"
 
 
 def test_ct_ntt(oracle, fx):

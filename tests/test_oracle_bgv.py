@@ -146,12 +146,15 @@ def test_golden_evaluator(oracle):
     assert np.array_equal(got, g["matrix_inner_sum"])
 
 
-@pytest.mark.parametrize("logn_small", [10, 8])
-def test_ring_switch_on_oracle(oracle, logn_small):
-    """TestRingSwitch (fhe/ring_switch_test.go:13-77): same-degree switch decrypts to the same slots;
-    smaller degree keeps the coefficients of X^(i*N/n) (SwitchCiphertextRingDegreeNTT)."""
+@pytest.mark.parametrize("num_p,logn_small", [(2, 10), (2, 8), (1, 10), (1, 8), (0, 10), (0, 7)])
+def test_ring_switch_on_oracle(oracle, num_p, logn_small):
+    """RingSwitchNew (fhe/ring_switch.go:106-113) on the oracle's BGV, on all three gadget paths Lattigo
+    takes by the key's LevelP (two special primes: RNS digit only, the reference's configurations; one:
+    base-2^13 digits + ModDown; none: base-2^13 digits, TestRingSwitch's parameters): the same-degree switch
+    decrypts to the same slots; a smaller degree keeps the coefficients of X^(i*N/n)
+    (SwitchCiphertextRingDegreeNTT)."""
     T = 0x3EE0001  # ring_switch_test.go:17
-    P = make_params(oracle, 10, 3, T=T)
+    P = make_params(oracle, 10, 3, num_p=num_p, T=T)
     P.seed(77)
     sk = P.keygen_secret()
     pk = P.keygen_public(sk)
@@ -159,12 +162,42 @@ def test_ring_switch_on_oracle(oracle, logn_small):
     vals[:2] = 1  # m := []uint64{1, 1}
     ct = P.rescale_to_level1(P.encrypt(pk, P.encode(vals)))
     sk_small = P.keygen_secret_small(logn_small)
+    rns, pw2 = P.rs_key_shape()
+    assert (rns, pw2) == ({2: 2, 1: 3, 0: 3}[num_p], 1 if num_p == 2 else 5)
     key = P.keygen_ringswitch(sk, sk_small, logn_small)
+    assert key.shape == (rns, pw2, 2, P.L + P.K, P.N)
     small = P.ring_switch(ct, key, logn_small)
     m = P.decrypt_small_coeffs(sk_small, logn_small, small)
     assert np.array_equal(m, P.decrypt_big_coeffs_l0(sk, ct)[::P.N >> logn_small])
     if logn_small == 10:
         assert np.array_equal(P.decode_coeffs(m, P.rescale_scale(P.L, 2), 2), vals[:2])
+    # level 0 reads RNS digit 0 only: the other digits of the key do not matter
+    key2 = key.copy()
+    key2[1:] = 0
+    assert np.array_equal(P.ring_switch(ct, key2, logn_small), small)
+
+
+def test_ring_switch_reference_test_parameters(oracle):
+    """TestRingSwitch itself (fhe/ring_switch_test.go:13-77): LogN = 12 -> 12, LogQ = [58], no special
+    prime, T = 0x3ee0001, m = [1, 1] encrypted under pk at level 0 (no rescale), RingSwitch, decrypt under
+    skNew, decode: mCheck == m.  With LevelP = -1 the key has ceil(58/13) = 5 power-of-two entries for its
+    one RNS digit and the switch has no ModDown."""
+    T = 0x3EE0001
+    P = make_params(oracle, 12, 1, num_p=0, T=T)
+    P.seed(13)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    m = np.array([1, 1], dtype=np.uint64)
+    ct = P.encrypt(pk, P.encode(m))
+    assert ct.shape == (2, 1, P.N)
+    sk_new = P.keygen_secret_small(12)
+    assert P.rs_key_shape() == (1, 5)
+    key = P.keygen_ringswitch(sk, sk_new, 12)
+    ct2 = P.ring_switch(ct, key, 12)
+    coeffs = P.decrypt_small_coeffs(sk_new, 12, ct2)
+    assert np.array_equal(P.decode_coeffs(coeffs, 1, 2), m)
+    # and the whole plaintext polynomial survives, not just two slots
+    assert np.array_equal(coeffs, P.decrypt_big_coeffs_l0(sk, ct))
 
 
 # ------------------------------------------------------------------ deterministic pk encryption (lo_encdet.c)

@@ -138,3 +138,118 @@ def test_merkle_tree_and_paths(oracle):
                 bad = path.copy()
                 bad[0, 0] ^= 1
                 assert not oracle.merkle_verify(leaves[idx], bad, root, idx)
+
+
+# ------------------------------------------------------------------ size logs: key material and ring-switched proofs
+def humanize_bytes(s):
+    """dustin/go-humanize Bytes(): SI units, one decimal below 10, none above (what fmt.Println shows in
+    cmd/client/main.go:132 and fhe/ligero.go:672-692)."""
+    import math
+    if s < 10:
+        return f"{s} B"
+    e = math.floor(math.log(s, 1000))
+    val = math.floor(s / 1000 ** e * 10 + 0.5) / 10
+    return (f"{val:.1f} " if val < 10 else f"{val:.0f} ") + ["B", "kB", "MB", "GB", "TB"][e]
+
+
+def base64_len(n):
+    return 4 * ((n + 2) // 3)
+
+
+# (rows, cols, LogN, "Marshaled keys length" baseline, with ring switch)
+# results/baseline/client/bench_*.txt:19, results/experimental/client/bench_*.txt:20
+SIZE_KATS = [
+    (2048, 1024, 12, "69 MB", "74 MB"),
+    (4096, 2048, 12, "103 MB", "110 MB"),
+    (8192, 4096, 13, "237 MB", "252 MB"),
+    (16384, 4096, 14, "504 MB", "533 MB"),
+]
+
+
+def _keys_request_len(pk, evks, rs_evk=None):
+    """len(json.Marshal(KeysRequest{...})) (cmd/client/main.go:26-32,105-130): []byte fields are base64
+    strings; without a ring switch the last two fields are null"""
+    n = len('{"public_key":"","relinearization_key":"","rotation_keys":[],"ring_switch_evk":,"params_lit":}')
+    n += base64_len(pk) + base64_len(evks[0])
+    n += sum(base64_len(k) + 2 for k in evks[1:]) + max(len(evks) - 2, 0)
+    if rs_evk is None:
+        return n + 2 * len("null")
+    return n + base64_len(rs_evk) + 2 + 150  # ParametersLiteral JSON: LogN, Q, P, PlaintextModulus...
+
+
+@pytest.mark.parametrize("rows,cols,log_n,keys,keys_rs", SIZE_KATS)
+def test_key_and_ring_switch_key_sizes_match_reference_logs(oracle, rows, cols, log_n, keys, keys_rs):
+    """The reference's size logs pin three things no test of its own does:
+      * the client generates pk + rlk + len(GaloisElementsForInnerSum(1, rows)) = 12 / 14 / 15 / 16 Galois keys,
+        each beta x 1 x 2 polynomials over L+K limbs (no power-of-two digits);
+      * the ring-switch key adds exactly ONE key of that same size -- so with two special primes its
+        BaseTwoDecomposition = 13 produces no extra digits (a base-2^13 gadget would add five).
+    Every serialised object carries a header of unknown exact length (MetaData, length words): the model
+    must give the logged string for any header between 0 and 2 KiB per key (the recalled framing -- 8 bytes
+    per limb, polynomial and vector -- is about 1.5 KiB for the largest key)."""
+    from helpers import make_params
+    from lumenos_amd import params as lp
+    logq, logp = lp.bgv_param_bits(cols, log_n, T_REF)
+    L, K, N = len(logq), len(logp), 1 << log_n
+    P = make_params(oracle, log_n, L, num_p=K)
+    beta = oracle.lib.lo_beta(P.h, L)
+    assert beta == (L + K - 1) // K
+    gal = lp.galois_elements_for_inner_sum(log_n, 1, rows)
+    assert len(gal) == {2048: 12, 4096: 14, 8192: 15, 16384: 16}[rows]
+    assert set(lp.galois_elements_used_by_inner_sum(log_n, rows)) <= set(gal)
+    assert lp.galois_elements_used_by_inner_sum(log_n, rows) == P.inner_sum_galois_elements(rows)
+    rns, pw2 = P.rs_key_shape(13)
+    assert (rns, pw2) == (beta, 1)
+    assert oracle.lib.lo_rs_key_words(P.h, 13) == oracle.lib.lo_evk_words(P.h)
+    for hdr in (0, 2048):
+        pk = 2 * (L + K) * N * 8 + hdr
+        evk = beta * 2 * (L + K) * N * 8 + hdr
+        rs_evk = rns * pw2 * 2 * (L + K) * N * 8 + hdr
+        assert humanize_bytes(_keys_request_len(pk, [evk] * (1 + len(gal)))) == keys, hdr
+        assert humanize_bytes(_keys_request_len(pk, [evk] * (1 + len(gal)), rs_evk)) == keys_rs, hdr
+        # the gadget the previous rounds restated (ceil(58/13) = 5 digits) is ruled out by the same log
+        assert humanize_bytes(_keys_request_len(pk, [evk] * (1 + len(gal)), 5 * rs_evk)) != keys_rs
+
+
+# results/baseline/server/bench_*.txt:31-36 and results/experimental/server/bench_*.txt:32-37:
+# (rows, cols, LogN, MatR, QueriedCols, whole proof) without and with the ring switch to LogN = 10
+PROOF_SIZES = [
+    (2048, 1024, 12, "135 MB", "41 MB", "310 MB", "17 MB", "41 MB", "75 MB"),
+    (4096, 2048, 12, "269 MB", "41 MB", "579 MB", "34 MB", "41 MB", "109 MB"),
+    (8192, 4096, 13, "1.1 GB", "81 MB", "2.2 GB", "68 MB", "81 MB", "218 MB"),
+    (16384, 4096, 14, "2.1 GB", "162 MB", "4.5 GB", "68 MB", "162 MB", "299 MB"),
+]
+
+
+def proof_size_lines(h1, h0):
+    """What EncryptedProof.WriteTo (fhe/ligero.go:659-705) prints for every configuration when a level-1
+    ciphertext of the big ring serialises to 2*2*N*8 + h1 bytes and a ring-switched one (level 0, N = 2^10)
+    to 2*1*1024*8 + h0: metadata (11 bytes) | MatR | MatZ | 309 queried level-1 columns | 309 paths of
+    log2(2*cols) digests | root."""
+    out = []
+    for rows, cols, log_n, *_ in PROOF_SIZES:
+        ct1, ct0 = 2 * 2 * (1 << log_n) * 8 + h1, 2 * 1 * 1024 * 8 + h0
+        tail = 309 * ct1 + 309 * int(np.log2(2 * cols)) * 32 + 32
+        out.append((rows, cols, log_n, humanize_bytes(cols * ct1), humanize_bytes(309 * ct1),
+                    humanize_bytes(11 + 2 * cols * ct1 + tail), humanize_bytes(cols * ct0),
+                    humanize_bytes(309 * ct1), humanize_bytes(11 + 2 * cols * ct0 + tail)))
+    return out
+
+
+def test_proof_sizes_match_reference_logs_and_bound_the_framing():
+    """All 24 size lines the reference logs for its proofs are reproduced by
+    `payload + framing`, and together they leave little room for the framing Lattigo's
+    rlwe.Ciphertext.WriteTo adds (MetaData block + length words), which this build cannot read offline:
+    325..444 bytes for a level-1 ciphertext, 252..351 for a ring-switched one.  Under the recalled framing
+    (MetaData | LE64(2) | per polynomial LE64(limbs) | per limb LE64(N): MetaData + 56 resp. + 40 bytes) the
+    MetaData block is 269..311 bytes -- tests/test_host_mirror.py holds the C++ mirror's block to that."""
+    ok1 = [h1 for h1 in range(0, 1200) if any(proof_size_lines(h1, h0) == PROOF_SIZES for h0 in range(200, 400, 10))]
+    assert (min(ok1), max(ok1)) == (325, 444)
+    # the whole-proof lines couple the two: the bounds of h0 are reached at the ends of h1's range
+    ok0 = [h0 for h0 in range(0, 1200) if any(proof_size_lines(h1, h0) == PROOF_SIZES for h1 in (325, 444))]
+    assert (min(ok0), max(ok0)) == (252, 351)
+    md = [m for m in range(0, 1200) if proof_size_lines(m + 56, m + 40) == PROOF_SIZES]
+    assert (min(md), max(md)) == (269, 311)
+    # a ring-switched ciphertext really is one limb of 2^10 words per polynomial: no other power of two fits
+    for n_small in (512, 2048):
+        assert humanize_bytes(1024 * (2 * n_small * 8 + 300)) != "17 MB"

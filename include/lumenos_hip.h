@@ -157,13 +157,20 @@ int lumen_rescale(lumen_ctx *ctx, const lumen_set *in, uint32_t target_limbs, lu
  * (head = LE64(2), poly_head = LE64(limbs), limb_head = LE64(N)) -- NOT byte-compatible with a
  * Lattigo peer; a root computed under it verifies only against this library's own serialisation.
  * lumen_ct_serialize writes ciphertexts [first, first+n) of a set in the current format into `out`
- * (n * lumen_ct_serialized_size(ctx, limbs) bytes): the proof marshaller, and the shim's one-off
- * byte comparison with Lattigo before it trusts device digests. */
+ * (n * lumen_ct_serialized_size(ctx, limbs) bytes): the proof marshaller (EncryptedProof.WriteTo,
+ * fhe/ligero.go:659-705, is metadata | MatR | MatZ | QueriedCols | paths | root with every ciphertext through
+ * ct.WriteTo), and the shim's one-off byte comparison with Lattigo before it trusts device digests.
+ * The wire image is assembled on the device and crosses PCIe as contiguous DMA: hand it page-locked
+ * memory (lumen_host_alloc; a Go []byte over it feeds the HTTP response with no further copy).
+ * lumen_ct_serialize_async is the same without the wait: `out` must be page-locked, the bytes are valid
+ * after lumen_sync(ctx) -- call it on a lumen_ctx_clone to move MatR while MatZ is computed. */
 int lumen_leaf_format_set(lumen_ctx *ctx, const uint8_t *head, uint32_t head_len, const uint8_t *poly_head,
                           uint32_t poly_head_len, const uint8_t *limb_head, uint32_t limb_head_len);
 size_t lumen_ct_serialized_size(lumen_ctx *ctx, uint32_t num_limbs);
 int lumen_ct_serialize(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n, uint8_t *out,
                        size_t cap);
+int lumen_ct_serialize_async(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n, uint8_t *out,
+                             size_t cap);
 
 /* ---- leaves of the commitment: serialize every ciphertext of a level-1 set in the current format
  * (ct.WriteTo, fhe/ligero.go:156-157) and SHA-256 it (core/tree.go:96-111).

@@ -398,7 +398,7 @@ extern "C" void lumen_host_free(void *p) {
     if (p) hipHostFree(p);
 }
 
-static bool host_is_pinned(const void *p) {
+bool lm_host_is_pinned(const void *p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
         (void)hipGetLastError(); // an ordinary malloc'd pointer is "invalid value" here
@@ -438,7 +438,7 @@ extern "C" int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, 
     LM_CHECK(ctx, (uint64_t)first + n <= set->count, "upload range [%u,%u) exceeds set of %u", first, first + n, set->count);
     const size_t ctw = lm_ctw(ctx, set), bytes = (size_t)n * ctw * sizeof(u64);
     char *dst = (char *)(set->d + (size_t)first * ctw);
-    if (bytes <= ((size_t)1 << 20) || host_is_pinned(host)) {
+    if (bytes <= ((size_t)1 << 20) || lm_host_is_pinned(host)) {
         LM_HIP(ctx, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     } else {
         if (int rc = io_buffers(ctx)) return rc;
@@ -455,20 +455,16 @@ extern "C" int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, 
     return 0;
 }
 
-extern "C" int lumen_set_download(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,
-                                  uint64_t *host) {
-    LM_CHECK(nullptr, ctx && set && host, "lumen_set_download: NULL argument");
-    LM_ENTER(ctx);
-    LM_CHECK(ctx, (uint64_t)first + n <= set->count, "download range [%u,%u) exceeds set of %u", first, first + n, set->count);
-    const size_t ctw = lm_ctw(ctx, set), bytes = (size_t)n * ctw * sizeof(u64);
-    const char *src = (const char *)(set->d + (size_t)first * ctw);
-    if (bytes <= ((size_t)1 << 20) || host_is_pinned(host)) {
+// device -> host on the context's stream.  Pageable destinations: chunk k+1 crosses the link while the CPU
+// copies chunk k out of its bounce buffer (that path always returns with `host` filled).
+int lm_d2h(lumen_ctx *ctx, void *host, const void *dev, size_t bytes, bool wait) {
+    const char *src = (const char *)dev;
+    if (bytes <= ((size_t)1 << 20) || lm_host_is_pinned(host)) {
         LM_HIP(ctx, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (wait || !lm_host_is_pinned(host)) LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return 0;
     }
     if (int rc = io_buffers(ctx)) return rc;
-    // chunk k+1 crosses the link while the CPU copies chunk k out of its bounce buffer
     const size_t nchunks = (bytes + LM_IO_CHUNK - 1) / LM_IO_CHUNK;
     auto issue = [&](size_t k) -> int {
         const size_t off = k * LM_IO_CHUNK, len = std::min(LM_IO_CHUNK, bytes - off);
@@ -486,6 +482,15 @@ extern "C" int lumen_set_download(lumen_ctx *ctx, const lumen_set *set, uint32_t
         par_memcpy((char *)host + off, ctx->io_host[k & 1], len);
     }
     return 0;
+}
+
+extern "C" int lumen_set_download(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,
+                                  uint64_t *host) {
+    LM_CHECK(nullptr, ctx && set && host, "lumen_set_download: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, (uint64_t)first + n <= set->count, "download range [%u,%u) exceeds set of %u", first, first + n, set->count);
+    const size_t ctw = lm_ctw(ctx, set), bytes = (size_t)n * ctw * sizeof(u64);
+    return lm_d2h(ctx, host, set->d + (size_t)first * ctw, bytes, true);
 }
 
 __global__ void k_fill_random(u64 *d, size_t words, uint32_t N, uint32_t nl, lm_mods mods, u64 seed) {

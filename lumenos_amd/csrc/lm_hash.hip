@@ -135,30 +135,89 @@ extern "C" size_t lumen_ct_serialized_size(lumen_ctx *ctx, uint32_t num_limbs) {
     return serialized_size(current_format(ctx, num_limbs), num_limbs, ctx->N);
 }
 
-extern "C" int lumen_ct_serialize(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n, uint8_t *out,
-                                  size_t cap) {
-    LM_CHECK(nullptr, ctx && set && (out || !n), "lumen_ct_serialize: NULL argument");
-    LM_ENTER(ctx);
-    LM_FULL_WIDTH(ctx, set, "lumen_ct_serialize");
+// ---- proof assembly (fhe/ligero.go:659-705: every ciphertext of MatR, MatZ and the queried columns
+// through ct.WriteTo): the wire image of a run of ciphertexts is assembled ON THE DEVICE -- the format's
+// byte strings interleaved with the limbs, at whatever byte alignment they impose -- and crosses PCIe as
+// one contiguous DMA.  One workgroup per (ciphertext, polynomial, limb): the N words of the limb land at
+// byte offset D of the image; for D = a mod 8, a != 0, every aligned output word is spliced from two
+// source words, and the 8 - a leading and a trailing bytes (shared words with the neighbouring header or
+// limb) are written bytewise by their one owner.  Linear reads, 8-byte coalesced writes.
+__global__ __launch_bounds__(256) void k_ct_wire(const u64 *__restrict__ set, uint32_t nl, uint32_t N,
+                                                 const leaf_fmt_t *__restrict__ fmt, uint8_t *__restrict__ wire,
+                                                 size_t each) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t l = blockIdx.x % nl, k = (blockIdx.x / nl) & 1;
+    const size_t i = blockIdx.x / (2 * nl);
+    const u32 hl = fmt->head_len, pl = fmt->poly_len, ll = fmt->limb_len;
+    const size_t limb_span = (size_t)ll + (size_t)N * 8;
+    const size_t D = i * each + hl + (size_t)(k + 1) * pl + (size_t)k * nl * limb_span + (size_t)l * limb_span + ll;
+    if (k == 0 && l == 0)
+        for (u32 t = tid; t < hl; t += 256) wire[i * each + t] = fmt->head[t];
+    if (l == 0)
+        for (u32 t = tid; t < pl; t += 256) wire[D - ll - pl + t] = fmt->poly[t];
+    for (u32 t = tid; t < ll; t += 256) wire[D - ll + t] = fmt->limb[t];
+    const u64 *src = set + ((i * 2 + k) * nl + l) * (size_t)N;
+    const u32 a = (u32)(D & 7);
+    if (a == 0) {
+        u64 *dst = reinterpret_cast<u64 *>(wire + D);
+        for (u32 m = tid; m < N; m += 256) dst[m] = src[m];
+        return;
+    }
+    const u32 lead = 8 - a;
+    if (tid < lead) wire[D + tid] = (uint8_t)(src[0] >> (8 * tid));
+    if (tid >= 64 && tid < 64 + a) wire[D + lead + (size_t)(N - 1) * 8 + (tid - 64)] = (uint8_t)(src[N - 1] >> (8 * (lead + tid - 64)));
+    u64 *dst = reinterpret_cast<u64 *>(wire + D + lead);
+    for (u32 m = tid; m + 1 < N; m += 256) dst[m] = (src[m] >> (8 * lead)) | (src[m + 1] << (8 * a));
+}
+
+// device -> host bytes on the context's stream: a page-locked destination takes the DMA directly, a
+// pageable one goes through the two bounce buffers (lm_ctx.hip).  wait: return when `host` holds the data.
+int lm_d2h(lumen_ctx *ctx, void *host, const void *dev, size_t bytes, bool wait);
+bool lm_host_is_pinned(const void *p);
+
+#define LM_WIRE_CHUNK ((size_t)512 << 20) // wire bytes assembled per kernel launch (device scratch of that size)
+static int serialize_run(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n, uint8_t *out, size_t cap,
+                         bool wait, const char *what) {
+    LM_FULL_WIDTH(ctx, set, what);
     LM_CHECK(ctx, (uint64_t)first + n <= set->count, "range [%u,%u) exceeds set of %u", first, first + n, set->count);
     const LeafFormat f = current_format(ctx, set->nl);
     const uint32_t N = ctx->N, nl = set->nl;
     const size_t each = serialized_size(f, nl, N), ctw = (size_t)2 * nl * N;
     LM_CHECK(ctx, cap >= each * n, "output buffer too small: need %zu bytes", each * n);
-    std::vector<uint64_t> host(ctw);
-    for (uint32_t i = 0; i < n; i++) {
-        if (int rc = lumen_set_download(ctx, set, first + i, 1, host.data())) return rc;
-        uint8_t *o = out + (size_t)i * each;
-        memcpy(o, f.head.data(), f.head.size()), o += f.head.size();
-        for (uint32_t k = 0; k < 2; k++) {
-            memcpy(o, f.poly.data(), f.poly.size()), o += f.poly.size();
-            for (uint32_t l = 0; l < nl; l++) {
-                memcpy(o, f.limb.data(), f.limb.size()), o += f.limb.size();
-                memcpy(o, host.data() + ((size_t)k * nl + l) * N, (size_t)N * 8), o += (size_t)N * 8; // little-endian host
-            }
+    if (!n) return 0;
+    LM_CHECK(ctx, wait || lm_host_is_pinned(out), "%s: the asynchronous form needs a page-locked buffer (lumen_host_alloc)", what);
+    const leaf_fmt_t *fmt = nullptr;
+    if (upload_format(ctx, f, "wire_fmt", &fmt)) return 1;
+    const uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, LM_WIRE_CHUNK / each));
+    uint8_t *wire = (uint8_t *)lm_scratch(ctx, "wire", (size_t)per * each + 8);
+    if (!wire) return 1;
+    for (uint32_t c0 = 0; c0 < n; c0 += per) {
+        const uint32_t cn = std::min(per, n - c0);
+        {
+            lm_prof_scope ps(ctx, "ct_wire", cn);
+            hipLaunchKernelGGL(k_ct_wire, dim3(cn * 2 * nl), dim3(256), 0, ctx->stream,
+                               set->d + (size_t)(first + c0) * ctw, nl, N, fmt, wire, each);
+            LM_HIP(ctx, hipGetLastError());
         }
+        // (the next chunk's kernel is behind this copy on the stream: one scratch buffer is enough)
+        if (int rc = lm_d2h(ctx, out + (size_t)c0 * each, wire, (size_t)cn * each, false)) return rc;
     }
+    if (wait) LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+extern "C" int lumen_ct_serialize(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n, uint8_t *out,
+                                  size_t cap) {
+    LM_CHECK(nullptr, ctx && set && (out || !n), "lumen_ct_serialize: NULL argument");
+    LM_ENTER(ctx);
+    return serialize_run(ctx, set, first, n, out, cap, true, "lumen_ct_serialize");
+}
+
+extern "C" int lumen_ct_serialize_async(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,
+                                        uint8_t *out, size_t cap) {
+    LM_CHECK(nullptr, ctx && set && (out || !n), "lumen_ct_serialize_async: NULL argument");
+    LM_ENTER(ctx);
+    return serialize_run(ctx, set, first, n, out, cap, false, "lumen_ct_serialize_async");
 }
 
 // One thread per leaf streams its ciphertext through SHA-256.  The format's byte strings have any

@@ -71,6 +71,7 @@ SYMBOLS = {
     "lumen_leaf_format_set": (C.c_int, [_vp, _u8p, C.c_uint32, _u8p, C.c_uint32, _u8p, C.c_uint32]),
     "lumen_ct_serialized_size": (C.c_size_t, [_vp, C.c_uint32]),
     "lumen_ct_serialize": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _u8p, C.c_size_t]),
+    "lumen_ct_serialize_async": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _u8p, C.c_size_t]),
     "lumen_leaf_digests": (C.c_int, [_vp, _vp, _u8p]),
     "lumen_load_public_key": (C.c_int, [_vp, _u64p]),
     "lumen_encrypt_pk": (C.c_int, [_vp, _u64p, C.c_uint32, _u8p, C.c_uint64, C.POINTER(_vp)]),
@@ -123,6 +124,11 @@ def load(build=True):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def pinned_bytes(n):
+    """uint8 array of n bytes in page-locked host memory (the proof's wire image)"""
+    return pinned_empty(((n + 7) // 8,)).view(np.uint8)[:n]
 
 
 def pinned_empty(shape):
@@ -373,6 +379,19 @@ class Context:
         out = np.zeros(max(each * n, 1), dtype=np.uint8)
         self._ck(self.lib.lumen_ct_serialize(self.h, s.h, first, n, out.ctypes.data_as(_u8p), each * n))
         return out[:each * n].tobytes()
+
+    def ct_serialized_size(self, nl):
+        return int(self.lib.lumen_ct_serialized_size(self.h, nl))
+
+    def ct_serialize_into(self, s, out, offset=0, first=0, n=None, wait=True):
+        """wire bytes of ciphertexts [first, first+n) of `s` into the uint8 array `out` at `offset`; wait=False
+        needs a page-locked array (pinned_bytes) and returns once the work is enqueued on this context's stream"""
+        n = s.count - first if n is None else n
+        size = self.ct_serialized_size(s.nl) * n
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and offset + size <= out.size
+        fn = self.lib.lumen_ct_serialize if wait else self.lib.lumen_ct_serialize_async
+        self._ck(fn(self.h, s.h, first, n, C.cast(out.ctypes.data + offset, _u8p), size))
+        return size
 
     def leaf_digests(self, s):
         out = np.zeros((s.count, 32), dtype=np.uint8)

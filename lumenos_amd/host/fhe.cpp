@@ -159,24 +159,33 @@ uint64_t RescaledScale(const Parameters &params, uint64_t scale, int fromLevel, 
 }
 
 static std::string hex_float(uint64_t v) {
-    // big.Float.Text('x', 32) of an integer below 2^64: 0x1.<32 hex digits>p+EE
+    // big.Float.Text('x', 39) of an integer below 2^64 held at 128 bits of precision
+    // ([LATTIGO-RECALL] rlwe.Scale: ScalePrecision = 128, ScalePrecisionLog10 = ceil(128 / log2(10)) = 39
+    // digits after the point): 0x1.<39 hex digits>p+EE
     if (!v) return "0x0p+00";
     int e = 63;
     while (!((v >> e) & 1)) e--;
-    const unsigned __int128 frac = ((unsigned __int128)(v ^ (1ull << e))) << (128 - e); // 128 fraction bits
-    char buf[64];
-    snprintf(buf, sizeof(buf), "0x1.%016llx%016llxp+%02d", (unsigned long long)(uint64_t)(frac >> 64),
-             (unsigned long long)(uint64_t)frac, e);
+    const uint64_t frac = e ? (v ^ (1ull << e)) << (64 - e) : 0; // the 64 fraction bits that can be non-zero
+    char buf[96];
+    snprintf(buf, sizeof(buf), "0x1.%016llx%023dp+%02d", (unsigned long long)frac, 0, e);
     return buf;
 }
 
 std::string MetaDataJSON(const MetaData &md, uint64_t plaintextModulus) {
-    char buf[512];
+    // [LATTIGO-RECALL rlwe/metadata.go, v6]: MarshalBinary = MarshalJSON of
+    //   {"PlaintextMetaData":{"Scale":{"Value":..,"Mod":..},"IsBatched":..,"IsBitReversed":..,"LogDimensions":[..,..]},
+    //    "CiphertextMetaData":{"IsNTT":..,"IsMontgomery":..}}
+    // booleans and log-dimensions as "0x%02x" strings, both numbers of Scale as hex-float text.  281 bytes here.
+    // Its LENGTH is pinned by the reference's size logs (tests/test_oracle_kat.py: 269..311 bytes under the
+    // length words of SetCiphertextFormat); rounds 1-2 recalled a 222-byte block (32 digits, decimal Mod, no
+    // IsBitReversed), which prints "134 MB" where the reference logs "Marshaled MatR: 135 MB".  The field
+    // order inside PlaintextMetaData is not pinned by anything on disk.
+    char buf[640];
     snprintf(buf, sizeof(buf),
-             "{\"PlaintextMetaData\":{\"Scale\":{\"Value\":\"%s\",\"Mod\":\"%llu\"},\"IsBatched\":\"0x%02x\","
-             "\"LogDimensions\":[\"0x%02x\",\"0x%02x\"]},\"CiphertextMetaData\":{\"IsNTT\":\"0x%02x\","
+             "{\"PlaintextMetaData\":{\"Scale\":{\"Value\":\"%s\",\"Mod\":\"%s\"},\"IsBatched\":\"0x%02x\","
+             "\"IsBitReversed\":\"0x00\",\"LogDimensions\":[\"0x%02x\",\"0x%02x\"]},\"CiphertextMetaData\":{\"IsNTT\":\"0x%02x\","
              "\"IsMontgomery\":\"0x%02x\"}}",
-             hex_float(md.Scale).c_str(), (unsigned long long)plaintextModulus, md.IsBatched ? 1 : 0,
+             hex_float(md.Scale).c_str(), hex_float(plaintextModulus).c_str(), md.IsBatched ? 1 : 0,
              (unsigned)md.LogRows, (unsigned)md.LogCols, md.IsNTT ? 1 : 0, md.IsMontgomery ? 1 : 0);
     return buf;
 }
@@ -504,6 +513,12 @@ EncryptedProof LigeroProver::Prove(core::Element point, ServerBFV &backend, core
 
     proof.Metadata = Committer->Metadata;
     proof.Root = Tree.MerkleRoot();
+    proof.PlaintextModulus = backend.GetParameters().T;
+    if (RingSwitchServer *rs = backend.RingSwitch()) { // ligero.go:336-342: RingSwitchNew on every inner-product output
+        proof.RingSwitchLogN = rs->LogN();
+        proof.MatRSwitched = rs->RingSwitchNew(matR, backend);
+        proof.MatZSwitched = rs->RingSwitchNew(matZ, backend);
+    }
     proof.MatR = std::move(matR);
     proof.MatZ = std::move(matZ);
     return proof;
@@ -578,27 +593,124 @@ Proof LigeroProveReference(const LigeroCommitter &c, const std::vector<uint64_t>
     return proof;
 }
 
-static void write_cts(std::vector<uint8_t> &buf, const Ciphertexts &c) {
-    // ct.WriteTo(buf) for every ciphertext of the slice, in the backend's current serialisation format
-    const int count = c.Len();
-    if (!count) return;
-    const size_t each = lumen_ct_serialized_size(c.Context(), (uint32_t)c.Level() + 1);
-    const size_t at = buf.size();
-    buf.resize(at + each * (size_t)count);
-    if (lumen_ct_serialize(c.Context(), c.Handle(), 0, (uint32_t)count, buf.data() + at, each * (size_t)count))
-        throw std::runtime_error(std::string("lumen_ct_serialize: ") + lumen_last_error(c.Context()));
+// ------------------------------------------------------------------ proof wire format
+WireBuffer::WireBuffer(size_t n) : n_(n) {
+    p_ = (uint8_t *)lumen_host_alloc(n ? n : 1);
+    if (!p_) throw std::runtime_error(std::string("lumen_host_alloc: ") + lumen_last_error(nullptr));
+}
+WireBuffer &WireBuffer::operator=(WireBuffer &&o) noexcept {
+    if (this != &o) {
+        if (p_) lumen_host_free(p_);
+        p_ = o.p_, n_ = o.n_;
+        o.p_ = nullptr, o.n_ = 0;
+    }
+    return *this;
+}
+WireBuffer::~WireBuffer() {
+    if (p_) lumen_host_free(p_);
+}
+
+std::string HumanizeBytes(uint64_t s) {
+    // dustin/go-humanize humanateBytes(s, 1000, ...): one decimal below 10, none above
+    char buf[64];
+    if (s < 10) {
+        snprintf(buf, sizeof(buf), "%llu B", (unsigned long long)s);
+        return buf;
+    }
+    static const char *sizes[] = {"B", "kB", "MB", "GB", "TB", "PB", "EB"};
+    const double e = std::floor(std::log((double)s) / std::log(1000.0));
+    const double val = std::floor((double)s / std::pow(1000.0, e) * 10 + 0.5) / 10;
+    snprintf(buf, sizeof(buf), val < 10 ? "%.1f %s" : "%.0f %s", val, sizes[(int)e]);
+    return buf;
+}
+
+// ct.WriteTo of a ring-switched ciphertext (level 0 of the small ring): framed on the host, 16 KB each
+static size_t small_ct_size(const MetaData &md, uint64_t T, int logn) {
+    return MetaDataJSON(md, T).size() + 8 + 2 * (8 + 8 + ((size_t)8 << logn));
+}
+static uint8_t *write_small_cts(uint8_t *o, const std::vector<uint64_t> &res, const MetaData &md, uint64_t T, int logn) {
+    const size_t n = (size_t)1 << logn, count = res.size() / (2 * n);
+    const std::string json = MetaDataJSON(md, T);
+    auto le64 = [&](uint64_t x) {
+        for (int i = 0; i < 8; i++) *o++ = (uint8_t)(x >> (8 * i));
+    };
+    for (size_t c = 0; c < count; c++) {
+        memcpy(o, json.data(), json.size()), o += json.size();
+        le64(2);
+        for (int k = 0; k < 2; k++) {
+            le64(1), le64(n);
+            memcpy(o, res.data() + (c * 2 + (size_t)k) * n, n * 8), o += n * 8; // little-endian host
+        }
+    }
+    return o;
+}
+
+static size_t slice_size(const Ciphertexts &c) {
+    return c.Len() ? lumen_ct_serialized_size(c.Context(), (uint32_t)c.Level() + 1) * (size_t)c.Len() : 0;
+}
+
+size_t EncryptedProof::MarshaledSize() const {
+    size_t n = 11;
+    if (RingSwitchLogN)
+        n += small_ct_size(MatR.Meta, PlaintextModulus, RingSwitchLogN) * (MatRSwitched.size() + MatZSwitched.size()) /
+             ((size_t)2 << RingSwitchLogN);
+    else
+        n += slice_size(MatR) + slice_size(MatZ);
+    n += slice_size(QueriedCols);
+    for (const auto &path : MerklePaths) n += path.size() * 32;
+    return n + Root.size();
+}
+
+void EncryptedProof::MarshalInto(uint8_t *out, size_t cap, bool pageLocked) const {
+    if (cap < MarshaledSize()) throw std::invalid_argument("MarshalInto: buffer too small");
+    std::vector<uint8_t> md;
+    Metadata.WriteTo(md); // ligero.go:660
+    memcpy(out, md.data(), md.size());
+    uint8_t *o = out + md.size();
+    lumen_ctx *ctx = QueriedCols.Context();
+    auto put = [&](const Ciphertexts &c) -> size_t { // ct.WriteTo(buf) for every ciphertext of the slice
+        const size_t bytes = slice_size(c);
+        if (bytes) {
+            const int rc = pageLocked ? lumen_ct_serialize_async(c.Context(), c.Handle(), 0, (uint32_t)c.Len(), o, bytes)
+                                      : lumen_ct_serialize(c.Context(), c.Handle(), 0, (uint32_t)c.Len(), o, bytes);
+            if (rc) throw std::runtime_error(std::string("lumen_ct_serialize: ") + lumen_last_error(c.Context()));
+        }
+        o += bytes;
+        return bytes;
+    };
+    size_t szR, szZ;
+    if (RingSwitchLogN) {
+        uint8_t *o0 = o;
+        o = write_small_cts(o, MatRSwitched, MatR.Meta, PlaintextModulus, RingSwitchLogN);
+        szR = (size_t)(o - o0), o0 = o;
+        o = write_small_cts(o, MatZSwitched, MatZ.Meta, PlaintextModulus, RingSwitchLogN);
+        szZ = (size_t)(o - o0);
+    } else {
+        szR = put(MatR); // ligero.go:664-671
+        szZ = put(MatZ); // ligero.go:674-681
+    }
+    const size_t szQ = put(QueriedCols); // ligero.go:684-691
+    for (const auto &path : MerklePaths)
+        for (const core::Digest &d : path) memcpy(o, d.data(), 32), o += 32; // ligero.go:694-698
+    memcpy(o, Root.data(), Root.size()), o += Root.size();                    // ligero.go:700
+    if (pageLocked && ctx && lumen_sync(ctx)) throw std::runtime_error(std::string("lumen_sync: ") + lumen_last_error(ctx));
+    if (!core::Span::quiet) {
+        printf("Marshaled MatR: %s\n", HumanizeBytes(szR).c_str());
+        printf("Marshaled MatZ: %s\n", HumanizeBytes(szZ).c_str());
+        printf("Marshaled QueriedCols: %s\n", HumanizeBytes(szQ).c_str());
+    }
 }
 
 std::vector<uint8_t> EncryptedProof::MarshalBinary() const {
-    std::vector<uint8_t> buf;
-    Metadata.WriteTo(buf);      // ligero.go:660
-    write_cts(buf, MatR);       // ligero.go:664-671
-    write_cts(buf, MatZ);       // ligero.go:674-681
-    write_cts(buf, QueriedCols); // ligero.go:684-691
-    for (const auto &path : MerklePaths)
-        for (const core::Digest &d : path) buf.insert(buf.end(), d.begin(), d.end()); // ligero.go:694-698
-    buf.insert(buf.end(), Root.begin(), Root.end());                                   // ligero.go:700
+    std::vector<uint8_t> buf(MarshaledSize());
+    MarshalInto(buf.data(), buf.size(), false);
     return buf;
+}
+
+WireBuffer EncryptedProof::MarshalBinaryPinned() const {
+    WireBuffer w(MarshaledSize());
+    MarshalInto(w.data(), w.size(), true);
+    return w;
 }
 
 } // namespace fhe

@@ -171,14 +171,46 @@ struct LigeroMetadata { // fhe/ligero.go:19-24
 
 int calculateQueries(double securityBits, int rhoInv); // ligero.go:65-71
 
+// page-locked host bytes (lumen_host_alloc): where a proof's wire image is assembled -- the device writes it
+// by DMA, and a Go []byte over the same memory feeds the HTTP response (cmd/server/main.go:154-171)
+class WireBuffer {
+  public:
+    WireBuffer() = default;
+    explicit WireBuffer(size_t n);
+    WireBuffer(WireBuffer &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr, o.n_ = 0; }
+    WireBuffer &operator=(WireBuffer &&o) noexcept;
+    WireBuffer(const WireBuffer &) = delete;
+    ~WireBuffer();
+    uint8_t *data() const { return p_; }
+    size_t size() const { return n_; }
+
+  private:
+    uint8_t *p_ = nullptr;
+    size_t n_ = 0;
+};
+
+// go-humanize Bytes(): what the reference prints for its marshaled sizes (ligero.go:672,682,692)
+std::string HumanizeBytes(uint64_t s);
+
 struct EncryptedProof { // fhe/ligero.go:185-192
     LigeroMetadata Metadata;
     Ciphertexts MatR, MatZ, QueriedCols;
+    // with a ring switch (ligero.go:336-342) MatR / MatZ are level-0 ciphertexts of the small ring instead:
+    // host residues [cols][2][2^RingSwitchLogN] (what RingSwitchNew returns), MetaData as the inputs'
+    std::vector<uint64_t> MatRSwitched, MatZSwitched;
+    int RingSwitchLogN = 0;
     std::vector<std::vector<core::Digest>> MerklePaths;
     std::vector<uint8_t> Root;
     std::vector<int> QueryIndices; // not part of the wire format; kept for tests
-    // ligero.go:646-705; every ciphertext through lumen_ct_serialize in the backend's current format
-    std::vector<uint8_t> MarshalBinary() const;
+    uint64_t PlaintextModulus = 0;
+    // ligero.go:646-705 (MarshalBinary = WriteTo into a buffer): metadata | MatR | MatZ | QueriedCols | paths |
+    // root, every ciphertext as ct.WriteTo emits it in the recalled framing (MetaDataJSON | LE64(2) | per
+    // polynomial LE64(limbs) | per limb LE64(N) | words).  The images of the three slices are assembled on the
+    // device (lumen_ct_serialize_async) and arrive by DMA.  Prints the reference's three "Marshaled ...: size" lines.
+    size_t MarshaledSize() const;
+    void MarshalInto(uint8_t *out, size_t cap, bool pageLocked) const;
+    std::vector<uint8_t> MarshalBinary() const; // pageable memory: bounce-buffered, slower
+    WireBuffer MarshalBinaryPinned() const;     // page-locked memory: the fast path
 };
 
 class LigeroCommitter;

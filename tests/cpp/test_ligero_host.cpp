@@ -1,12 +1,15 @@
 // C++ twin of TestLigeroE2E (fhe/ligero_test.go:70-176) against the host mirror in
 // lumenos_amd/host: the server side runs on the GPU through the C ABI, the client side
 // (keys, decryption) and the plain verifier arithmetic come from the CPU oracle (test infra).
-//   usage: test_ligero_host <logN> <rows> <cols> <numQ>
+//   usage: test_ligero_host <logN> <rows> <cols> <numQ> [ringSwitchLogN]
+// With ringSwitchLogN the run is the reference's "experimental" configuration (cmd/client/main.go:112-131,
+// fhe/ligero.go:336-342): MatR / MatZ leave as level-0 ciphertexts of the small ring.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "../../lumenos_amd/host/fhe.hpp"
@@ -36,6 +39,7 @@ int main(int argc, char **argv) {
     const int rows = argc > 2 ? atoi(argv[2]) : 512;
     const int cols = argc > 3 ? atoi(argv[3]) : 16;
     const int numQ = argc > 4 ? atoi(argv[4]) : 6;
+    const int ringSwitchLogN = argc > 5 ? atoi(argv[5]) : 0;
     core::Span::quiet = false;
 
     // run(): parameters, keys (ligero_test.go:36-68)
@@ -78,6 +82,21 @@ int main(int argc, char **argv) {
         const uint8_t zero32[32] = {0};
         REQUIRE(memcmp(server.EncSeedForTest(), other.EncSeedForTest(), 32) != 0, "two servers share an encryption seed");
         REQUIRE(memcmp(server.EncSeedForTest(), zero32, 32) != 0, "encryption seed left at zero");
+    }
+
+    // NewRingSwitchClient (ring_switch.go:16-57) on the client = the oracle; NewRingSwitchServer + SetRingSwitchServer
+    // (cmd/server/main.go:103-119) on the mirror, which gets the WHOLE key the client posts
+    std::vector<int64_t> skSmall;
+    std::vector<uint64_t> rsKey;
+    std::unique_ptr<fhe::RingSwitchServer> rsServer;
+    if (ringSwitchLogN) {
+        skSmall.resize((size_t)1 << ringSwitchLogN);
+        lo_keygen_secret_small(op, &rng, (uint32_t)ringSwitchLogN, skSmall.data());
+        rsKey.resize(lo_rs_key_words(op, 13));
+        REQUIRE(rsKey.size() == lo_evk_words(op), "with two special primes the ring-switch key is one Galois key's size");
+        lo_keygen_ringswitch(op, &rng, sk.data(), skSmall.data(), (uint32_t)ringSwitchLogN, 13, rsKey.data());
+        rsServer.reset(new fhe::RingSwitchServer(server, rsKey, ringSwitchLogN));
+        server.SetRingSwitchServer(rsServer.get());
     }
 
     // testLigeroE2E: witness, encryption of the batched columns by the server's own encoder/encryptor
@@ -132,14 +151,27 @@ int main(int argc, char **argv) {
     le64(f_head, 2), le64(f_poly, 2), le64(f_limb, (uint64_t)N);
     lo_ct_format fmt = {f_head.data(), f_poly.data(), f_limb.data(), (uint32_t)f_head.size(), (uint32_t)f_poly.size(),
                         (uint32_t)f_limb.size()};
+    // cmd/server/main.go:244-250: "Marshal proof" -- into page-locked memory, the three slices' wire images
+    // assembled on the device; then once more the slow way (pageable vector): same bytes
+    span = core::Span::StartSpan("Marshal proof", nullptr);
+    fhe::WireBuffer wire = proof.MarshalBinaryPinned();
+    span->End();
+    printf("Marshaled encrypted proof length: %s\n", fhe::HumanizeBytes(wire.size()).c_str());
     std::vector<uint8_t> marshaled = proof.MarshalBinary();
+    REQUIRE(marshaled.size() == wire.size() && !memcmp(marshaled.data(), wire.data(), wire.size()),
+            "MarshalBinaryPinned and MarshalBinary disagree");
     const size_t ct1 = lo_ct_serialized_size_fmt(&fmt, 2, (uint32_t)N);
     REQUIRE(ct1 == json.size() + 8 + 2 * (8 + 2 * (8 + (size_t)N * 8)), "serialised size");
+    const size_t nSmall = ringSwitchLogN ? (size_t)1 << ringSwitchLogN : 0;
+    const size_t ct0 = json.size() + 8 + 2 * (8 + 8 + nSmall * 8); // a ring-switched ciphertext: level 0, degree n
+    const size_t ctR = ringSwitchLogN ? ct0 : ct1;
     const int S = cols * rhoInv;
     int depth = 0;
     while ((1 << depth) < S) depth++;
-    REQUIRE(marshaled.size() == 11 + (size_t)(2 * cols + 309) * ct1 + (size_t)309 * depth * 32 + 32,
+    REQUIRE(marshaled.size() == 11 + (size_t)2 * cols * ctR + (size_t)309 * ct1 + (size_t)309 * depth * 32 + 32,
             "marshaled size %zu", marshaled.size());
+    REQUIRE(marshaled[0] == (uint8_t)rows && marshaled[4] == (uint8_t)cols && marshaled[8] == rhoInv &&
+                marshaled[9] == (309 & 0xFF) && marshaled[10] == (309 >> 8), "LigeroMetadata.WriteTo bytes (ligero.go:755-761)");
 
     // ---- client: decrypt (EncryptedProof.Decrypt, ligero.go:381-502) with the oracle
     auto decrypt = [&](const std::vector<uint64_t> &host, int idx, int nvals) {
@@ -148,6 +180,37 @@ int main(int argc, char **argv) {
         return v;
     };
     std::vector<uint64_t> hR = proof.MatR.Download(), hZ = proof.MatZ.Download(), hQ = proof.QueriedCols.Download();
+    {
+        // every ciphertext of the wire image against the checker's serialiser (ligero.go:664-691)
+        std::vector<uint8_t> one(ct1);
+        if (!ringSwitchLogN)
+            for (int w = 0; w < 2; w++)
+                for (int j = 0; j < cols; j++) {
+                    lo_ct_serialize_fmt((w ? hZ : hR).data() + (size_t)j * 4 * N, 2, (uint32_t)N, &fmt, one.data());
+                    REQUIRE(!memcmp(one.data(), marshaled.data() + 11 + ((size_t)w * cols + j) * ct1, ct1),
+                            "marshaled bytes of Mat%c[%d] differ from the checker's serialisation", w ? 'Z' : 'R', j);
+                }
+        else {
+            // RingSwitchNew of every MatR / MatZ ciphertext against the oracle, and their framing
+            std::vector<uint8_t> f0_poly, f0_limb;
+            le64(f0_poly, 1), le64(f0_limb, (uint64_t)nSmall);
+            lo_ct_format fmt0 = {f_head.data(), f0_poly.data(), f0_limb.data(), (uint32_t)f_head.size(), 8, 8};
+            REQUIRE(lo_ct_serialized_size_fmt(&fmt0, 1, (uint32_t)nSmall) == ct0, "small ciphertext size");
+            std::vector<uint64_t> want(2 * nSmall);
+            std::vector<uint8_t> one0(ct0);
+            REQUIRE(proof.MatRSwitched.size() == (size_t)cols * 2 * nSmall && proof.MatZSwitched.size() == proof.MatRSwitched.size(),
+                    "ring-switched slices have the wrong size");
+            for (int w = 0; w < 2; w++)
+                for (int j = 0; j < cols; j++) {
+                    lo_ring_switch(op, (w ? hZ : hR).data() + (size_t)j * 4 * N, 2, rsKey.data(), 13, (uint32_t)ringSwitchLogN, want.data());
+                    const uint64_t *got = (w ? proof.MatZSwitched : proof.MatRSwitched).data() + (size_t)j * 2 * nSmall;
+                    REQUIRE(!memcmp(got, want.data(), want.size() * 8), "RingSwitchNew(Mat%c[%d]) differs from the oracle", w ? 'Z' : 'R', j);
+                    lo_ct_serialize_fmt(want.data(), 1, (uint32_t)nSmall, &fmt0, one0.data());
+                    REQUIRE(!memcmp(one0.data(), marshaled.data() + 11 + ((size_t)w * cols + j) * ct0, ct0),
+                            "marshaled bytes of the ring-switched Mat%c[%d] differ", w ? 'Z' : 'R', j);
+                }
+        }
+    }
     std::vector<uint64_t> MatR(cols), MatZ(cols); // slot 0 of every column (decodeSingleElement, ligero.go:428-434)
     REQUIRE(!lo_decrypt_decode_batch(op, sk.data(), hR.data(), cols, 2, scale, MatR.data(), 1), "decrypt MatR");
     REQUIRE(!lo_decrypt_decode_batch(op, sk.data(), hZ.data(), cols, 2, scale, MatZ.data(), 1), "decrypt MatZ");
@@ -195,7 +258,7 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> leaf(ct1);
     for (size_t qi = 0; qi < qidx.size(); qi++) {
         lo_ct_serialize_fmt(hQ.data() + qi * 4 * N, 2, (uint32_t)N, &fmt, leaf.data());
-        REQUIRE(!memcmp(leaf.data(), marshaled.data() + 11 + ((size_t)2 * cols + qi) * ct1, ct1),
+        REQUIRE(!memcmp(leaf.data(), marshaled.data() + 11 + (size_t)2 * cols * ctR + qi * ct1, ct1),
                 "marshaled bytes of queried column %zu differ from the checker's serialisation", qi);
         core::Digest d = core::Sha256(leaf.data(), leaf.size());
         REQUIRE(core::VerifyMerklePath(d, proof.MerklePaths[qi], proof.Root, (unsigned)qidx[qi]),

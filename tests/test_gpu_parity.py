@@ -154,6 +154,21 @@ def test_leaf_format_any_byte_alignment(oracle, small, lens):
             blob = ctx.ct_serialize(s, 3, 2)
             want = [P.ct_serialize(cts[c], (head, poly, limb)) for c in range(67)]
             assert blob == want[3] + want[4]
+            # the wire image of the whole slice -- what EncryptedProof.WriteTo emits for MatR (ligero.go:664-671) --
+            # is assembled on the device: every ciphertext starts where the previous one ends, at any alignment
+            assert ctx.ct_serialize(s) == b"".join(want)
+            # ... and the asynchronous form into page-locked memory at an odd offset, on a clone's stream
+            from lumenos_amd.hip import pinned_bytes
+            each = ctx.ct_serialized_size(nl)
+            assert each == len(want[0])
+            buf = pinned_bytes(11 + 67 * each)
+            buf[:] = 0xEE
+            twin = ctx.clone()
+            ctx.sync()
+            twin.ct_serialize_into(s, buf, offset=11, wait=False)
+            twin.sync()
+            assert buf[:11].tobytes() == b"\xee" * 11 and buf[11:].tobytes() == b"".join(want)
+            twin.close()
             assert len(want[0]) == sum(lens[:1]) + 2 * (lens[1] + nl * (lens[2] + 8 * P.N))
             for c in range(67):
                 assert dig[c].tobytes() == oracle.sha256(want[c]), (nl, c)

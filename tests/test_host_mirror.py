@@ -45,16 +45,65 @@ def test_host_transcript_and_field_match_oracle(oracle):
     assert lib is not None
 
 
+def test_metadata_block_and_humanize_fit_the_reference_size_logs():
+    """The bytes the mirror frames every proof ciphertext with (MetaDataJSON + the length words of
+    SetCiphertextFormat) against what the reference's 24 size lines allow (tests/test_oracle_kat.py:
+    a MetaData block of 269..311 bytes), for the scales the path produces; and go-humanize's rounding
+    (half-to-even on the one decimal it keeps) at the values that decide "134 MB" against "135 MB"."""
+    from lumenos_amd import _build
+    host = _build.build_host()
+    src = os.path.join(ROOT, "tests", "cpp", "metadata_len.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "metadata_len")
+    hd, cd = os.path.dirname(host), os.path.dirname(_build.LIB)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", exe, "-L" + hd, "-llumenos_host", "-L" + cd,
+                           "-llumenos_hip", f"-Wl,-rpath,{hd}:{cd}"])
+    for scale, log_cols in ((1, 11), (144115188075593728, 13), (3, 12)):
+        out = subprocess.check_output([exe, str(scale), str(log_cols), "134550528", "134500000", "4456000000", "9",
+                                       "68540000", "999"]).decode().split("\n")
+        assert 269 <= int(out[0]) <= 311, out[0]
+        assert int(out[0]) == len(out[1]) == 281
+        assert out[1].startswith('{"PlaintextMetaData":{"Scale":{"Value":"0x1.') and out[1].endswith('"IsMontgomery":"0x00"}}')
+        assert out[2:8] == ["135 MB", "134 MB", "4.5 GB", "9 B", "68 MB", "999 B"]
+
+
+# reference span names (fhe/ligero.go:97,105,224-225,262 -- the four that define the metric; cmd/server/main.go
+# for the outer ones) and the marshaled sizes the reference logs for the shape
+# (results/{baseline,experimental}/server/bench_*.txt:31-37)
+SPANS = ["Encode (", "Merkle tree built (", "InnerProduct(Matrix, r) (", "InnerProduct(Matrix, b) (", "Query columns (",
+         "Commit FHE evaluation (", "Prove FHE evaluation (", "Marshal proof ("]
+SHAPES = [
+    # logN, rows, cols, L, ringSwitchLogN, (MatR, MatZ, QueriedCols, proof) or None for the build's own small shapes
+    ((10, 512, 16, 6, 0), None),
+    ((11, 2048, 64, 8, 0), None),
+    ((11, 2048, 64, 8, 10), None),
+    ((12, 2048, 1024, 10, 0), ("135 MB", "135 MB", "41 MB", "310 MB")),
+    ((12, 2048, 1024, 10, 10), ("17 MB", "17 MB", "41 MB", "75 MB")),
+    ((12, 4096, 2048, 11, 0), ("269 MB", "269 MB", "41 MB", "579 MB")),
+    ((12, 4096, 2048, 11, 10), ("34 MB", "34 MB", "41 MB", "109 MB")),
+    ((13, 8192, 4096, 12, 0), ("1.1 GB", "1.1 GB", "81 MB", "2.2 GB")),
+]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(10, 512, 16, 6), (11, 2048, 64, 8), (12, 2048, 1024, 10), (12, 4096, 2048, 11),
-                                   (13, 8192, 4096, 12)])
-def test_ligero_e2e_host_mirror(shape):
-    """TestLigeroE2E twin: Commit + Prove through the C++ mirror on the GPU, decrypt + Verify with the
-    oracle.  The two small shapes take more limbs than the heuristic gives (a 16- or 64-column Encode is
-    as deep in scalar multiplications per limb as the heuristic assumes only from 1024 columns up); the
-    last three are the reference's own test shape (2048x1024, LogN=12: TestLigeroE2E / TestLigeroPPD,
-    BASELINE config 1) and BASELINE configs B and 3 (4096x2048, 8192x4096 with rows = N) on exactly the
-    chain fhe.GenerateBGVParamsForNTT derives: L = 10 / 11 / 12."""
-    res = subprocess.run([build_binary()] + [str(x) for x in shape], capture_output=True, text=True, timeout=1500)
+@pytest.mark.parametrize("shape,sizes", SHAPES)
+def test_ligero_e2e_host_mirror(shape, sizes):
+    """TestLigeroE2E twin: Commit + Prove + MarshalBinary through the C++ mirror on the GPU, decrypt + Verify
+    with the oracle.  The two small shapes take more limbs than the heuristic gives (a 16- or 64-column Encode
+    is as deep in scalar multiplications per limb as the heuristic assumes only from 1024 columns up); the
+    others are the reference's own test shape (2048x1024, LogN=12: TestLigeroE2E / TestLigeroPPD, BASELINE
+    config 1) and BASELINE configs B and 3 (4096x2048, 8192x4096 with rows = N) on exactly the chain
+    fhe.GenerateBGVParamsForNTT derives: L = 10 / 11 / 12 -- each must print the reference's span names and
+    the marshaled sizes the reference logged for that shape, which holds the serialisation framing
+    (MetaData block + length words) to the published proofs; with a ring-switch degree the run is the
+    "experimental" configuration (MatR / MatZ ring-switched to LogN = 10) against ITS logged sizes."""
+    args = [str(x) for x in shape[:4]] + ([str(shape[4])] if shape[4] else [])
+    res = subprocess.run([build_binary()] + args, capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "PASS TestLigeroE2E" in res.stdout
+    for name in SPANS:
+        assert name in res.stdout, name
+    assert "Number of queried columns: 309" in res.stdout
+    if sizes:
+        for label, want in zip(("Marshaled MatR", "Marshaled MatZ", "Marshaled QueriedCols",
+                                "Marshaled encrypted proof length"), sizes):
+            assert f"{label}: {want}" in res.stdout, (label, want, [l for l in res.stdout.splitlines() if "Marshaled" in l])

@@ -8,19 +8,29 @@ BASELINE.json's metric is quoted on: 16384 x 4096, LogN = 14 (12 Q limbs, 2 P
 limbs, rhoInv = 2, 309 queries).  It fits one GPU (about 75 GB of the 288 GB).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (strong scaling, fixed job; N a power of two): rank r holds ONLY its block of cols/N
-input columns.  Encode is lane-sharded (the ciphertext-axis transform never mixes
+works as typed for any N: for N > 1 this process never touches the GPU -- it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`
+as a child, relays rank 0's JSON line and exits with the child's code.  Launched under
+torch.distributed.run directly (RANK / WORLD_SIZE set) it is one rank of that job.
+
+N > 1 (strong scaling, fixed job; N a power of two with N/world >= 64 lanes): rank r holds ONLY its block of
+cols/N input columns.  Encode is lane-sharded (the ciphertext-axis transform never mixes
 lanes): an all-to-all over xGMI turns the ranks' column blocks into lane shards of all
 columns, every rank encodes its 1/N of the lanes, a second all-to-all hands every rank whole
 ciphertexts of its block of encoded columns.  Everything else is per column (rescale + leaf
 hashing; ct x pt + InnerSum + rescale on the rank's input columns; query gather).  The leaf
 digests are all-gathered on device buffers (RCCL) and the Merkle root is built on the device.
-Nothing is replicated.  (Other N: the round-1 path -- every rank holds the matrix and runs the
-mixing passes itself.)
+Nothing is replicated.  Worlds the lane path cannot serve are REFUSED unless --allow-replicated asks for
+the round-1 path (every rank holds the matrix and runs the mixing passes itself); config.parallelism names
+the path that ran.
 
-Rank 0 prints ONE JSON line (see the keys at the bottom of main()).
+Rank 0 prints ONE JSON line (see the keys at the bottom of main()).  At N = 1 the default run also carries
+  * marshal_s / io_inclusive_s: the proof as wire-format bytes in page-locked host memory
+    (EncryptedProof.WriteTo, fhe/ligero.go:659-705) and a step that starts with the input ciphertexts in
+    host memory and ends there (never `value`);
+  * other_configs: short passes over the other BASELINE.json configurations (2048x1024, 4096x2048,
+    8192x4096, and 16384x4096 with the ring switch to LogN = 10), so that the driver's one command attests them.
 """
 import argparse
 import json
@@ -119,7 +129,7 @@ NTT_KERNELS = ("ks_modup_ntt", "ks_moddown_ntt", "rescale_limb_ntt", "rescale_la
 class Job:
     """Device-resident inputs of one prover run + the step function."""
 
-    def __init__(self, cfg, rank, world, device, ring_switch_logn=0):
+    def __init__(self, cfg, rank, world, device, ring_switch_logn=0, allow_replicated=False):
         from lumenos_amd.hip import Context
         self.rows, self.cols, self.log_n = CONFIGS[cfg]
         self.rank, self.world = rank, world
@@ -134,6 +144,10 @@ class Job:
         # lane-sharded Encode needs a power-of-two world whose lane shards keep at least one tile
         self.lane_path = world > 1 and (world & (world - 1)) == 0 and self.cols % world == 0 and (self.N // world) >= 64
         self.logw = world.bit_length() - 1 if self.lane_path else 0
+        if world > 1 and not self.lane_path and not allow_replicated:
+            raise SystemExit(f"bench.py: {world} ranks cannot run the lane-sharded path for {cfg} (needs a power-of-two "
+                             f"world dividing cols = {self.cols} with N/world >= 64 lanes); --allow-replicated runs the "
+                             "round-1 path instead (every rank holds the whole input and repeats the mixing passes)")
         # synthetic inputs: uniform residues (kernels are data-independent); with the lane path a
         # rank only ever holds its own block of columns
         own = self.cols // world if self.lane_path else self.cols
@@ -154,13 +168,10 @@ class Job:
                 rand_limbs(P.q + P.p, (beta, 2, self.N)).transpose(1, 2, 0, 3))  # [beta][2][L+K][N]
             ctx.load_galois_key(g, evk)
         self.query_idx = rng.integers(0, self.S, size=self.queries).astype(np.uint32)
-        self.ring_switch_logn = ring_switch_logn
+        self.ring_switch_logn = 0
+        self._rand_limbs = rand_limbs
         if ring_switch_logn:
-            # the whole evaluation key a client posts (cmd/client/main.go:124-131): [rns][pw2][2][L+K][N]; with
-            # two special primes that is one Galois key's size (no power-of-two digits)
-            rns, pw2 = ctx.ringswitch_key_shape(13)[:2]
-            key = np.ascontiguousarray(rand_limbs(P.q + P.p, (rns, pw2, 2, self.N)).transpose(1, 2, 3, 0, 4))
-            ctx.load_ringswitch_key(ring_switch_logn, key)
+            self.enable_ring_switch(ring_switch_logn)
         # column shards (input columns; encoded columns are sharded by the transform itself)
         self.col_lo, self.col_hi = self.cols * rank // world, self.cols * (rank + 1) // world
         if self.lane_path:  # self.matrix IS the rank's block; its slice of the one Enc(0) for the lane Encode
@@ -168,25 +179,79 @@ class Job:
             self.zero_lanes = np.ascontiguousarray(self.zero_ct[:, :, rank * nw:(rank + 1) * nw])
         ctx.sync()
 
-    # ---- host I/O of a prover run, measured by --include-io
+    def enable_ring_switch(self, logn):
+        """BASELINE config 5: RingSwitchNew on MatR / MatZ (ligero.go:336-342).  The key is the whole evaluation
+        key a client posts (cmd/client/main.go:124-131), [rns][pw2][2][L+K][N]; with two special primes that is
+        one Galois key's size (no power-of-two digits)."""
+        P = self.P
+        rns, pw2 = self.ctx.ringswitch_key_shape(13)[:2]
+        key = np.ascontiguousarray(self._rand_limbs(P.q + P.p, (rns, pw2, 2, self.N)).transpose(1, 2, 3, 0, 4))
+        self.ctx.load_ringswitch_key(logn, key)
+        self.ring_switch_logn = logn
+
+    def close(self):
+        for a in ("io_ctx",):
+            c = getattr(self, a, None)
+            if c is not None:
+                c.close()
+        self.matrix.free()
+        self.ctx.close()
+
+    # ---- host I/O of a prover run (SURVEY K11): the io leg of the default run
     def io_setup(self):
-        """Pinned host buffers (lumen_host_alloc): the input ciphertexts as the Go shim's stage() lays
-        them out, and room for the proof's ciphertexts; a clone context whose stream carries downloads
-        while the main context computes."""
-        from lumenos_amd.hip import pinned_empty
+        """Page-locked host buffers (lumen_host_alloc): the input ciphertexts as the Go shim's stage() lays them
+        out, and the proof's wire image -- metadata | MatR | MatZ | QueriedCols | paths | root
+        (EncryptedProof.WriteTo, fhe/ligero.go:659-705) -- which the device assembles and DMAs into place; a clone
+        context whose stream carries that while the main context computes."""
+        from lumenos_amd.hip import pinned_bytes, pinned_empty
         self.h_matrix = pinned_empty((self.cols, 2, self.L, self.N))
         self.matrix.download_into(self.h_matrix)  # content: the synthetic matrix itself
-        self.h_r = pinned_empty((self.col_hi - self.col_lo, 2, 2, self.N))
-        self.h_z = pinned_empty((self.col_hi - self.col_lo, 2, 2, self.N))
-        self.h_q = pinned_empty((self.queries, 2, 2, self.N))
+        # the reference's framing as the C++ mirror restates it: a 281-byte MetaData block + LE64 length words
+        head = bytes(281) + (2).to_bytes(8, "little")
+        self.ctx.leaf_format_set(head, (2).to_bytes(8, "little"), self.N.to_bytes(8, "little"))
+        self.ct1 = self.ctx.ct_serialized_size(2)
+        depth = (self.S - 1).bit_length()
+        self.wire_len = 11 + (2 * self.cols + self.queries) * self.ct1 + self.queries * depth * 32 + 32
+        self.wire = pinned_bytes(self.wire_len)
         self.io_ctx = self.ctx.clone()
 
-    def step_io(self):
-        """One step including the PCIe legs a drop-in pays: upload of the input ciphertexts (12.9 GB at D),
-        download of MatR / MatZ / the queried columns (4.4 GB at D).  MatR crosses the link on the clone's
-        stream while MatZ is computed; the upload cannot overlap (Encode needs every column)."""
-        import threading
+    def _marshal_tail(self, off, nodes, root):
+        """Merkle paths + root behind the ciphertexts (ligero.go:694-700): host bytes, 309 x depth x 32"""
+        depth = (self.S - 1).bit_length()
+        lvl_off, n, paths = 0, self.S, np.empty((self.queries, depth, 32), dtype=np.uint8)
+        idx = self.query_idx.astype(np.int64).copy()
+        for d in range(depth):
+            sib = np.minimum(idx ^ 1, n - 1)  # an unpaired last node is its own sibling (core/tree.go:127-131)
+            paths[:, d] = nodes[lvl_off + sib]
+            lvl_off, n, idx = lvl_off + n, (n + 1) // 2, idx >> 1
+        self.wire[off:off + paths.size] = paths.reshape(-1)
+        self.wire[off + paths.size:off + paths.size + 32] = np.frombuffer(root, dtype=np.uint8)
+        return off + paths.size + 32
+
+    def marshal(self, mat_r, mat_z, q, nodes, root):
+        """EncryptedProof.MarshalBinary of results that sit in HBM: the three slices' wire images assembled on the
+        device, one DMA each into the page-locked image; returns seconds (the reference's "Marshal proof" span,
+        cmd/server/main.go:244-250: 2.3 s at 16384 x 4096)."""
         ctx = self.ctx
+        ctx.sync()
+        t0 = time.perf_counter()
+        self.wire[:11] = np.frombuffer(np.array([self.rows, self.cols], "<u4").tobytes() + bytes([RHO_INV])
+                                       + np.array([self.queries], "<u2").tobytes(), dtype=np.uint8)
+        off = 11
+        for s_ in (mat_r, mat_z, q):
+            off += ctx.ct_serialize_into(s_, self.wire, offset=off, wait=False)
+        off = self._marshal_tail(off, nodes, root)
+        ctx.sync()
+        assert off == self.wire_len
+        return time.perf_counter() - t0
+
+    def step_io(self, slices=8):
+        """One step that starts with the input ciphertexts in (page-locked) host memory and ends with the proof's
+        wire-format bytes there: upload (12.9 GB at D: one DMA, not overlappable in the fhe API's order -- Encode
+        needs every column), the step, and the marshalling overlapped with it: MatR and MatZ are computed in
+        column slices, each slice's wire image is assembled and DMA'd by the clone context behind the kernels
+        that produce it (lumen_ctx_wait: no host block) while the main context goes on."""
+        ctx, io = self.ctx, self.io_ctx
         t = {}
         t0 = time.perf_counter()
         self.matrix.upload(self.h_matrix)
@@ -195,25 +260,31 @@ class Job:
         lvl1 = ctx.rescale(mine, 2)
         mine.free()
         ctx.leaf_digests_begin(lvl1)
-        cols = self.matrix.slice(self.col_lo, self.col_hi - self.col_lo)
-        mat_r = ctx.matrix_inner_sum(cols, self.r_pt, self.rows)
-        ctx.sync()
-        th = threading.Thread(target=lambda: self.io_ctx.download_into(mat_r, self.h_r))
-        th.start()
-        mat_z = ctx.matrix_inner_sum(cols, self.b_pt, self.rows)
-        cols.free()
+        self.wire[:11] = np.frombuffer(np.array([self.rows, self.cols], "<u4").tobytes() + bytes([RHO_INV])
+                                       + np.array([self.queries], "<u2").tobytes(), dtype=np.uint8)
+        keep, off = [], 11
+        per = (self.cols + slices - 1) // slices
+        for pt in (self.r_pt, self.b_pt):
+            for c0 in range(0, self.cols, per):
+                cols = self.matrix.slice(c0, min(per, self.cols - c0))
+                part = ctx.matrix_inner_sum(cols, pt, self.rows)
+                io.wait_for(ctx)
+                off += io.ct_serialize_into(part, self.wire, offset=off, wait=False)
+                keep += [cols, part]
         q = ctx.gather(lvl1, self.query_idx)
         dig = ctx.leaf_digests_end()
         nodes, root = ctx.merkle_build(dig)
         ctx.sync()
         t1 = time.perf_counter()
-        mat_z.download_into(self.h_z)
-        q.download_into(self.h_q)
-        th.join()
-        t["download_tail_s"] = time.perf_counter() - t1
+        off += ctx.ct_serialize_into(q, self.wire, offset=off, wait=False)
+        off = self._marshal_tail(off, nodes, root)
+        ctx.sync()
+        io.sync()
+        assert off == self.wire_len
+        t["marshal_tail_s"] = time.perf_counter() - t1
         t["total_s"] = time.perf_counter() - t0
-        for s in (q, mat_r, mat_z, lvl1):
-            s.free()
+        for s_ in keep[::-1] + [q, lvl1]:
+            s_.free()
         return t
 
     def step_lanes(self, dist):
@@ -252,7 +323,7 @@ class Job:
             s.free()
         return root
 
-    def step(self, dist=None):
+    def step(self, dist=None, keep=False):
         if self.lane_path and dist is not None:
             return self.step_lanes(dist)
         ctx = self.ctx
@@ -284,6 +355,9 @@ class Job:
             dig = all_gather_digests(dist, dig, my_cols, self.S, self.world)
         nodes, root = ctx.merkle_build(dig)
         ctx.sync()
+        if keep:
+            lvl1.free()
+            return mat_r, mat_z, q, nodes, root
         for s in (q, mat_r, mat_z, lvl1):
             s.free()
         return root
@@ -433,6 +507,38 @@ def cpu_baseline(cfg, budget_s=20.0):
     }
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` for N > 1: this process never initialises the GPU (no torch.cuda, no HIP) --
+    it starts one rank per GPU under torch.distributed.run as a CHILD process (never an exec), relays the
+    child's output (rank 0's JSON line) and returns its exit code (torch.distributed.run exits non-zero when
+    any rank fails)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:  # rank 0's JSON line goes to stdout; whatever a library chats there (gloo) to stderr
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
+    return proc.wait()
+
+
+def timed_steps(job, dist, steps, warmup, barrier):
+    for _ in range(warmup):
+        job.step(dist)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step(dist)
+    barrier()
+    return (time.perf_counter() - t0) / steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -444,19 +550,27 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal only)")
-    ap.add_argument("--include-io", action="store_true",
-                    help="also time steps that upload the input ciphertexts from and download the proof's "
-                         "ciphertexts to pinned host memory (reported as io_inclusive_s; never `value`)")
+    ap.add_argument("--allow-replicated", action="store_true",
+                    help="N>1 worlds the lane-sharded path cannot serve: run the round-1 replicated-input path "
+                         "instead of refusing (named in config.parallelism)")
+    ap.add_argument("--include-io", action="store_true", help="kept for old command lines: the io leg is on by default")
+    ap.add_argument("--no-io", action="store_true",
+                    help="skip marshal_s / io_inclusive_s (upload of the inputs from and the proof's wire bytes into "
+                         "page-locked host memory; reported beside `value`, never as `value`)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short passes over the other BASELINE.json configurations")
+    ap.add_argument("--other-steps", type=int, default=3)
     ap.add_argument("--ring-switch-logn", type=int, default=0,
                     help="BASELINE config 5: ring-switch MatR/MatZ to this ring degree (fhe/ring_switch.go)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the lumenos HIP path has no CPU fallback")
@@ -469,7 +583,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.dist_backend)  # "nccl" is RCCL on ROCm
 
-    job = Job(args.config, rank, world, local_rank, args.ring_switch_logn)
+    job = Job(args.config, rank, world, local_rank, args.ring_switch_logn, args.allow_replicated)
 
     def barrier():
         if dist is not None:
@@ -531,18 +645,51 @@ def main():
                         "note": "VALU-bound integer kernel: the >= 50 % HBM target of north_star is not reachable at "
                                 "10 multiply-adds per 64-bit Shoup product; see DESIGN.md section 6"}
     io = None
-    if args.include_io and world == 1:
+    if world == 1 and not args.no_io:
         job.io_setup()
-        job.step_io()  # warm-up: first touch of the bounce paths
-        runs = [job.step_io() for _ in range(max(1, args.steps))]
+        outs = job.step(keep=True)
+        job.marshal(*outs)  # first touch of the wire image and the staging paths
+        marshal_s = min(job.marshal(*outs) for _ in range(3))
+        for s_ in outs[:3]:
+            s_.free()
+        job.step_io()  # warm-up
+        runs = [job.step_io() for _ in range(2)]
         best = min(runs, key=lambda r: r["total_s"])
         gb_in = job.cols * 2 * job.L * job.N * 8 / 1e9
-        gb_out = (2 * (job.col_hi - job.col_lo) + job.queries) * 4 * job.N * 8 / 1e9
-        io = {"io_inclusive_s": round(best["total_s"], 4), "upload_s": round(best["upload_s"], 4),
-              "download_tail_s": round(best["download_tail_s"], 4), "upload_GB": round(gb_in, 2),
-              "download_GB": round(gb_out, 2), "upload_GBps": round(gb_in / best["upload_s"], 1),
-              "staging": "pinned host buffers (lumen_host_alloc); MatR downloads on a clone context's stream "
-                         "under the MatZ inner product; input upload not overlapped (Encode needs all columns)"}
+        io = {"marshal_s": round(marshal_s, 4), "io_inclusive_s": round(best["total_s"], 4),
+              "io": {"upload_s": round(best["upload_s"], 4), "marshal_tail_s": round(best["marshal_tail_s"], 4),
+                     "upload_GB": round(gb_in, 2), "upload_GBps": round(gb_in / best["upload_s"], 1),
+                     "proof_wire_GB": round(job.wire_len / 1e9, 3),
+                     "marshal_GBps": round(job.wire_len / 1e9 / marshal_s, 1),
+                     "reference_marshal_s": {"16384x4096": 2.254, "8192x4096": 1.135, "4096x2048": 0.347,
+                                             "2048x1024": 0.156}.get(args.config),  # results/baseline/server/bench_*.txt:34
+                     "note": "marshal_s: EncryptedProof.MarshalBinary of results resident in HBM -- wire images of MatR, "
+                             "MatZ and the queried columns assembled on the device (k_ct_wire), one DMA each into "
+                             "page-locked memory, Merkle paths + root appended (the reference's 'Marshal proof' span). "
+                             "io_inclusive_s: input ciphertexts from page-locked host memory (one DMA, not overlappable "
+                             "in the fhe API's order: Encode needs every column), the step, and the same marshalling "
+                             "overlapped with it on a clone context (column slices, lumen_ctx_wait); ends with the "
+                             "proof's wire bytes in host memory"}}
+    others = None
+    if world == 1 and not args.no_other_configs and not args.ring_switch_logn:
+        others = {}
+        if args.config == "16384x4096":  # BASELINE config 5 on the resident job: + RingSwitchNew -> LogN = 10
+            job.enable_ring_switch(10)
+            sec = timed_steps(job, None, args.other_steps, 1, barrier)
+            others["16384x4096+ring-switch->LogN=10"] = {
+                "value": round(sec, 4), "unit": "s", "steps": args.other_steps,
+                "reference_s": 417.6, "ring_switch_added_s": round(sec - sec_per_step, 4)}
+            job.ring_switch_logn = 0
+        main_ctx = job.ctx
+        for cfg in ("2048x1024", "4096x2048", "8192x4096"):
+            if cfg == args.config:
+                continue
+            oj = Job(cfg, 0, 1, local_rank)
+            sec = timed_steps(oj, None, args.other_steps, 1, lambda: oj.ctx.sync())
+            others[cfg] = {"value": round(sec, 4), "unit": "s", "steps": args.other_steps,
+                           "reference_s": PUBLISHED_SECONDS[cfg], "L": oj.L, "LogN": oj.log_n}
+            oj.close()
+        assert job.ctx is main_ctx
     if rank == 0:
         census = limb_ntt_census(job.rows, job.cols, job.L, job.K, job.log_n)
         out = {
@@ -561,9 +708,14 @@ def main():
             "config": {"workload": f"Encode+Commit+InnerProduct(r,b)+QueryCols {args.config} LogN={job.log_n} "
                                    f"L={job.L} K={job.K} rhoInv={RHO_INV} queries={job.queries}"
                                    + (f" +ring-switch->LogN={args.ring_switch_logn}" if args.ring_switch_logn else ""),
-                       "parallelism": (f"{world} GPUs: lane-sharded Encode between two xGMI all-to-alls, columns sharded "
-                                       "elsewhere, digest all-gather + Merkle root on device buffers"
-                                       if job.lane_path else f"columns sharded over {world} GPU(s); digest all-gather"),
+                       "parallelism": ("1 GPU: the whole job resident in HBM" if world == 1 else
+                                       f"lane path: {world} GPUs, lane-sharded Encode between two xGMI all-to-alls, columns "
+                                       "sharded elsewhere, digest all-gather + Merkle root on device buffers"
+                                       if job.lane_path else
+                                       f"REPLICATED path (--allow-replicated): every one of the {world} ranks holds the whole "
+                                       "input and repeats the mixing passes of Encode; columns sharded elsewhere; digest "
+                                       "all-gather through the host"),
+                       "lane_path": bool(job.lane_path),
                        "baseline_ref": "BASELINE.md: reference Go/Lattigo CPU, m7i.8xlarge 32 vCPU"},
             # limb transforms the device EXECUTES per step (sum of the NTT kernels' units: the rescale to level 1
             # runs on coefficients, 14 transforms per polynomial instead of the reference's 75) ...
@@ -576,6 +728,8 @@ def main():
         }
         if io:
             out.update(io)
+        if others:
+            out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out))

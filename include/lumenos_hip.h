@@ -68,6 +68,15 @@ void lumen_ctx_destroy(lumen_ctx *ctx);
  * a context on the same device that shares src's tables and keys and owns its streams and scratch.
  * Destroy clones and source in any order; the shared tables go with the last one. */
 int lumen_ctx_clone(lumen_ctx *src, lumen_ctx **out);
+/* ctx's stream waits -- on the device, the host does not block -- for everything enqueued so far on `other`
+ * (same device): the hand-over between a producer context and the clone that serialises / downloads its
+ * results while the producer goes on (the reference's R and Z goroutines, fhe/ligero.go:231-242). */
+int lumen_ctx_wait(lumen_ctx *ctx, lumen_ctx *other);
+/* The library's tuning switches (A/B tools; every default is the measured best; DESIGN.md "Run-time
+ * switches") are read from the environment ONCE, by lumen_ctx_create; clones inherit them.  This setter is
+ * the in-process form for tests and tools: name = "LUMEN_KS_BATCH", "LUMEN_KS_LANES",
+ * "LUMEN_KS_FUSED_DIGITS" (value < 0: derived default), "LUMEN_CT_BLOCKS", "LUMEN_DEBUG". */
+int lumen_ctx_set_tuning(lumen_ctx *ctx, const char *name, long value);
 const char *lumen_last_error(const lumen_ctx *ctx); /* ctx may be NULL */
 int lumen_sync(lumen_ctx *ctx);
 /* number of ct x scalar multiplications issued: ServerBFV.MulCounter (bfv.go:44-46) */

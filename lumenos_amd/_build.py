@@ -10,13 +10,24 @@ ARCH = "gfx950"
 
 
 def source_hash():
-    """SHA-256 over the HIP sources and headers: stamps profiles (PMC summaries) so that bench.py only
-    quotes hardware counters collected on the code it is timing."""
+    """SHA-256 over the HIP sources and headers AND what else decides the binary that runs: the extra
+    compile flags (LUMEN_HIPCC_FLAGS) and, when the Python binding is pointed at another build of the library
+    (LUMEN_HIP_LIB, tools/build_variant.sh), that variant's name and its recorded flags.  Stamps profiles (PMC
+    summaries) so that bench.py only quotes hardware counters collected on the code it is timing."""
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
+    flags = " ".join(os.environ.get("LUMEN_HIPCC_FLAGS", "").split())
+    variant = os.environ.get("LUMEN_HIP_LIB", "")
+    if variant:
+        vdir = os.path.dirname(os.path.abspath(variant))
+        flags_file = os.path.join(vdir, "FLAGS")
+        flags = "variant:" + os.path.basename(vdir) + ":" + (open(flags_file).read().strip() if os.path.exists(flags_file)
+                                                               else "unrecorded")
+    if flags:
+        h.update(b"\0flags\0" + flags.encode())
     return h.hexdigest()[:16]
 
 

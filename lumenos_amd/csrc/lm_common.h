@@ -73,7 +73,20 @@ struct lm_shared {
     ~lm_shared();
 };
 
+// Tuning switches of the A/B tools ("Run-time switches").  The environment is read ONCE, in
+// lumen_ctx_create (a clone copies its source's values): no getenv under LM_ENTER, so a setenv in the host
+// process can neither race with nor change the kernels a running prover uses.  lumen_ctx_set_tuning is the
+// in-process way for tests and tools.
+struct lm_tuning {
+    uint32_t ks_batch = 64;      // LUMEN_KS_BATCH: columns per key-switch batch
+    uint32_t ks_lanes = 1;       // LUMEN_KS_LANES: 2 = column batches alternate on two streams
+    int32_t ks_fused_digits = -1; // LUMEN_KS_FUSED_DIGITS: digits packed inside k_intt_pack (-1: derive)
+    uint32_t ct_blocks = 1;      // LUMEN_CT_BLOCKS: 0 = Encode through the op-by-op interpreter
+    uint32_t debug = 0;          // LUMEN_DEBUG
+};
+
 struct lumen_ctx {
+    lm_tuning tune;
     // every entry point locks the context (LM_ENTER): concurrent calls on ONE context are serialised
     // here, not left to the caller (the reference runs the R and Z inner products on two goroutines,
     // fhe/ligero.go:231-242); recursive because entry points call one another
@@ -85,6 +98,7 @@ struct lumen_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream_aux = nullptr; // side jobs that overlap the main stream (leaf hashing)
     hipEvent_t ev_aux = nullptr;
+    hipEvent_t ev_xdep = nullptr; // lumen_ctx_wait: "everything enqueued on this context so far"
     uint32_t aux_digests = 0;         // leaves of the lumen_leaf_digests_begin job in flight
     const u64 *aux_lo = nullptr, *aux_hi = nullptr; // storage that job is reading
     uint8_t *aux_host = nullptr;      // pinned staging of its digests

@@ -724,12 +724,9 @@ __global__ __launch_bounds__(LM_CB_THREADS) void k_ct_blocks(ct_blocks_args a, l
     }
 }
 
-// LUMEN_CT_BLOCKS=0: the op-by-op interpreter instead (A/B switch, read at every call so that a test can
-// run both kernels on the same input in one process)
-static bool ct_blocks_enabled() {
-    const char *e = getenv("LUMEN_CT_BLOCKS");
-    return !(e && *e && atoi(e) == 0);
-}
+// LUMEN_CT_BLOCKS=0 (read at lumen_ctx_create; lumen_ctx_set_tuning for a test that runs both kernels on the
+// same input in one process): the op-by-op interpreter instead
+static bool ct_blocks_enabled(const lumen_ctx *ctx) { return ctx->tune.ct_blocks != 0; }
 
 // final_g0/final_ng: groups of the final pass to run (all when final_ng == 0); final_pos: device
 // table slot -> output position for that pass (the plan's own permutation when NULL)
@@ -763,7 +760,7 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
         const uint32_t ng = final_pass && final_ng ? final_ng : d.ngroups;
         // (a tile must not straddle two limbs: every supported width, N >= 256 and lane shards of >= 64
         // coefficients, is a multiple of the 64-lane tile)
-        if (ct_blocks_enabled() && ((ctx->N >> logw) % LM_CB_W) == 0) {
+        if (ct_blocks_enabled(ctx) && ((ctx->N >> logw) % LM_CB_W) == 0) {
             ct_blocks_args b;
             b.srcA = a.srcA, b.srcB = a.srcB, b.dst = a.dst, b.slots = a.slots, b.out_pos = a.out_pos, b.scal = a.scal;
             b.mops = d.d_mops, b.mlayer = d.d_mlayer, b.mtotal = d.mtotal, b.mlayers = d.mlayers;

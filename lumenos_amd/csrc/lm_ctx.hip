@@ -161,8 +161,53 @@ static int ctx_private_init(lumen_ctx *ctx) {
     LM_HIP(ctx, hipStreamCreate(&ctx->stream_aux));
     LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
     LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming));
+    LM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_xdep, hipEventDisableTiming));
     LM_HIP(ctx, hipEventCreate(&ctx->tm0));
     LM_HIP(ctx, hipEventCreate(&ctx->tm1));
+    return 0;
+}
+
+static int tuning_set(lm_tuning &t, const char *name, long v) {
+    const std::string n(name ? name : "");
+    if (n == "LUMEN_KS_BATCH") t.ks_batch = (v >= 1 && v <= 4096) ? (uint32_t)v : 64;
+    else if (n == "LUMEN_KS_LANES") t.ks_lanes = v == 2 ? 2 : 1;
+    else if (n == "LUMEN_KS_FUSED_DIGITS") t.ks_fused_digits = v >= 0 ? (int32_t)v : -1;
+    else if (n == "LUMEN_CT_BLOCKS") t.ct_blocks = v != 0;
+    else if (n == "LUMEN_DEBUG") t.debug = v != 0;
+    else return 1;
+    return 0;
+}
+static void tuning_from_env(lm_tuning &t) {
+    for (const char *n : {"LUMEN_KS_BATCH", "LUMEN_KS_LANES", "LUMEN_KS_FUSED_DIGITS", "LUMEN_CT_BLOCKS", "LUMEN_DEBUG"}) {
+        const char *e = getenv(n);
+        if (e && *e) tuning_set(t, n, atol(e)); // an empty override counts as unset
+    }
+}
+
+// A/B tools and tests: the same switches the environment sets at lumen_ctx_create, on a live context
+// (value < 0 returns LUMEN_KS_FUSED_DIGITS to its derived default).  Not for production code paths.
+extern "C" int lumen_ctx_set_tuning(lumen_ctx *ctx, const char *name, long value) {
+    LM_CHECK(nullptr, ctx && name, "lumen_ctx_set_tuning: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, !tuning_set(ctx->tune, name, value), "unknown tuning switch %s", name);
+    return 0;
+}
+
+// ctx's stream waits for everything enqueued on other's stream so far -- without blocking the host.  What a
+// pipeline of contexts needs: a clone serialises / downloads MatR behind the kernels that produce it while
+// the producer context goes on to MatZ (fhe/ligero.go:231-242 runs the two on separate evaluator copies).
+extern "C" int lumen_ctx_wait(lumen_ctx *ctx, lumen_ctx *other) {
+    LM_CHECK(nullptr, ctx && other, "lumen_ctx_wait: NULL argument");
+    if (ctx == other) return 0;
+    hipEvent_t ev;
+    {
+        LM_ENTER(other);
+        LM_HIP(other, hipEventRecord(other->ev_xdep, other->stream));
+        ev = other->ev_xdep;
+    }
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, ctx->device == other->device, "lumen_ctx_wait: contexts on devices %d and %d", ctx->device, other->device);
+    LM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
     return 0;
 }
 
@@ -183,6 +228,7 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
     std::unique_ptr<lumen_ctx, void (*)(lumen_ctx *)> guard(new lumen_ctx(std::make_shared<lm_shared>()),
                                                             lumen_ctx_destroy);
     lumen_ctx *ctx = guard.get();
+    tuning_from_env(ctx->tune); // the only place the library reads its environment
     ctx->device = desc->device;
     ctx->logN = desc->log_n;
     ctx->N = 1u << desc->log_n;
@@ -230,6 +276,7 @@ extern "C" int lumen_ctx_clone(lumen_ctx *src, lumen_ctx **out) {
     LM_ENTER(src);
     std::unique_ptr<lumen_ctx, void (*)(lumen_ctx *)> guard(new lumen_ctx(src->sh), lumen_ctx_destroy);
     lumen_ctx *ctx = guard.get();
+    ctx->tune = src->tune;
     ctx->device = src->device;
     ctx->logN = src->logN, ctx->N = src->N, ctx->L = src->L, ctx->K = src->K, ctx->T = src->T;
     memcpy(ctx->mod, src->mod, sizeof(ctx->mod));
@@ -262,6 +309,7 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
             if (ctx->ev_io[i]) hipEventDestroy(ctx->ev_io[i]);
         }
         if (ctx->ev_stage) hipEventDestroy(ctx->ev_stage);
+        if (ctx->ev_xdep) hipEventDestroy(ctx->ev_xdep);
         if (ctx->ev_aux) hipEventDestroy(ctx->ev_aux);
         if (ctx->stream_aux) hipStreamDestroy(ctx->stream_aux);
         if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);

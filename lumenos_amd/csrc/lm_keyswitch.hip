@@ -29,15 +29,9 @@
 
 #include "lm_ks_dev.h"
 
-#define LM_KS_BATCH 64 // columns processed together (scratch ~ 172 limbs per column)
-static uint32_t ks_batch() { // LUMEN_KS_BATCH overrides the default (tuning knob)
-    static const uint32_t v = [] {
-        const char *e = getenv("LUMEN_KS_BATCH");
-        const long x = e ? atol(e) : 0;
-        return (uint32_t)(x >= 1 && x <= 4096 ? x : LM_KS_BATCH);
-    }();
-    return v;
-}
+// columns processed together (scratch ~ 172 limbs per column): 64 by default, LUMEN_KS_BATCH at context
+// creation (lm_tuning)
+static uint32_t ks_batch(const lumen_ctx *ctx) { return ctx->tune.ks_batch; }
 
 // 64 x 64 -> 128-bit product as four 32x32+64 multiply-adds (the compiler's __int128 multiply goes
 // through v_mul_lo/hi_u32, twice as slow each)
@@ -737,15 +731,9 @@ int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s, int lan
 // Enqueue on the context's second stream for the lifetime of the guard.  Independent column
 // batches alternate between the two streams so that the HBM-bound steps of one batch (gadget
 // product, correction-bit pass) overlap the VALU-bound transforms of the other.
-static uint32_t ks_lanes() {
-    static const uint32_t n = [] {
-        // one lane by default: with two, independent column batches overlap on two streams (about 1 %
-        // faster end to end) but per-kernel event timings then include the other lane's kernels
-        const char *e = getenv("LUMEN_KS_LANES");
-        return (e && atoi(e) == 2) ? 2u : 1u;
-    }();
-    return n;
-}
+// one lane by default: with two (LUMEN_KS_LANES=2 at context creation), independent column batches overlap
+// on two streams (about 1 % faster end to end) but per-kernel event timings then include the other lane's
+static uint32_t ks_lanes(const lumen_ctx *ctx) { return ctx->tune.ks_lanes; }
 // digits whose packing is fused into the c1 inverse transform (k_intt_pack): the largest count whose
 // B * nf two-transform workgroups are whole rounds of the device's workgroup slots (CUs x resident
 // workgroups per CU: 256 x 1 at N = 2^14, so 4 of 6 digits at B = 64), so that no slot waits for a
@@ -767,7 +755,7 @@ static uint32_t intt_pack_slots(lumen_ctx *ctx) {
             per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lm_lds_for(1u << LOGN), 2048 / lm_nthreads(LOGN)));
         }
         (void)hipGetLastError();
-        if (getenv("LUMEN_DEBUG"))
+        if (ctx->tune.debug)
             fprintf(stderr, "[lumenos_hip] k_intt_pack<%d>: %d workgroup(s) per CU, %d CUs\n", LOGN, per_cu,
                     prop.multiProcessorCount);
         return (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
@@ -775,8 +763,7 @@ static uint32_t intt_pack_slots(lumen_ctx *ctx) {
     return v;
 }
 static uint32_t ks_fused_digits(lumen_ctx *ctx, uint32_t B, uint32_t L) {
-    const char *e = getenv("LUMEN_KS_FUSED_DIGITS"); // read at every call: a test runs several settings in one process
-    const long forced = e && *e ? atol(e) : -1l;
+    const long forced = ctx->tune.ks_fused_digits; // LUMEN_KS_FUSED_DIGITS at context creation / lumen_ctx_set_tuning
     const uint32_t pairs = L / 2; // digits with two limbs
     if (forced >= 0) return std::min<uint32_t>((uint32_t)forced, pairs);
     uint32_t slots = 0;
@@ -1073,7 +1060,7 @@ extern "C" int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, 
     lm_set_guard og(ctx, o);
     if (in->words)
         LM_HIP(ctx, hipMemcpyAsync(o->d, in->d, in->words * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    const uint32_t Bmax = std::min<uint32_t>(ks_batch(), std::max(in->count, 1u));
+    const uint32_t Bmax = std::min<uint32_t>(ks_batch(ctx), std::max(in->count, 1u));
     KsScratch s;
     if (get_scratch(ctx, Bmax, tb->beta, &s)) return 1;
     const size_t ctw = (size_t)2 * in->nl * ctx->N;
@@ -1100,7 +1087,7 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
     lumen_set *o = nullptr;
     if (int rc = lumen_set_create(ctx, matrix->count, target, &o)) return rc;
     lm_set_guard og(ctx, o);
-    const uint32_t Bmax = std::min<uint32_t>(ks_batch(), std::max(matrix->count, 1u));
+    const uint32_t Bmax = std::min<uint32_t>(ks_batch(ctx), std::max(matrix->count, 1u));
     // the rescale to level 1 runs on groups of batches: one batch alone (2*B polynomials) does not
     // fill the 256 CUs in the kernels that take one workgroup per polynomial
     const uint32_t group = std::min<uint32_t>(8 * Bmax, std::max(matrix->count, 1u));
@@ -1109,18 +1096,18 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
     u64 *acc = (u64 *)lm_scratch(ctx, "ks_acc", (size_t)group * ctw * 8);
     u64 *work = (u64 *)lm_scratch(ctx, "rescale_work", (size_t)group * ctw * 8);
     u64 *tbuf = (u64 *)lm_scratch(ctx, "rescale_t", (size_t)group * 2 * N * 8);
-    if (get_scratch(ctx, Bmax, tb->beta, &s[0], 0) || (ks_lanes() > 1 && get_scratch(ctx, Bmax, tb->beta, &s[1], 1)) ||
+    if (get_scratch(ctx, Bmax, tb->beta, &s[0], 0) || (ks_lanes(ctx) > 1 && get_scratch(ctx, Bmax, tb->beta, &s[1], 1)) ||
         !acc || !work || !tbuf)
         return 1;
     for (uint32_t g0 = 0; g0 < matrix->count; g0 += group) {
         const uint32_t gn = std::min(group, matrix->count - g0);
         // fork: the second lane starts after everything already enqueued on the main stream
-        if (ks_lanes() > 1) {
+        if (ks_lanes(ctx) > 1) {
             LM_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             LM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         }
         uint32_t lane = 0;
-        for (uint32_t first = 0; first < gn; first += Bmax, lane = (lane + 1) % ks_lanes()) {
+        for (uint32_t first = 0; first < gn; first += Bmax, lane = (lane + 1) % ks_lanes(ctx)) {
             const uint32_t B = std::min(Bmax, gn - first);
             u64 *a = acc + (size_t)first * ctw;
             LaneGuard guard(ctx, (int)lane);
@@ -1129,7 +1116,7 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
             if (int rc = inner_sum_batch(ctx, a, B, rows, tb, s[lane])) return rc; // ligero.go:325
         }
         // join: the rescale of the group needs both lanes
-        if (ks_lanes() > 1) {
+        if (ks_lanes(ctx) > 1) {
             LM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             LM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }

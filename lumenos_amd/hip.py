@@ -45,6 +45,8 @@ SYMBOLS = {
     "lumen_host_alloc": (_vp, [C.c_size_t]),
     "lumen_host_free": (None, [_vp]),
     "lumen_last_error": (C.c_char_p, [_vp]),
+    "lumen_ctx_wait": (C.c_int, [_vp, _vp]),
+    "lumen_ctx_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_long]),
     "lumen_sync": (C.c_int, [_vp]),
     "lumen_mul_counter": (C.c_uint64, [_vp]),
     "lumen_set_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vpp]),
@@ -276,6 +278,14 @@ class Context:
 
     def sync(self):
         self._ck(self.lib.lumen_sync(self.h))
+
+    def wait_for(self, other):
+        """this context's stream waits (on the device) for everything enqueued on `other` so far"""
+        self._ck(self.lib.lumen_ctx_wait(self.h, other.h))
+
+    def set_tuning(self, name, value):
+        """A/B switch of the tools and tests (lumen_ctx_set_tuning); the environment is only read at creation"""
+        self._ck(self.lib.lumen_ctx_set_tuning(self.h, name.encode(), int(value)))
 
     def download_into(self, s, out, first=0):
         """download a set (possibly created by another context of this device) on THIS context's stream"""

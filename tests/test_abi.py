@@ -122,3 +122,23 @@ def test_no_kernel_spills_or_uses_scratch():
         assert v.get("ScratchSize [bytes/lane]", 0) == 0 and v.get("VGPRs Spill", 0) == 0, (k, v)
     big = {k: v for k, v in rep.items() if "Li14E" in k and ("k_modup_ntt" in k or "k_moddown_ntt" in k or "k_limb_ntt" in k)}
     assert big and all(v["VGPRs"] <= 128 for v in big.values()), big  # 1024 threads x 4 waves/SIMD at N = 2^14
+
+
+def test_environment_is_read_once_at_context_creation():
+    """The library is documented thread-safe under cgo: getenv() must not run under a compute entry point
+    (it races with setenv in the host process and would let the environment swap kernels mid-proof).  The
+    one call sits in the helper lumen_ctx_create uses; everything else reads ctx->tune."""
+    hits = []
+    csrc = os.path.join(ROOT, "lumenos_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+                code = line.split("//")[0]
+                if "getenv(" in code:
+                    hits.append((f, i))
+    assert [h[0] for h in hits] == ["lm_ctx.hip"], hits
+    src = open(os.path.join(csrc, "lm_ctx.hip")).read()
+    body = src[src.index("static void tuning_from_env"):]
+    body = body[:body.index("\n}\n")]
+    assert "getenv(" in body
+    assert src.count("tuning_from_env(") == 2  # the definition and the call in lumen_ctx_create

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -163,3 +164,27 @@ def test_lane_sharded_exchange_world2():
 
 def test_lane_sharded_exchange_world4():
     _run_lane_world(4)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as typed: the parent starts one rank per GPU under torch.distributed.run as a
+    child process, relays its output and exits with its code.  Without a GPU here every rank stops at "needs a
+    HIP device" -- which proves the ranks were started with RANK / WORLD_SIZE set and that the parent reports
+    their failure instead of the old "must be launched with torch.distributed.run"."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the rehearsal in profiles/ covers the real run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--config", "2048x1024", "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
+    assert "needs a HIP device" in res.stderr, res.stderr[-1500:]
+    assert "must be launched with" not in res.stderr
+    # the parent itself never imports torch.cuda / HIP: it is a plain launcher
+    src = open(os.path.join(root, "bench.py")).read()
+    body = src[src.index("def launch_ranks"):src.index("def timed_steps")]
+    code = body[body.index('"""', body.index('"""') + 3) + 3:]  # behind the docstring
+    assert "torch.cuda" not in code and "lumenos_amd" not in code and "import torch" not in code

@@ -239,7 +239,7 @@ def test_inner_sum_matches_oracle(oracle, keyed, n):
 
 
 @pytest.mark.parametrize("nf", [0, 1, 2])
-def test_inner_sum_fused_digit_packing(oracle, keyed, nf, monkeypatch):
+def test_inner_sum_fused_digit_packing(oracle, keyed, nf):
     """k_intt_pack: the (hi, lo) packing of the first nf two-limb digits is fused into the c1 inverse
     transform, the others go through k_pack_v.  The library picks nf from the batch size (4 of 6 digits at
     64 columns); here every split of L = 5 limbs -- digits (0,1) (2,3) (4) -- is forced in turn."""
@@ -250,8 +250,11 @@ def test_inner_sum_fused_digit_packing(oracle, keyed, nf, monkeypatch):
     for g, e in zip(gl, evks):
         ctx.load_galois_key(g, e)
     cts = random_cts(P, 3, 5, seed=640 + nf)
-    monkeypatch.setenv("LUMEN_KS_FUSED_DIGITS", str(nf))
-    got = ctx.inner_sum(ctx.upload(cts), n).download()
+    try:
+        ctx.set_tuning("LUMEN_KS_FUSED_DIGITS", nf)
+        got = ctx.inner_sum(ctx.upload(cts), n).download()
+    finally:
+        ctx.set_tuning("LUMEN_KS_FUSED_DIGITS", -1)
     for c in range(3):
         assert np.array_equal(got[c], P.inner_sum(cts[c], n, evks)), c
 
@@ -389,7 +392,7 @@ def test_full_size_matrix_inner_sum(oracle, full_d):
     assert int(P.decrypt(sk, got[0], 1, P.rescale_scale(P.L, 2))[0]) == want
 
 
-def test_full_size_inner_sum_batch_of_64_fused_packing(oracle, full_d, monkeypatch):
+def test_full_size_inner_sum_batch_of_64_fused_packing(oracle, full_d):
     """The headline geometry of step 1 of a rotation: 64 columns at N = 2^14, L = 12 -- the batch size at
     which k_intt_pack fuses the packing of 4 of the 6 digits into the c1 transform (256 two-transform
     workgroups + 256 single ones).  Same 64 random ciphertexts through the fused launch (the library's
@@ -402,10 +405,11 @@ def test_full_size_inner_sum_batch_of_64_fused_packing(oracle, full_d, monkeypat
     for g, e in zip(gl, evks):
         ctx.load_galois_key(g, e)
     cts = random_cts(P, 64, P.L, seed=6464)
-    monkeypatch.delenv("LUMEN_KS_FUSED_DIGITS", raising=False)
+    ctx.set_tuning("LUMEN_KS_FUSED_DIGITS", -1)
     fused = ctx.inner_sum(ctx.upload(cts), n).download()
-    monkeypatch.setenv("LUMEN_KS_FUSED_DIGITS", "0")
+    ctx.set_tuning("LUMEN_KS_FUSED_DIGITS", 0)
     plain = ctx.inner_sum(ctx.upload(cts), n).download()
+    ctx.set_tuning("LUMEN_KS_FUSED_DIGITS", -1)
     assert np.array_equal(fused, plain)
     for c in (0, 63):
         assert np.array_equal(fused[c], P.inner_sum(cts[c], n, evks)), c
@@ -433,8 +437,9 @@ def test_encode_shards_cover_full_encode(oracle, small, world):
         seen[idx] += 1
     assert np.all(seen == 1)
 
-def test_encode_interpreter_matches_register_blocked_kernel(oracle, small, monkeypatch):
-    """LUMEN_CT_BLOCKS=0 selects the op-by-op interpreter (k_ct_pass) the register-blocked kernel
+def test_encode_interpreter_matches_register_blocked_kernel(oracle, small):
+    """LUMEN_CT_BLOCKS=0 (lumen_ctx_set_tuning here: the library reads its environment once, at context
+    creation) selects the op-by-op interpreter (k_ct_pass) the register-blocked kernel
     (k_ct_blocks) replaced: both replay the same schedule, so Encode and the in-place transform must come
     out identical -- and equal to the oracle -- either way."""
     P, ctx = small
@@ -446,12 +451,15 @@ def test_encode_interpreter_matches_register_blocked_kernel(oracle, small, monke
     want = P.ct_encode(m, rho, zero, roots)
     cts = random_cts(P, 256, 2, seed=193)
     want_ntt = P.ct_ntt(cts, 256, roots)
-    for blocks in ("1", "0"):
-        monkeypatch.setenv("LUMEN_CT_BLOCKS", blocks)
-        assert np.array_equal(ctx.encode(ctx.upload(m), zero, rho).download(), want), blocks
-        s = ctx.upload(cts)
-        ctx.ct_ntt(s, 256)
-        assert np.array_equal(s.download(), want_ntt), blocks
+    try:
+        for blocks in (1, 0):
+            ctx.set_tuning("LUMEN_CT_BLOCKS", blocks)
+            assert np.array_equal(ctx.encode(ctx.upload(m), zero, rho).download(), want), blocks
+            s = ctx.upload(cts)
+            ctx.ct_ntt(s, 256)
+            assert np.array_equal(s.download(), want_ntt), blocks
+    finally:
+        ctx.set_tuning("LUMEN_CT_BLOCKS", 1)
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

@@ -7,12 +7,26 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/lumenos_amd/csrc/variants/$name
 mkdir -p "$out"
+echo "$*" > "$out/FLAGS"   # lumenos_amd/_build.py source_hash() folds the variant's name and flags into the profile stamp
 objs=()
 for s in "$root"/lumenos_amd/csrc/*.hip; do
   o=$out/$(basename "${s%.hip}").o
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-result "$@" -c "$s" -o "$o" &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-result \
+    -Rpass-analysis=kernel-resource-usage "$@" -c "$s" -o "$o" > "$o.log" 2>&1 &
   objs+=("$o")
 done
 wait
+# the same gate as the product build: no kernel may spill or use scratch (a variant that does is not an A/B
+# of the product, it is a different machine code regime)
+python3 - "$out" <<'PY'
+import glob, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "..", "..", ".."))
+from lumenos_amd import _build
+for log in sorted(glob.glob(os.path.join(sys.argv[1], "*.o.log"))):
+    text = open(log, errors="ignore").read()
+    if "error:" in text:
+        sys.exit(text[-3000:])
+    _build.check_resources(_build._resource_usage(text), log)
+PY
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$out/liblumenos_hip.so" "${objs[@]}"
 echo "$out/liblumenos_hip.so"

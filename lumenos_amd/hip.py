@@ -287,6 +287,13 @@ class Context:
         """A/B switch of the tools and tests (lumen_ctx_set_tuning); the environment is only read at creation"""
         self._ck(self.lib.lumen_ctx_set_tuning(self.h, name.encode(), int(value)))
 
+    def upload_into(self, s, host, first=0):
+        """upload ciphertexts [first, first + len(host)) of a set (possibly another context's) on THIS context's
+        stream: a clone feeds the producer's input set while the producer computes on what already arrived"""
+        assert host.dtype == np.uint64 and host.flags["C_CONTIGUOUS"] and host.shape[1:] == s.shape[1:]
+        if host.shape[0]:
+            self._ck(self.lib.lumen_set_upload(self.h, s.h, first, host.shape[0], _p64(host)))
+
     def download_into(self, s, out, first=0):
         """download a set (possibly created by another context of this device) on THIS context's stream"""
         assert out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"] and out.shape[1:] == s.shape[1:]

@@ -335,19 +335,41 @@ __device__ __forceinline__ void lm_fwd_stages(u64 *e, const lm_twset<R, UW> &T, 
     }
 }
 
-// R inverse stages on inputs in [0, 3q); log_t0 = log2 of the first stage's butterfly distance.
+// Twiddles of R inverse stages (first stage at butterfly distance 2^log_t0) for block blk, loaded apart from
+// the stages that use them: stage st takes 2^(R-st-1) of them.  Left inside the stage loop, the compiler
+// requests some of a pass's per-lane table words only when their stage comes up (two of the seven in the
+// second pass at N = 2^14, each followed by s_waitcnt vmcnt(0): an L2 round trip in the middle of the
+// butterflies); fetched as a set they are all in flight before the pass's LDS reads, and a pass with several
+// work items per lane can request the next item's set before it computes the current one (LM_INV_TW_PREFETCH).
+// N = 2^14: 9.4 -> 10.1 M inverse transforms/s.  (FIRST marks the first pass's sets: a transposed [g][w] table
+// layout for them -- every load instruction one contiguous kilobyte instead of lanes 64 / 32 bytes apart --
+// was measured and changes nothing, 9.35 against 9.40: the loads wait on L2 latency, not on request count.)
+template <int R, bool UW, bool FIRST>
+struct lm_inv_twset {
+    tw_t w[(1 << R) - 1];
+    static constexpr int off(int st) { return (1 << R) - (1 << (R - st)); } // stages 0..st-1 hold 2^R - 2^(R-st)
+    __device__ __forceinline__ void load(const tw_t *__restrict__ tw, uint32_t logN, uint32_t log_t0, uint32_t blk) {
+#pragma unroll
+        for (int st = 0; st < R; st++) {
+            const uint32_t m = 1u << (logN - log_t0 - st - 1);
+#pragma unroll
+            for (int g = 0; g < (1 << (R - st - 1)); g++)
+                w[off(st) + g] = lm_tw_load<UW>(tw, m + (blk << (R - st - 1)) + g);
+        }
+    }
+};
+
+// R inverse stages on inputs in [0, 3q) with preloaded twiddles.
 // Output e[i] has taken the sum branch in its last k stages (k = R for i = 0, else R-1-floor(log2 i))
 // and is below 3q * 2^k <= 48q.  Unless this is the transform's last pass (whose storer multiplies by
 // N^-1 and takes any value below 2^64) the outputs are brought back under 3q: k conditional
 // subtractions, or one multiplication-free Shoup reduction when k >= 3.
-template <int R, bool UW, bool LAST>
-__device__ __forceinline__ void lm_inv_stages(u64 *e, uint32_t logN, uint32_t log_t0, uint32_t blk,
-                                              const tw_t *__restrict__ tw, const lm_qc &c) {
+template <int R, bool UW, bool LAST, bool FIRST>
+__device__ __forceinline__ void lm_inv_stages(u64 *e, const lm_inv_twset<R, UW, FIRST> &T, const lm_qc &c) {
     static_assert(R <= 4, "3q * 2^R must stay below 2^64");
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int half = 1 << st, span = half << 1;
-        const uint32_t m = 1u << (logN - log_t0 - st - 1);
         const u64 C = c.q3 << st;
         // all sums and differences of the stage first, then the multiplications (as in the forward stages)
         u64 dif[(1 << R) / 2];
@@ -361,7 +383,7 @@ __device__ __forceinline__ void lm_inv_stages(u64 *e, uint32_t logN, uint32_t lo
             }
 #pragma unroll
         for (int g = 0; g < ((1 << R) / span); g++) {
-            const tw_t W = lm_tw_load<UW>(tw, m + (blk << (R - st - 1)) + g);
+            const tw_t W = T.w[lm_inv_twset<R, UW, FIRST>::off(st) + g];
 #pragma unroll
             for (int k = 0; k < half; k++)
                 e[g * span + k + half] = lm_shoup3<UW>(dif[g * half + k], W.w, W.wp, c.nq);
@@ -599,18 +621,26 @@ __device__ __forceinline__ void lm_inv_first(u64 *s, const tw_t *tw, const lm_qc
         const uint32_t w = D::local(tid, m);
         const uint32_t base = w << R;
         u64 e[1 << R];
+        lm_inv_twset<R, false, true> T;
+        T.load(tw, LOGN, 0, w);
         ld(base, e, 1 << R);
-        lm_inv_stages<R, false, false>(e, LOGN, 0, w, tw, c);
+        lm_inv_stages<R, false, false, true>(e, T, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + k)] = e[k];
     }
 }
 
+#ifndef LM_INV_TW_PREFETCH
+#define LM_INV_TW_PREFETCH 1 // wave-local inverse passes: request work item m+1's twiddles before computing item m
+#endif
 template <int LOGN, int R, int LT>
 __device__ __forceinline__ void lm_inv_mid(u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid) {
     using D = lm_deal<LOGN, R>;
     if (!D::valid(tid)) return;
-#pragma unroll 1
+    constexpr bool UW = LT >= 6;
+    lm_inv_twset<R, UW, false> T[2];
+    T[0].load(tw, LOGN, LT, D::local(tid, 0) >> LT);
+#pragma unroll
     for (uint32_t m = 0; m < D::reps; m++) {
         const uint32_t w = D::local(tid, m);
         const uint32_t blk = w >> LT, off = w & ((1u << LT) - 1);
@@ -618,7 +648,9 @@ __device__ __forceinline__ void lm_inv_mid(u64 *s, const tw_t *tw, const lm_qc &
         u64 e[1 << R];
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << LT))];
-        lm_inv_stages<R, (LT >= 6), false>(e, LOGN, LT, blk, tw, c);
+        if (LM_INV_TW_PREFETCH && m + 1 < D::reps) T[(m + 1) & 1].load(tw, LOGN, LT, D::local(tid, m + 1) >> LT);
+        if (!LM_INV_TW_PREFETCH && m) T[0].load(tw, LOGN, LT, blk);
+        lm_inv_stages<R, UW, false, false>(e, T[LM_INV_TW_PREFETCH ? (m & 1) : 0], c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << LT))] = e[k];
     }
@@ -635,6 +667,8 @@ template <int LOGN, int R, class Storer>
 __device__ __forceinline__ void lm_inv_last(const u64 *s, const tw_t *tw, const lm_qc &c, uint32_t tid, Storer &st) {
     constexpr uint32_t log_t0 = LOGN - R, items = 1u << log_t0, NT = lm_nthreads(LOGN);
     constexpr uint32_t reps = items / NT ? items / NT : 1;
+    lm_inv_twset<R, true, false> T; // wave-uniform (block 0 for every item): scalar loads, once
+    T.load(tw, LOGN, log_t0, 0);
 #pragma unroll 1
     for (uint32_t m = 0; m < reps; m++) {
         const uint32_t w = tid + m * NT;
@@ -645,7 +679,7 @@ __device__ __forceinline__ void lm_inv_last(const u64 *s, const tw_t *tw, const 
         // a storer with a member pre(w) is told the work item before its butterflies run: whatever it
         // reads from global memory for coefficients w + (k << log_t0), k < 2^R, is then in flight under them
         if constexpr (lm_has_pre<Storer>::value) st.pre(w);
-        lm_inv_stages<R, true, true>(e, LOGN, log_t0, 0, tw, c);
+        lm_inv_stages<R, true, true, false>(e, T, c);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) {
             if constexpr (lm_has_slot<Storer>::value)
@@ -676,6 +710,10 @@ __device__ __forceinline__ void lm_inv_rec(u64 *sm, const tw_t *tw, const lm_qc 
         lm_inv_rec<LOGN, P + 1, LT + R>(sm, tw, c, tid, ld, st);
     }
 }
+// (Requests ACROSS the inverse's passes, as lm_fwd14_xpass does for the forward transform -- the second pass's
+// first set under the first pass, the wave-uniform sets before the fences and the barrier -- were measured at
+// N = 2^14: 10.14 against 10.17 M transforms/s with the first pass left as the rolled loop, 9.48 with its two
+// work items unrolled.  Not kept.)
 template <int LOGN, class Loader, class Storer>
 __device__ __forceinline__ void lm_ntt_inverse(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid, uint32_t,
                                                Loader &ld, Storer &st) {

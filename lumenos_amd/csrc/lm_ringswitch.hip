@@ -209,14 +209,9 @@ extern "C" int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, u
     LM_HIP(ctx, hipMemcpy(sp->d_key, mont.data(), words * 8, hipMemcpyHostToDevice));
     // small ring tables on q_0: psi_small = psi^(N/n)
     const uint32_t n = 1u << log_n_small;
-    const uint64_t q0 = ctx->mod[0], psi = h_powmod(ctx->psi[0], N / n, q0), psi_inv = h_invmod(psi, q0);
-    std::vector<tw_t> f(n), b(n);
-    uint64_t cf = 1, cb = 1;
-    for (uint32_t jdx = 0; jdx < n; jdx++) {
-        const uint32_t rr = h_bitrev(jdx, (int)log_n_small);
-        f[rr] = h_tw(cf, q0), b[rr] = h_tw(cb, q0);
-        cf = h_mulmod(cf, psi, q0), cb = h_mulmod(cb, psi_inv, q0);
-    }
+    const uint64_t q0 = ctx->mod[0], psi = h_powmod(ctx->psi[0], N / n, q0);
+    std::vector<tw_t> f, b;
+    lm_build_tw(q0, psi, log_n_small, f, b); // the layout the transforms of that degree expect
     LM_HIP(ctx, hipMalloc((void **)&sp->d_tw_small, n * sizeof(tw_t)));
     LM_HIP(ctx, hipMalloc((void **)&sp->d_tw_small_inv, n * sizeof(tw_t)));
     LM_HIP(ctx, hipMemcpy(sp->d_tw_small, f.data(), n * sizeof(tw_t), hipMemcpyHostToDevice));

@@ -448,7 +448,10 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
     const u64 *uq = u + ((size_t)pw * LK + t) * N;
     const u64 *ain = acc_in + ((size_t)pw * L + t) * N; // c0 (w == 0) / c1 (w == 1) limb of the accumulator
     u64 *aout = acc_out + ((size_t)pw * L + t) * N;
-    const tw_t pi = pinv[t];
+    // -P^-1 as a Shoup constant: (q - w, ~w') -- floor((q - w) * 2^64 / q) = 2^64 - 1 - floor(w * 2^64 / q) for
+    // w * 2^64 not a multiple of q -- so that u' - lift * P^-1 is ONE multiply-add with u' in the addend slot
+    tw_t pi = pinv[t];
+    pi.w = qc.q - pi.w, pi.wp = ~pi.wp;
     auto ld = [&](uint32_t i) { return bx_apply(c, up0[i], up1[i], qc); };
     // the store phase combines every finished run of 8 with the gadget product u (and c0 for w == 0): both
     // are requested by pre() before the run's butterflies, not after them
@@ -469,9 +472,9 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
 #pragma unroll
             for (int k = 0; k < RUN; k++)
                 if (k < count) {
-                    // u' - lift * P^-1 (u' = u * P^-1 comes out of the gadget product, see
-                    // lumen_load_galois_key); the multiplication takes the unreduced lift: < 4q
-                    u64 x = uv[k] + qc.q3 - lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq);
+                    // u' - lift * P^-1 = u' + lift * (-P^-1) (u' = u * P^-1 comes out of the gadget product, see
+                    // lumen_load_galois_key); the multiplication takes the unreduced lift: result < 4q
+                    u64 x = lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq, uv[k]);
                     x = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
                     if (w == 0) x = lm_addmod(x, cv[k], qc.q);
                     sm[LM_PAD(i0 + k)] = x; // the slots this work item just consumed

@@ -8,9 +8,11 @@ set -e
 out=$GRAFT_REPO_ROOT/$1; cfg=${2:-16384x4096}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline"
+# (the default run's extra legs -- io, other configurations -- launch other kernels or the same ones on other
+# rings; the summaries are per kernel NAME, so they are left out of the profiled command to keep it short)
+B="$GRAFT_REPO_ROOT/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-io --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 $B > "$out/stats.log" 2>&1
-B1="$GRAFT_REPO_ROOT/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile"
+B1="$GRAFT_REPO_ROOT/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile --no-io --no-other-configs"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 $B1 > "$out/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 $B1 > "$out/write.log" 2>&1
 # SQ counters of the same command (instruction counts and VALU-busy cycles), two more PMC-only passes

@@ -458,6 +458,15 @@ class Params:
         self.o.lib.lo_keygen_secret_small(self.h, self._r(), logn_small, c.ctypes.data_as(C.POINTER(C.c_int64)))
         return c
 
+    def small_secret_ntt(self, sk_small):
+        """skNew of the SAME ring degree (TestRingSwitch) as NTT-domain residues [L+K][N], like keygen_secret's"""
+        assert sk_small.size == self.N
+        out = np.zeros((self.L + self.K, self.N), dtype=np.uint64)
+        for i, q in enumerate(self.moduli):
+            v = np.array([int(x) % q for x in sk_small], dtype=np.uint64)
+            out[i] = self.limb_ntt(v, i)
+        return out
+
     def keygen_ringswitch(self, sk, sk_small, logn_small, w=13):
         key = np.zeros((*self.rs_key_shape(w), 2, self.L + self.K, self.N), dtype=np.uint64)
         self.o.lib.lo_keygen_ringswitch(self.h, self._r(), _p64(sk), sk_small.ctypes.data_as(C.POINTER(C.c_int64)),

@@ -9,7 +9,11 @@ the C ABI -- against Lattigo's own outputs, stage by stage:
     rescale.lmfx     Rescale once and the loop to level 1, Scale bookkeeping
     writeto.lmfx     ct.WriteTo bytes: the leaf layout (head / poly_head / limb_head) and its SHA-256
     innersum_*.lmfx  MulNew + InnerSum(ct, 1, n) + Rescale with real Galois keys (n = N/2 and n = N)
-    ringswitch.lmfx  ApplyEvaluationKey into the small ring
+    ringswitch.lmfx  ApplyEvaluationKey into the small ring (two special primes: key [beta][1], hybrid RNS digit)
+    ringswitch_nop.lmfx  TestRingSwitch's parameters: LogQ = [58], no special prime (key [1][5], bit-decomposed)
+  and, inside params.lmfx / innersum_N.lmfx: the COUNT and content of GaloisElementsForInnerSum, the [RNS][pw2]
+  shape of Galois / relinearisation / ring-switch keys, the serialised sizes behind "Marshaled keys length",
+  and the two candidate orders of the row swap in InnerSum(ct, 1, N)
     ct_ntt.lmfx      fhe.NTT on ciphertexts            (only with `go run -tags withfhe`)
 
 Until those files exist every "lattigo" case SKIPS with the reason below -- the restatement stays
@@ -130,8 +134,14 @@ def synthesize(oracle, out_dir, log_n=10, cols=16):
         "P": np.array(mods[L:], dtype=np.uint64), "T": np.array([T_REF], dtype=np.uint64),
         "psi": np.array(P.psi, dtype=np.uint64), "psi_T": np.array([lp.encoder_psi(T_REF, log_n)], dtype=np.uint64),
         "roots_forward_q0_montgomery": table,
-        "galois_elements_inner_sum_half": np.array(P.inner_sum_galois_elements(N // 2), dtype=np.uint64),
-        "galois_elements_inner_sum_full": np.array(P.inner_sum_galois_elements(N), dtype=np.uint64),
+        "galois_elements_inner_sum_half": np.array(lp.galois_elements_for_inner_sum(log_n, 1, N // 2)[::-1], dtype=np.uint64),
+        "galois_elements_inner_sum_full": np.array(lp.galois_elements_for_inner_sum(log_n, 1, N)[::-1], dtype=np.uint64),
+        "galois_count_half": np.array([log_n], dtype=np.uint64), "galois_count_full": np.array([log_n + 2], dtype=np.uint64),
+        "galois_element_row_swap": np.array([2 * N - 1], dtype=np.uint64),
+        "rlk.shape": np.array([P.beta(), 1, 0], dtype=np.uint64),
+        "pk_marshal_len": np.array([2 * (L + K) * N * 8 + 300], dtype=np.uint64),
+        "rlk_marshal_len": np.array([P.beta() * 2 * (L + K) * N * 8 + 900], dtype=np.uint64),
+        "galois_key_marshal_len": np.array([P.beta() * 2 * (L + K) * N * 8 + 916], dtype=np.uint64),
         "field_roots_forward": oracle.field_roots(T_REF, 2 * cols),
     })
     values = np.array([(i * 0x9e3779b97f4a7c15 + 12345) % (1 << 64) % T_REF for i in range(N)], dtype=np.uint64)
@@ -177,17 +187,30 @@ def synthesize(oracle, out_dir, log_n=10, cols=16):
 
     for n in (N // 2, N):
         gl = P.inner_sum_galois_elements(n)
-        evks = [P.keygen_galois(sk, g) for g in gl]
-        d = {"n": np.array([n], dtype=np.uint64), "galois_elements": np.array(gl[::-1], dtype=np.uint64),  # any order
+        gen = list(dict.fromkeys(lp.galois_elements_for_inner_sum(log_n, 1, n)))  # what the client generates keys for
+        gen_keys = {g: P.keygen_galois(sk, g) for g in gen}
+        evks = [gen_keys[g] for g in gl]
+        d = {"n": np.array([n], dtype=np.uint64), "galois_elements": np.array(gen[::-1], dtype=np.uint64),  # any order
              "keys_montgomery": np.array([1], dtype=np.uint64), "sk": to_montgomery(sk, mods)[None], "r": r,
              "plaintext": rpt[None]}
-        for i, (g, e) in enumerate(list(zip(gl, evks))[::-1]):
+        for i, (g, e) in enumerate(list(gen_keys.items())[::-1]):
             d[f"key{i}.galois_element"] = np.array([g], dtype=np.uint64)
             d[f"key{i}"] = to_montgomery(e, mods).reshape(-1, L + K, N)
             d[f"key{i}.shape"] = np.array([e.shape[0], 1, 0], dtype=np.uint64)
         ct_rec(d, "in", ct)
-        inner = P.inner_sum(P.mul_plain(ct, rpt), n, evks)
+        col0 = P.mul_plain(ct, rpt)
+        inner = P.inner_sum(col0, n, evks)
         ct_rec(d, "inner_sum", inner)
+        if n == N:  # the two places the row swap can sit (tools/go_dump/main.go)
+            add = lambda a, b: ((a.astype(object) + b.astype(object)) % np.array(mods[:L], dtype=object)[None, :, None]).astype(np.uint64)
+            half, rs = evks[:-1], evks[-1]
+            a = P.inner_sum(col0, N // 2, half)
+            ct_rec(d, "cols_only", a)
+            ar = P.automorphism(a, 2 * N - 1, rs)
+            ct_rec(d, "rows_of_cols", ar)
+            ct_rec(d, "cand_cols_then_rows", add(a, ar))
+            b = add(col0, P.automorphism(col0, 2 * N - 1, rs))
+            ct_rec(d, "cand_rows_then_cols", P.inner_sum(b, N // 2, half))
         out = P.rescale_to_level1(inner)
         ct_rec(d, "out", out, P.rescale_scale(L, 2))
         d["slot0"] = P.decrypt(sk, out, 1, P.rescale_scale(L, 2))
@@ -204,7 +227,33 @@ def synthesize(oracle, out_dir, log_n=10, cols=16):
     d["out"] = out[:, None, :]
     d["out.flags"] = flags(0)
     d["out.scale"] = np.array([P.rescale_scale(L, 2)], dtype=np.uint64)
+    d["level_p"] = np.array([K - 1], dtype=np.uint64)
+    d["key_marshal_len"] = np.array([key.size * 8 + 916], dtype=np.uint64)
     lmfx.write(os.path.join(out_dir, "ringswitch.lmfx"), d)
+
+    # TestRingSwitch's parameters: one 58-bit modulus, no special prime, T = 0x3ee0001, same ring degree
+    from helpers import make_params
+    T2 = 0x3EE0001
+    P2 = make_params(oracle, log_n, 1, num_p=0, T=T2)
+    P2.seed(77)
+    sk2 = P2.keygen_secret()
+    pk2 = P2.keygen_public(sk2)
+    m = np.array([1, 1], dtype=np.uint64)
+    ct0 = P2.encrypt(pk2, P2.encode(m))
+    sk_new = P2.keygen_secret_small(log_n)
+    key2 = P2.keygen_ringswitch(sk2, sk_new, log_n)
+    out2 = P2.ring_switch(ct0, key2, log_n)
+    q0 = P2.moduli[0]
+    d = {"logN": np.array([log_n], dtype=np.uint64), "Q": np.array([q0], dtype=np.uint64), "T": np.array([T2], dtype=np.uint64),
+         "psi_q0": np.array([P2.psi[0]], dtype=np.uint64), "level_p": np.array([2**64 - 1], dtype=np.uint64),
+         "key": to_montgomery(key2, [q0]).reshape(-1, 1, N), "key.shape": np.array([*key2.shape[:2], 13], dtype=np.uint64),
+         "keys_montgomery": np.array([1], dtype=np.uint64),
+         "sk_new": to_montgomery(P2.small_secret_ntt(sk_new), [q0])[None], "decoded": m}
+    d["in"] = ct0
+    d["in.flags"], d["in.scale"] = flags(0), np.array([1], dtype=np.uint64)
+    d["out"] = out2[:, None, :]
+    d["out.flags"], d["out.scale"] = flags(0), np.array([1], dtype=np.uint64)
+    lmfx.write(os.path.join(out_dir, "ringswitch_nop.lmfx"), d)
 
     S = 2 * cols
     roots = oracle.field_roots(T_REF, S)
@@ -258,9 +307,25 @@ def test_params(oracle, fx):
     inv = pow(1 << 64, -1, q0)
     for j in (0, 1, 2, 3, P.N // 2, P.N - 1):
         assert int(tab[lp.bit_reverse(j, P.logN)]) * inv % q0 == pow(psi0, j, q0), j
-    assert set(int(x) for x in rec["galois_elements_inner_sum_half"]) == set(P.inner_sum_galois_elements(P.N // 2))
-    assert set(int(x) for x in rec["galois_elements_inner_sum_full"]) == set(P.inner_sum_galois_elements(P.N)), \
-        "InnerSum over all N slots: SURVEY Appendix D-1 (row swap 2N-1 expected)"
+    # the list the client generates keys for: rotations {1..n/2, n} (+ the row swap iff n > N/2), any order,
+    # duplicates included (rotations N/2 and N are both the element 1) -- what the reference's key-size logs show
+    for which, n in (("half", P.N // 2), ("full", P.N)):
+        got = sorted(int(x) for x in rec[f"galois_elements_inner_sum_{which}"])
+        assert got == sorted(lp.galois_elements_for_inner_sum(P.logN, 1, n)), \
+            f"GaloisElementsForInnerSum(1, {n}): SURVEY Appendix D-1 (row swap 2N-1 expected for n = N)"
+        assert set(P.inner_sum_galois_elements(n)) <= set(got), "InnerSum uses a key the client does not generate"
+        if f"galois_count_{which}" in rec:
+            assert int(rec[f"galois_count_{which}"][0]) == len(got) == P.logN + (2 if which == "full" else 0)
+    if "galois_element_row_swap" in rec:
+        assert int(rec["galois_element_row_swap"][0]) == 2 * P.N - 1
+    if "rlk.shape" in rec:
+        assert tuple(int(x) for x in rec["rlk.shape"][:2]) == (P.beta(), 1), "relinearisation key: [beta][1]"
+    if "pk_marshal_len" in rec:
+        # serialised sizes behind "Marshaled keys length": payload + a framing of at most a few KiB
+        LK = P.L + P.K
+        assert 0 <= int(rec["pk_marshal_len"][0]) - 2 * LK * P.N * 8 <= 4096
+        for k in ("rlk_marshal_len", "galois_key_marshal_len"):
+            assert 0 <= int(rec[k][0]) - P.beta() * 2 * LK * P.N * 8 <= 4096, k
     fr = rec["field_roots_forward"]
     assert np.array_equal(fr, oracle.field_roots(T_REF, len(fr)))
 
@@ -355,7 +420,13 @@ def _inner_sum_inputs(P, rec):
         i += 1
     n = int(rec["n"][0])
     gl = P.inner_sum_galois_elements(n)
-    assert set(gl) == set(keys), "Galois elements of InnerSum(ct, 1, n)"
+    from lumenos_amd import params as lp
+    assert set(keys) == set(lp.galois_elements_for_inner_sum(P.logN, 1, n)), "keys generated for InnerSum(ct, 1, n)"
+    assert set(gl) <= set(keys), "Galois elements InnerSum(ct, 1, n) uses"
+    i = 0
+    while f"key{i}" in rec:
+        assert tuple(int(x) for x in rec[f"key{i}.shape"][:2]) == (P.beta(), 1), "Galois key: [beta][1], no power-of-two digits"
+        i += 1
     return n, gl, [keys[g] for g in gl]
 
 
@@ -374,6 +445,47 @@ def test_inner_sum(oracle, fx, which):
     assert int(P.decrypt(sk, out, 1, int(rec["out.scale"][0]))[0]) == int(rec["slot0"][0])
 
 
+def test_inner_sum_row_swap_order(oracle, fx):
+    """InnerSum(ct, 1, N): WHERE the row swap sits is not observable after decryption but decides the
+    ciphertext bits.  The dump carries both compositions; exactly the one this repository restates
+    (N/2 column rotations first, then + RotateRows) must be Lattigo's, and the oracle must reproduce the
+    intermediate after the last column rotation."""
+    _, P, _, load = fx
+    rec = load(f"innersum_{P.N}.lmfx")
+    if "cols_only" not in rec:
+        pytest.skip("fixture set predates the row-swap candidates")
+    n, gl, evks = _inner_sum_inputs(P, rec)
+    lattigo = std_ct(rec, "inner_sum")
+    a, b = std_ct(rec, "cand_cols_then_rows"), std_ct(rec, "cand_rows_then_cols")
+    assert np.array_equal(lattigo, a) or np.array_equal(lattigo, b), "InnerSum(ct, 1, N) is neither composition"
+    assert np.array_equal(lattigo, a), ("Lattigo folds the two slot rows BEFORE the column rotations: "
+                                        "lo_inner_sum / lumen_inner_sum apply the row swap last")
+    col0 = P.mul_plain(std_ct(rec, "in"), rec["plaintext"][0])
+    cols = P.inner_sum(col0, P.N // 2, evks[:-1])
+    assert np.array_equal(cols, std_ct(rec, "cols_only")), "after the last column rotation"
+    assert np.array_equal(P.automorphism(cols, 2 * P.N - 1, evks[-1]), std_ct(rec, "rows_of_cols")), "RotateRows"
+
+
+def test_ring_switch_without_special_primes(oracle, fx):
+    """TestRingSwitch's own parameters (fhe/ring_switch_test.go:13-77): LogQ = [58], no P -> the key has
+    LevelP = -1, [1][ceil(58/13) = 5] entries, and ApplyEvaluationKey takes the bit-decomposed product."""
+    from oracle.loader import Params
+    _, _, _, load = fx
+    rec = load("ringswitch_nop.lmfx")
+    q0, T2, log_n = int(rec["Q"][0]), int(rec["T"][0]), int(rec["logN"][0])
+    P2 = Params.from_moduli(oracle, log_n, [q0], [], T2)
+    assert P2.psi[0] == int(rec["psi_q0"][0])
+    assert int(rec["level_p"][0]) == 2**64 - 1, "MaxLevelP() of parameters without P is -1"
+    key = ringswitch_key(rec, "key", [q0], 1, 0, int(rec["keys_montgomery"][0]))
+    assert key.shape[:2] == P2.rs_key_shape(int(rec["key.shape"][2])) == (1, 5)
+    ct = std_ct(rec, "in")
+    want = rec["out"][:, 0, :]
+    assert np.array_equal(P2.ring_switch(ct, key, log_n), want), "bit-decomposed gadget product (unsigned digits, no ModDown)"
+    sk_new = rec["sk_new"][0]
+    sk_new = from_montgomery(sk_new, [q0]) if int(rec["keys_montgomery"][0]) else sk_new
+    assert [int(x) for x in P2.decrypt(sk_new, want[:, None, :], 2)] == [int(x) for x in rec["decoded"]] == [1, 1]
+
+
 def test_ring_switch(oracle, fx):
     _, P, _, load = fx
     rec = load("ringswitch.lmfx")
@@ -383,6 +495,10 @@ def test_ring_switch(oracle, fx):
     # as the reference's key-size logs say), [L][ceil(bits/13)] with LevelP <= 0
     assert key.shape[:2] == P.rs_key_shape(int(rec["key.shape"][2]) or 13), \
         f"Lattigo's ring-switch key is {key.shape[:2]}, the restatement expects {P.rs_key_shape(13)}"
+    if "level_p" in rec:
+        assert int(rec["level_p"][0]) == P.K - 1
+    if "key_marshal_len" in rec:  # one Galois key's size: the "+ 5 / 7 / 15 / 29 MB" of the experimental logs
+        assert 0 <= int(rec["key_marshal_len"][0]) - key.size * 8 <= 4096
     ct = std_ct(rec, "in")
     assert np.array_equal(P.ring_switch(ct, key, small), rec["out"][:, 0, :]), \
         "ApplyEvaluationKey into the small ring (level-0 gadget product, ModDown, sub-ring extraction)"
@@ -442,6 +558,13 @@ def test_gpu_against_fixtures(oracle, fx):
         ctx.load_ringswitch_key(small, key)
         assert np.array_equal(ctx.ring_switch(ctx.upload(std_ct(rec, "in")[None]))[0], rec["out"][:, 0, :])
 
+        # the intermediate after the last column rotation of InnerSum(ct, 1, N) (row swap applied last)
+        rec = load(f"innersum_{P.N}.lmfx")
+        if "cols_only" in rec:
+            ct, pt = std_ct(rec, "in"), rec["plaintext"][0]
+            cols = ctx.inner_sum(ctx.mul_plain(ctx.upload(ct[None]), pt), P.N // 2).download()[0]
+            assert np.array_equal(cols, std_ct(rec, "cols_only")), "lumen_inner_sum over the N/2 columns"
+
         rec = load("encrypt.lmfx")
         sk = sk_of(P, rec)
         ctx.load_secret_key(sk)
@@ -449,6 +572,23 @@ def test_gpu_against_fixtures(oracle, fx):
         ctx.encoder_set(lp.encoder_psi(T_REF, P.logN))
         l1 = ctx.rescale(ctx.upload(std_ct(rec, "ciphertext")[None]), 2)
         assert np.array_equal(ctx.decrypt(l1, P.N, P.rescale_scale(P.L, 2))[0], rec["values"]), "lumen_decrypt"
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ring_switch_without_special_primes(oracle, fx):
+    """ringswitch_nop.lmfx through the C ABI: a context without special primes, the [1][5] key, no ModDown"""
+    from lumenos_amd.hip import Context
+    _, _, _, load = fx
+    rec = load("ringswitch_nop.lmfx")
+    q0, T2, log_n = int(rec["Q"][0]), int(rec["T"][0]), int(rec["logN"][0])
+    ctx = Context(log_n, [q0], [], [int(rec["psi_q0"][0])], T2)
+    try:
+        key = ringswitch_key(rec, "key", [q0], 1, 0, int(rec["keys_montgomery"][0]))
+        assert ctx.ringswitch_key_shape(int(rec["key.shape"][2])) == key.shape
+        ctx.load_ringswitch_key(log_n, key)
+        assert np.array_equal(ctx.ring_switch(ctx.upload(std_ct(rec, "in")[None]))[0], rec["out"][:, 0, :])
     finally:
         ctx.close()
 

@@ -26,6 +26,7 @@ package main
 import (
 	"bytes"
 	"encoding/binary"
+	"encoding/json"
 	"flag"
 	"fmt"
 	"os"
@@ -150,6 +151,7 @@ func main() {
 	out := flag.String("out", "lattigo_fixtures", "output directory")
 	logN := flag.Int("logN", 10, "ring degree of the fixtures")
 	cols := flag.Int("cols", 16, "matrix columns (chooses the Q chain as fhe.GenerateBGVParamsForNTT does)")
+	keySizes := flag.Bool("keysizes", false, "also marshal the whole KeysRequest of cmd/client (run with -logN 12 -cols 1024 to reproduce '69 MB')")
 	flag.Parse()
 	must(os.MkdirAll(*out, 0o755))
 
@@ -194,8 +196,46 @@ func main() {
 		f.u64s("psi", psi)
 		f.scalar("psi_T", psiOf(params.RingT().SubRings[0]))
 		f.u64s("roots_forward_q0_montgomery", ringQ.SubRings[0].RootsForward)
+		// the list the CLIENT generates keys for (fhe/ligero_test.go:53, cmd/client/main.go:81): expected
+		// rotations {1..n/2, n} plus the row swap iff n > N/2 -- log2(n)+1 resp. log2(N)+2 elements, in Go's map order
 		f.u64s("galois_elements_inner_sum_half", params.GaloisElementsForInnerSum(1, N/2))
 		f.u64s("galois_elements_inner_sum_full", params.GaloisElementsForInnerSum(1, N))
+		f.scalar("galois_count_half", uint64(len(params.GaloisElementsForInnerSum(1, N/2))))
+		f.scalar("galois_count_full", uint64(len(params.GaloisElementsForInnerSum(1, N))))
+		f.scalar("galois_element_row_swap", params.GaloisElementForRowRotation())
+		// serialised sizes behind "Marshaled keys length" (cmd/client/main.go:87-132): pk, rlk, one Galois key
+		pkBytes, err := pk.MarshalBinary()
+		must(err)
+		rlk := kgen.GenRelinearizationKeyNew(sk)
+		rlkBytes, err := rlk.MarshalBinary()
+		must(err)
+		gk0 := kgen.GenGaloisKeyNew(params.GaloisElement(1), sk)
+		gkBytes, err := gk0.MarshalBinary()
+		must(err)
+		f.scalar("pk_marshal_len", uint64(len(pkBytes)))
+		f.scalar("rlk_marshal_len", uint64(len(rlkBytes)))
+		f.scalar("galois_key_marshal_len", uint64(len(gkBytes)))
+		f.u64s("rlk.shape", []uint64{uint64(len(rlk.Value)), uint64(len(rlk.Value[0])), uint64(rlk.BaseTwoDecomposition)})
+		if *keySizes { // the whole KeysRequest as the client posts it, for n = N/2 and n = N (heavy at real sizes)
+			for _, n := range []int{N / 2, N} {
+				gks := kgen.GenGaloisKeysNew(params.GaloisElementsForInnerSum(1, n), sk)
+				rot := make([][]byte, len(gks))
+				for i, k := range gks {
+					rot[i], err = k.MarshalBinary()
+					must(err)
+				}
+				body, err := json.Marshal(struct {
+					PublicKey          []byte                 `json:"public_key"`
+					RelinearizationKey []byte                 `json:"relinearization_key"`
+					RotationKeys       [][]byte               `json:"rotation_keys"`
+					RingSwitchEvk      []byte                 `json:"ring_switch_evk"`
+					ParamsLit          *bgv.ParametersLiteral `json:"params_lit"`
+				}{PublicKey: pkBytes, RelinearizationKey: rlkBytes, RotationKeys: rot})
+				must(err)
+				f.scalar(fmt.Sprintf("keys_request_len_n%d", n), uint64(len(body)))
+				fmt.Printf("Marshaled keys length (rows = %d): %d bytes\n", n, len(body))
+			}
+		}
 		field, err := core.NewPrimeField(params.PlaintextModulus(), 2*(*cols))
 		must(err)
 		roots := make([]uint64, field.N())
@@ -318,6 +358,26 @@ func main() {
 		f.polys("plaintext", rPt.Value)
 		col, err := ev.MulNew(ct, rPt)
 		must(err)
+		if n == N {
+			// where does the row swap sit?  Both orders decrypt to the same slots but differ bit for bit:
+			//   A: InnerSum over the N/2 columns first, then + RotateRows        (what this repository restates)
+			//   B: ct + RotateRows(ct) first, then InnerSum over the N/2 columns
+			// plus the intermediate after the last column rotation of A
+			a := col.CopyNew()
+			must(ev.InnerSum(a, 1, N/2, a))
+			f.ct("cols_only", a)
+			ar, err := ev.RotateRowsNew(a)
+			must(err)
+			f.ct("rows_of_cols", ar)
+			must(ev.Add(a, ar, a))
+			f.ct("cand_cols_then_rows", a)
+			b := col.CopyNew()
+			br, err := ev.RotateRowsNew(b)
+			must(err)
+			must(ev.Add(b, br, b))
+			must(ev.InnerSum(b, 1, N/2, b))
+			f.ct("cand_rows_then_cols", b)
+		}
 		must(ev.InnerSum(col, 1, n, col))
 		f.ct("inner_sum", col)
 		for col.Level() > 1 {
@@ -354,7 +414,51 @@ func main() {
 		must(eval.ApplyEvaluationKey(level1, rsEvk, ct2))
 		f.ct("out", ct2)
 		f.polysQP("sk_small", skNew.Value)
+		f.scalar("level_p", uint64(lvlP))
+		rsBytes, err := rsEvk.MarshalBinary()
+		must(err)
+		f.scalar("key_marshal_len", uint64(len(rsBytes))) // the "+ 5 / 7 / 15 / 29 MB" of the experimental key-size logs
 		f.save(*out, "ringswitch.lmfx")
+	}
+	// ---- ringswitch_nop.lmfx: TestRingSwitch's own parameters (fhe/ring_switch_test.go:13-77): LogQ = [58], NO
+	// special prime, T = 0x3ee0001, same ring degree; the key then has LevelP = -1 and ApplyEvaluationKey takes
+	// the bit-decomposed gadget product (no ModDown)
+	{
+		p2, err := bgv.NewParametersFromLiteral(bgv.ParametersLiteral{LogN: *logN, LogQ: []int{58}, PlaintextModulus: 0x3ee0001})
+		must(err)
+		kg2 := rlwe.NewKeyGenerator(p2)
+		sk2, pk2 := kg2.GenKeyPairNew()
+		enc2 := bgv.NewEncoder(p2)
+		m := []uint64{1, 1}
+		pt2 := bgv.NewPlaintext(p2, p2.MaxLevel())
+		pt2.IsBatched = true
+		must(enc2.Encode(m, pt2))
+		ct0, err := rlwe.NewEncryptor(p2, pk2).EncryptNew(pt2)
+		must(err)
+		pNew, err := bgv.NewParametersFromLiteral(bgv.ParametersLiteral{
+			LogN: *logN, Q: []uint64{p2.Q()[0]}, P: []uint64{}, PlaintextModulus: p2.PlaintextModulus(),
+		})
+		must(err)
+		skNew := rlwe.NewKeyGenerator(pNew).GenSecretKeyNew()
+		lvlQ, lvlP, base := p2.MaxLevel(), p2.MaxLevelP(), 13
+		rsEvk := kg2.GenEvaluationKeyNew(sk2, skNew, rlwe.EvaluationKeyParameters{LevelQ: &lvlQ, LevelP: &lvlP, BaseTwoDecomposition: &base})
+		f := newFile()
+		f.scalar("logN", uint64(*logN))
+		f.u64s("Q", p2.Q())
+		f.scalar("T", p2.PlaintextModulus())
+		f.scalar("psi_q0", psiOf(p2.RingQ().SubRings[0]))
+		f.scalar("level_p", uint64(int64(lvlP))) // -1 as two's complement
+		f.evk("key", rsEvk)
+		f.scalar("keys_montgomery", 1)
+		f.ct("in", ct0)
+		ct2 := rlwe.NewCiphertext(pNew, 1, pNew.MaxLevel())
+		must(bgv.NewEvaluator(p2, nil).ApplyEvaluationKey(ct0, rsEvk, ct2))
+		f.ct("out", ct2)
+		f.polys("sk_new", skNew.Value.Q)
+		dec := make([]uint64, len(m))
+		must(bgv.NewEncoder(pNew).Decode(rlwe.NewDecryptor(pNew, skNew).DecryptNew(ct2), dec))
+		f.u64s("decoded", dec)
+		f.save(*out, "ringswitch_nop.lmfx")
 	}
 	_ = L
 	dumpFHE(*out, params, sk, pk, encoder, encryptor) // no-op unless built with -tags withfhe

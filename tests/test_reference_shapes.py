@@ -258,3 +258,48 @@ def test_plain_prover_on_the_device(oracle, rows, cols):
     idx = np.array([3, S - 1, 3, 0], dtype=np.uint32)
     assert np.array_equal(ctx.gather(enc, idx).download().reshape(4, rows), want.T[idx])
     ctx.close()
+
+
+def test_wire_image_of_more_than_one_chunk_at_headline_size(oracle, config):
+    """lumen_ct_serialize assembles the wire image in device chunks of 512 MiB: 1100 level-1 ciphertexts at
+    N = 2^14 (577 MB, two chunks) in a format of odd lengths, straight into page-locked memory and through the
+    pageable path, against bytes assembled here from the downloaded residues.  (The proof of the headline
+    configuration is 4.46 GB: nine chunks for MatR alone.)"""
+    from lumenos_amd.hip import pinned_bytes
+    name, P, ctx, _ = config
+    if not name.startswith("D_"):
+        pytest.skip("one large case is enough")
+    count, nl = 1100, 2
+    head, poly, limb = b"H" * 281 + (2).to_bytes(8, "little"), b"p" * 7, b"l" * 3
+    s = ctx.new_set(count, nl).fill_random(77)
+    try:
+        ctx.leaf_format_set(head, poly, limb)
+        each = ctx.ct_serialized_size(nl)
+        assert each == len(head) + 2 * (len(poly) + nl * (len(limb) + 8 * P.N)) and count * each > (512 << 20)
+        host = s.download()
+        want = np.empty((count, each), dtype=np.uint8)
+        want[:, :len(head)] = np.frombuffer(head, dtype=np.uint8)
+        off = len(head)
+        for k in range(2):
+            want[:, off:off + len(poly)] = np.frombuffer(poly, dtype=np.uint8)
+            off += len(poly)
+            for l in range(nl):
+                want[:, off:off + len(limb)] = np.frombuffer(limb, dtype=np.uint8)
+                off += len(limb)
+                want[:, off:off + 8 * P.N] = host[:, k, l, :].astype("<u8").view(np.uint8).reshape(count, 8 * P.N)
+                off += 8 * P.N
+        assert off == each
+        buf = pinned_bytes(count * each)
+        ctx.ct_serialize_into(s, buf, wait=False)
+        ctx.sync()
+        assert np.array_equal(buf.reshape(count, each), want)
+        # one ciphertext against the oracle's serialiser, and the pageable path over a chunk boundary
+        assert buf[5 * each:6 * each].tobytes() == P.ct_serialize(host[5], (head, poly, limb))
+        per = (512 << 20) // each
+        assert ctx.ct_serialize(s, per - 2, 4) == want[per - 2:per + 2].tobytes()
+        pageable = np.zeros(count * each, dtype=np.uint8)
+        ctx.ct_serialize_into(s, pageable)
+        assert np.array_equal(pageable.reshape(count, each), want)
+    finally:
+        ctx.leaf_format_set()
+        s.free()

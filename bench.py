@@ -709,6 +709,31 @@ def main():
                         if sq.get("SQ_INSTS_VALU") else None,
                         "note": "VALU-bound integer kernel: the >= 50 % HBM target of north_star is not reachable at "
                                 "10 multiply-adds per 64-bit Shoup product; see DESIGN.md section 6"}
+    # ---- the plain limb transform north_star names (k_limb_ntt, no fused load/store work): steady-state rate on
+    # the resident input matrix (98 304 transforms per pass; the set is transformed and transformed back)
+    ntt_kernel = None
+    if world == 1 and not args.no_kernel_profile:
+        reps, n_tr = 12, job.matrix.count * 2 * job.L
+        rates = {}
+        job.ctx.set_ntt(job.matrix, False)
+        job.ctx.set_ntt(job.matrix, True)  # warm; leaves the residues as they were (bit-exact round trip)
+        for name, inv in (("forward", False), ("inverse", True)):
+            # forward then inverse restore the data, so alternate untimed passes of the other direction
+            total_ms = 0.0
+            for _ in range(reps):
+                if inv:
+                    job.ctx.set_ntt(job.matrix, False)
+                job.ctx.timer_start()
+                job.ctx.set_ntt(job.matrix, inv)
+                total_ms += job.ctx.timer_stop()
+                if not inv:
+                    job.ctx.set_ntt(job.matrix, True)
+            rates[name] = n_tr * reps / (total_ms * 1e-3)
+        ntt_kernel = {"kernel": "k_limb_ntt", "log_n": job.log_n, "limb_ntts_per_launch": n_tr,
+                      "forward_per_s": round(rates["forward"], 1), "inverse_per_s": round(rates["inverse"], 1),
+                      "forward_hbm_frac": round(rates["forward"] * 16.0 * job.N / 8e12, 4),
+                      "inverse_hbm_frac": round(rates["inverse"] * 16.0 * job.N / 8e12, 4),
+                      "ct_ntts_forward_per_s": round(rates["forward"] / (2 * job.L), 1)}
     io = None
     if world == 1 and not args.no_io:
         job.io_setup()
@@ -797,6 +822,7 @@ def main():
             "limb_ntts_reference_equiv_per_s": round(census / sec_per_step, 1),
             "ct_ntts_reference_equiv_per_s": round(census / sec_per_step / (2 * job.L), 1),
             "roofline": roofline,
+            "ntt_kernel": ntt_kernel,
             "kernels": stages,
         }
         if io:

@@ -1,5 +1,6 @@
 """Randomised differential run of the HIP path against the CPU oracle (developer tool, not collected
-by pytest): random ring degrees, limb counts, 1 or 2 special primes, random shapes.
+by pytest): random ring degrees, limb counts, 1 or 2 special primes, random shapes; the wire image and leaf
+digests in random serialisation formats; the ring switch with 0, 1 or 2 special primes into random degrees.
 
 usage: [FUZZ_LOGN=13,14] python tests/dev/fuzz_gpu.py [cases] [seed]
 """
@@ -79,7 +80,42 @@ def one_case(o, rng, case):
     got = ctx.encrypt_pk(pts, 2, seed, first).download()
     assert np.array_equal(got[1], P.encrypt_det(pk, pts[1], seed, first + 1)), (tag, "encrypt")
     what.append("encrypt")
+    # wire image of a random run of ciphertexts in a random serialisation format (any byte alignment)
+    lens = [int(rng.integers(0, 300)), int(rng.integers(0, 20)), int(rng.integers(0, 20))]
+    fmt = tuple(bytes(rng.integers(0, 256, size=k, dtype=np.uint8)) for k in lens)
+    nlw = int(rng.integers(1, num_q + 1))
+    c4 = random_cts(P, int(rng.integers(1, 6)), nlw, seed=case + 11)
+    s4 = ctx.upload(c4)
+    ctx.leaf_format_set(*fmt)
+    first_ct = int(rng.integers(0, c4.shape[0]))
+    want = b"".join(P.ct_serialize(c4[c], fmt) for c in range(first_ct, c4.shape[0]))
+    assert ctx.ct_serialize(s4, first_ct) == want, (tag, "wire", lens, nlw)
+    dig = ctx.leaf_digests(s4)
+    assert dig[0].tobytes() == o.sha256(P.ct_serialize(c4[0], fmt)), (tag, "leaf digest", lens)
+    ctx.leaf_format_set()
+    what.append(f"wire{lens}")
     ctx.close()
+    # ring switch on the gadget path the number of special primes selects (a context of its own: K = 0 too)
+    kp = int(rng.choice([0, 1, 2]))
+    T_small = 0x3EE0001
+    P2 = make_params(o, log_n, int(rng.integers(1, 4)), num_p=kp, T=T_small)
+    P2.seed(int(rng.integers(1, 2**31)))
+    ctx2 = make_context(P2)
+    sk2 = P2.keygen_secret()
+    pk2 = P2.keygen_public(sk2)
+    small = int(rng.choice([x for x in (8, 10, 11, 12, 13, 14) if x <= log_n]))
+    ctr = np.stack([P2.rescale_to_level1(P2.encrypt(pk2, P2.encode(rng.integers(0, T_small, size=P2.N, dtype=np.uint64))))
+                    for _ in range(2)])
+    sks = P2.keygen_secret_small(small)
+    key = P2.keygen_ringswitch(sk2, sks, small)
+    ctx2.load_ringswitch_key(small, key)
+    got = ctx2.ring_switch(ctx2.upload(ctr))
+    for c in range(2):
+        assert np.array_equal(got[c], P2.ring_switch(ctr[c], key, small)), (tag, "ring switch", kp, small, c)
+        assert np.array_equal(P2.decrypt_small_coeffs(sks, small, got[c]),
+                              P2.decrypt_big_coeffs_l0(sk2, ctr[c])[::P2.N >> small]), (tag, "ring switch decrypt", kp, small)
+    what.append(f"ringswitch(K={kp}->2^{small})")
+    ctx2.close()
     print(tag, "ok:", " ".join(what), flush=True)
 
 

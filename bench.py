@@ -216,6 +216,30 @@ class Job:
         self.io_ctx = self.ctx.clone()
         self.up_ctx = self.ctx.clone()
 
+    def encrypt_matrix(self):
+        """Server-side witness encryption (cmd/server/main.go:188-208): `cols` columns of `rows` slot
+        values from page-locked host memory -> Encoder.Encode + EncryptNew under pk on the device
+        (lumen_encrypt_values), result resident in HBM as Commit's input.  Seconds, best of 3."""
+        from lumenos_amd.hip import pinned_empty
+        ctx, P = self.ctx, self.P
+        rng = np.random.default_rng(5)
+        pk = np.stack([np.stack([rng.integers(0, q, size=self.N, dtype=np.uint64) for q in P.q + P.p]) for _ in range(2)])
+        ctx.load_public_key(pk)
+        ctx.encoder_set(lp.encoder_psi(P.T, P.log_n))
+        vals = pinned_empty((self.cols, self.rows))
+        vals[:] = rng.integers(0, P.T, size=(self.cols, self.rows), dtype=np.uint64)
+        seed = np.arange(32, dtype=np.uint8)
+        best = None
+        for _ in range(4):
+            ctx.sync()
+            t0 = time.perf_counter()
+            s_ = ctx.encrypt_values(vals, seed, 0)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            s_.free()
+            best = dt if best is None else min(best, dt)
+        return best
+
     def _marshal_tail(self, off, nodes, root):
         """Merkle paths + root behind the ciphertexts (ligero.go:694-700): host bytes, 309 x depth x 32"""
         depth = (self.S - 1).bit_length()
@@ -746,12 +770,16 @@ def main():
         runs = [job.step_io() for _ in range(2)]
         best = min(runs, key=lambda r: r["total_s"])
         want = hashlib_sha(job.wire)
+        enc_s = job.encrypt_matrix()
         job.step_io_fused()
         fused = min([job.step_io_fused() for _ in range(2)], key=lambda r: r["total_s"])
         assert hashlib_sha(job.wire) == want, "the fused order produced different proof bytes"
         gb_in = job.cols * 2 * job.L * job.N * 8 / 1e9
         io = {"marshal_s": round(marshal_s, 4), "io_inclusive_s": round(best["total_s"], 4),
               "io_inclusive_fused_order_s": round(fused["total_s"], 4),
+              # what precedes the metric in the reference's server (cmd/server/main.go:188-208, "Encrypt matrix":
+              # 66.84 s at 16384x4096): the raw witness columns from host memory, Encoder.Encode + EncryptNew on the device
+              "encrypt_matrix_s": round(enc_s, 4),
               "io": {"upload_s": round(best["upload_s"], 4), "marshal_tail_s": round(best["marshal_tail_s"], 4),
                      "upload_GB": round(gb_in, 2), "upload_GBps": round(gb_in / best["upload_s"], 1),
                      "proof_wire_GB": round(job.wire_len / 1e9, 3),

@@ -19,7 +19,7 @@ def main():
     ctx = Context(P.log_n, P.q, P.p, P.psi, P.T)
     L = len(P.q)
     rng = np.random.default_rng(1)
-    pk = np.stack([np.stack([rng.integers(0, q, size=P.N, dtype=np.uint64) for q in P.q]) for _ in range(2)])
+    pk = np.stack([np.stack([rng.integers(0, q, size=P.N, dtype=np.uint64) for q in P.q + P.p]) for _ in range(2)])  # over QP
     ctx.load_public_key(pk)
     seed = np.arange(32, dtype=np.uint8)
     ctx.encrypt_pk(None, 64, seed, 0).free()

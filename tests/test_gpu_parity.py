@@ -880,6 +880,26 @@ def test_error_paths_report_status_and_message(oracle, small):
     fresh.leaf_digests_begin(fresh.new_set(3, 2).fill_random(4))
     fails(lambda: fresh.leaf_digests_begin(fresh.new_set(3, 2).fill_random(5)), "already in flight")
     assert fresh.leaf_digests_end().shape == (3, 32)
+    # round-3 entry points: the asynchronous serialiser wants page-locked memory and a large enough buffer,
+    # tuning switches are a closed list, the ring switch needs its key and a supported target degree
+    import ctypes as C
+    from lumenos_amd.hip import pinned_bytes
+    u8p = C.POINTER(C.c_uint8)
+    each = fresh.ct_serialized_size(2)
+    fails(lambda: fresh.ct_serialize_into(s2, np.zeros(2 * each, dtype=np.uint8), wait=False), "page-locked")
+    buf = pinned_bytes(3 * each)
+    fails(lambda: fresh._ck(fresh.lib.lumen_ct_serialize(fresh.h, s2.h, 0, 2, buf.ctypes.data_as(u8p), each)), "too small")
+    fails(lambda: fresh._ck(fresh.lib.lumen_ct_serialize(fresh.h, s2.h, 1, 2, buf.ctypes.data_as(u8p), 3 * each)), "exceeds set")
+    fails(lambda: fresh.set_tuning("LUMEN_NO_SUCH_SWITCH", 1), "unknown tuning switch")
+    out = np.zeros(2 * 2 * 256, dtype=np.uint64)
+    fails(lambda: fresh._ck(fresh.lib.lumen_ring_switch(fresh.h, s2.h, out.ctypes.data_as(C.POINTER(C.c_uint64)))),
+          "no ring-switch key")
+    key = np.zeros(fresh.ringswitch_key_shape(), dtype=np.uint64)
+    fails(lambda: fresh.load_ringswitch_key(9, key), "not supported")
+    fails(lambda: fresh.load_ringswitch_key(P.logN + 1, key), "not supported")
+    key[0, 0, 0, 0, 0] = 2**63
+    fails(lambda: fresh.load_ringswitch_key(8, key), "out of range")
+    fresh.wait_for(fresh)  # waiting for oneself is a no-op, not a deadlock
     fresh.close()
 
 

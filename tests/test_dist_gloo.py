@@ -166,6 +166,11 @@ def test_lane_sharded_exchange_world4():
     _run_lane_world(4)
 
 
+def test_lane_sharded_exchange_world8():
+    """the world the 8-GPU node runs: 8 ranks, one input column and 8 lanes each"""
+    _run_lane_world(8)
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` as typed: the parent starts one rank per GPU under torch.distributed.run as a
     child process, relays its output and exits with its code.  Without a GPU here every rank stops at "needs a

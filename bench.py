@@ -270,6 +270,22 @@ class Job:
         assert off == self.wire_len
         return time.perf_counter() - t0
 
+    def unmarshal(self):
+        """EncryptedProof.UnmarshalBinary on the client's side of the wire (ligero.go:654-753): the image of the three
+        slices from page-locked memory back into HBM sets, taken apart on the device; returns seconds and checks
+        that the bytes come back as the residues they were made from."""
+        ctx = self.ctx
+        ctx.sync()
+        t0 = time.perf_counter()
+        off, sets = 11, []
+        for count in (self.cols, self.cols, self.queries):
+            n = count * self.ct1
+            sets.append(ctx.ct_deserialize(self.wire[off:off + n], count, 2))
+            off += n
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        return dt, sets
+
     def step_io(self, slices=8):
         """One step that starts with the input ciphertexts in (page-locked) host memory and ends with the proof's
         wire-format bytes there: upload (12.9 GB at D: one DMA, not overlappable in the fhe API's order -- Encode
@@ -764,6 +780,11 @@ def main():
         outs = job.step(keep=True)
         job.marshal(*outs)  # first touch of the wire image and the staging paths
         marshal_s = min(job.marshal(*outs) for _ in range(3))
+        unmarshal_s, back = job.unmarshal()
+        for a_, b_ in zip(outs[:3], back):  # the round trip of ligero_test.go:118-126, on the device
+            assert np.array_equal(a_.download(0, 2), b_.download(0, 2)) and np.array_equal(
+                a_.download(a_.count - 1, 1), b_.download(b_.count - 1, 1)), "unmarshalled ciphertexts differ"
+            b_.free()
         for s_ in outs[:3]:
             s_.free()
         job.step_io()  # warm-up
@@ -775,7 +796,8 @@ def main():
         fused = min([job.step_io_fused() for _ in range(2)], key=lambda r: r["total_s"])
         assert hashlib_sha(job.wire) == want, "the fused order produced different proof bytes"
         gb_in = job.cols * 2 * job.L * job.N * 8 / 1e9
-        io = {"marshal_s": round(marshal_s, 4), "io_inclusive_s": round(best["total_s"], 4),
+        io = {"marshal_s": round(marshal_s, 4), "unmarshal_s": round(unmarshal_s, 4),
+              "io_inclusive_s": round(best["total_s"], 4),
               "io_inclusive_fused_order_s": round(fused["total_s"], 4),
               # what precedes the metric in the reference's server (cmd/server/main.go:188-208, "Encrypt matrix":
               # 66.84 s at 16384x4096): the raw witness columns from host memory, Encoder.Encode + EncryptNew on the device

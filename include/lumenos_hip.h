@@ -180,6 +180,13 @@ int lumen_ct_serialize(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uin
                        size_t cap);
 int lumen_ct_serialize_async(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n, uint8_t *out,
                              size_t cap);
+/* The way back: EncryptedProof.ReadFrom (fhe/ligero.go:707-753: rlwe.Ciphertext.ReadFrom for every entry of MatR,
+ * MatZ and the queried columns).  `bytes`: n serialised ciphertexts of num_limbs limbs back to back in the current
+ * format (len = n * lumen_ct_serialized_size).  The image crosses PCIe as it is and is taken apart on the
+ * device into a new set -- what a client that owns a GPU feeds to lumen_decrypt.  The format's byte strings
+ * are compared with the image: any difference (another level or ring degree, a corrupt proof) is an error. */
+int lumen_ct_deserialize(lumen_ctx *ctx, const uint8_t *bytes, size_t len, uint32_t n, uint32_t num_limbs,
+                         lumen_set **out);
 
 /* ---- leaves of the commitment: serialize every ciphertext of a level-1 set in the current format
  * (ct.WriteTo, fhe/ligero.go:156-157) and SHA-256 it (core/tree.go:96-111).

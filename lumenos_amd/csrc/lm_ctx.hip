@@ -479,13 +479,10 @@ static int io_buffers(lumen_ctx *ctx) {
     return 0;
 }
 
-extern "C" int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, uint32_t n,
-                                const uint64_t *host) {
-    LM_CHECK(nullptr, ctx && set && host, "lumen_set_upload: NULL argument");
-    LM_ENTER(ctx);
-    LM_CHECK(ctx, (uint64_t)first + n <= set->count, "upload range [%u,%u) exceeds set of %u", first, first + n, set->count);
-    const size_t ctw = lm_ctw(ctx, set), bytes = (size_t)n * ctw * sizeof(u64);
-    char *dst = (char *)(set->d + (size_t)first * ctw);
+// host -> device on the context's stream; returns when `host` may be reused.  A page-locked source is handed
+// to the DMA engine as it is, a pageable one goes through the two bounce buffers.
+int lm_h2d(lumen_ctx *ctx, void *dev, const void *host, size_t bytes) {
+    char *dst = (char *)dev;
     if (bytes <= ((size_t)1 << 20) || lm_host_is_pinned(host)) {
         LM_HIP(ctx, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     } else {
@@ -501,6 +498,15 @@ extern "C" int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, 
     }
     LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `host` is caller memory
     return 0;
+}
+
+extern "C" int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, uint32_t n,
+                                const uint64_t *host) {
+    LM_CHECK(nullptr, ctx && set && host, "lumen_set_upload: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, (uint64_t)first + n <= set->count, "upload range [%u,%u) exceeds set of %u", first, first + n, set->count);
+    const size_t ctw = lm_ctw(ctx, set), bytes = (size_t)n * ctw * sizeof(u64);
+    return lm_h2d(ctx, set->d + (size_t)first * ctw, host, bytes);
 }
 
 // device -> host on the context's stream.  Pageable destinations: chunk k+1 crosses the link while the CPU

@@ -220,6 +220,82 @@ extern "C" int lumen_ct_serialize_async(lumen_ctx *ctx, const lumen_set *set, ui
     return serialize_run(ctx, set, first, n, out, cap, false, "lumen_ct_serialize_async");
 }
 
+// ---- the way back (EncryptedProof.ReadFrom, fhe/ligero.go:707-753, every ciphertext through ct.ReadFrom): a
+// client that owns a GPU uploads the proof's bytes as they arrived -- one DMA -- and the image is taken apart
+// on the device: the inverse of k_ct_wire, same work split.  The format's byte strings are compared with the
+// image on the way (a proof of another level / ring degree, or a corrupt one, must not become residues):
+// mismatching bytes are counted in *bad.
+__global__ __launch_bounds__(256) void k_ct_unwire(const uint8_t *__restrict__ wire, size_t each, uint32_t nl,
+                                                   uint32_t N, const leaf_fmt_t *__restrict__ fmt,
+                                                   u64 *__restrict__ set, unsigned int *__restrict__ bad) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t l = blockIdx.x % nl, k = (blockIdx.x / nl) & 1;
+    const size_t i = blockIdx.x / (2 * nl);
+    const u32 hl = fmt->head_len, pl = fmt->poly_len, ll = fmt->limb_len;
+    const size_t limb_span = (size_t)ll + (size_t)N * 8;
+    const size_t D = i * each + hl + (size_t)(k + 1) * pl + (size_t)k * nl * limb_span + (size_t)l * limb_span + ll;
+    unsigned int wrong = 0;
+    if (k == 0 && l == 0)
+        for (u32 t = tid; t < hl; t += 256) wrong += wire[i * each + t] != fmt->head[t];
+    if (l == 0)
+        for (u32 t = tid; t < pl; t += 256) wrong += wire[D - ll - pl + t] != fmt->poly[t];
+    for (u32 t = tid; t < ll; t += 256) wrong += wire[D - ll + t] != fmt->limb[t];
+    if (wrong) atomicAdd(bad, wrong);
+    u64 *dst = set + ((i * 2 + k) * nl + l) * (size_t)N;
+    const u32 a = (u32)(D & 7);
+    if (a == 0) {
+        const u64 *src = reinterpret_cast<const u64 *>(wire + D);
+        for (u32 m = tid; m < N; m += 256) dst[m] = src[m];
+        return;
+    }
+    // word m of the limb straddles the aligned words w[m] and w[m + 1] of the image, w[0] at D - a
+    const u64 *w = reinterpret_cast<const u64 *>(wire + D - a);
+    for (u32 m = tid; m < N; m += 256) dst[m] = (w[m] >> (8 * a)) | (w[m + 1] << (8 * (8 - a)));
+}
+
+int lm_h2d(lumen_ctx *ctx, void *dev, const void *host, size_t bytes);
+
+extern "C" int lumen_ct_deserialize(lumen_ctx *ctx, const uint8_t *bytes, size_t len, uint32_t n, uint32_t num_limbs,
+                                    lumen_set **out) {
+    LM_CHECK(nullptr, ctx && out && (bytes || !n), "lumen_ct_deserialize: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, num_limbs >= 1 && num_limbs <= ctx->L, "num_limbs %u out of range [1,%u]", num_limbs, ctx->L);
+    const LeafFormat f = current_format(ctx, num_limbs);
+    const uint32_t N = ctx->N;
+    const size_t each = serialized_size(f, num_limbs, N);
+    LM_CHECK(ctx, len == each * n, "%u serialised ciphertexts of %u limbs are %zu bytes in the current format, not %zu", n,
+             num_limbs, each * n, len);
+    lumen_set *o = nullptr;
+    if (int rc = lumen_set_create(ctx, n, num_limbs, &o)) return rc;
+    lm_set_guard og(ctx, o);
+    if (n) {
+        const leaf_fmt_t *fmt = nullptr;
+        if (upload_format(ctx, f, "wire_fmt", &fmt)) return 1;
+        unsigned int *bad = (unsigned int *)lm_scratch(ctx, "wire_bad", sizeof(unsigned int));
+        const uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, LM_WIRE_CHUNK / each));
+        // (+ 16: the kernel reads the aligned word behind the last limb's last byte)
+        uint8_t *wire = (uint8_t *)lm_scratch(ctx, "wire", (size_t)per * each + 16);
+        if (!wire || !bad) return 1;
+        LM_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(unsigned int), ctx->stream));
+        const size_t ctw = (size_t)2 * num_limbs * N;
+        for (uint32_t c0 = 0; c0 < n; c0 += per) {
+            const uint32_t cn = std::min(per, n - c0);
+            if (int rc = lm_h2d(ctx, wire, bytes + (size_t)c0 * each, (size_t)cn * each)) return rc;
+            lm_prof_scope ps(ctx, "ct_unwire", cn);
+            hipLaunchKernelGGL(k_ct_unwire, dim3(cn * 2 * num_limbs), dim3(256), 0, ctx->stream, wire, each, num_limbs, N,
+                               fmt, o->d + (size_t)c0 * ctw, bad);
+            LM_HIP(ctx, hipGetLastError());
+        }
+        unsigned int h_bad = 0;
+        LM_HIP(ctx, hipMemcpyAsync(&h_bad, bad, sizeof(h_bad), hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LM_CHECK(ctx, h_bad == 0, "%u bytes of the image differ from the serialisation format in force (another level or ring "
+                                  "degree, another MetaData block, or a corrupt proof)", h_bad);
+    }
+    *out = og.release();
+    return 0;
+}
+
 // One thread per leaf streams its ciphertext through SHA-256.  The format's byte strings have any
 // length, so the limb data sits at an arbitrary byte offset of the 64-byte blocks: words are
 // assembled with a byte shift (r bytes pending in `acc`) and staged in an LDS block buffer

@@ -74,6 +74,7 @@ SYMBOLS = {
     "lumen_ct_serialized_size": (C.c_size_t, [_vp, C.c_uint32]),
     "lumen_ct_serialize": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _u8p, C.c_size_t]),
     "lumen_ct_serialize_async": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _u8p, C.c_size_t]),
+    "lumen_ct_deserialize": (C.c_int, [_vp, _u8p, C.c_size_t, C.c_uint32, C.c_uint32, _vpp]),
     "lumen_leaf_digests": (C.c_int, [_vp, _vp, _u8p]),
     "lumen_load_public_key": (C.c_int, [_vp, _u64p]),
     "lumen_encrypt_pk": (C.c_int, [_vp, _u64p, C.c_uint32, _u8p, C.c_uint64, C.POINTER(_vp)]),
@@ -409,6 +410,14 @@ class Context:
         fn = self.lib.lumen_ct_serialize if wait else self.lib.lumen_ct_serialize_async
         self._ck(fn(self.h, s.h, first, n, C.cast(out.ctypes.data + offset, _u8p), size))
         return size
+
+    def ct_deserialize(self, blob, n, nl):
+        """n serialised ciphertexts of nl limbs (bytes, or a uint8 array -- page-locked for one DMA) -> a set"""
+        a = np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, (bytes, bytearray, memoryview)) else blob
+        assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_ct_deserialize(self.h, C.cast(a.ctypes.data, _u8p), a.size, n, nl, C.byref(h)))
+        return DeviceSet(self, h)
 
     def leaf_digests(self, s):
         out = np.zeros((s.count, 32), dtype=np.uint8)

@@ -701,6 +701,44 @@ void EncryptedProof::MarshalInto(uint8_t *out, size_t cap, bool pageLocked) cons
     }
 }
 
+EncryptedProof EncryptedProof::UnmarshalBinary(const uint8_t *data, size_t len, ServerBFV &backend, const MetaData &meta) {
+    if (len < 11 + 32) throw std::invalid_argument("UnmarshalBinary: too short");
+    EncryptedProof p;
+    auto le = [&](size_t at, int n) {
+        uint64_t v = 0;
+        for (int i = 0; i < n; i++) v |= (uint64_t)data[at + i] << (8 * i);
+        return v;
+    };
+    p.Metadata = {(int)le(0, 4), (int)le(4, 4), (int)le(8, 1), (int)le(9, 2)}; // LigeroMetadata.ReadFrom (ligero.go:763-778)
+    p.PlaintextModulus = backend.GetParameters().T;
+    lumen_ctx *ctx = backend.Context();
+    SetCiphertextFormat(backend, meta, 1);
+    const size_t each = lumen_ct_serialized_size(ctx, 2);
+    size_t off = 11;
+    auto take = [&](int count) {
+        const size_t bytes = each * (size_t)count;
+        if (off + bytes > len) throw std::invalid_argument("UnmarshalBinary: truncated ciphertext slice");
+        lumen_set *s = nullptr;
+        backend.check(lumen_ct_deserialize(ctx, data + off, bytes, (uint32_t)count, 2, &s), "lumen_ct_deserialize");
+        off += bytes;
+        return Ciphertexts(ctx, s, meta);
+    };
+    p.MatR = take(p.Metadata.Cols);      // ligero.go:712-718
+    p.MatZ = take(p.Metadata.Cols);      // ligero.go:720-726
+    p.QueriedCols = take(p.Metadata.Queries); // ligero.go:728-734
+    const int merkleLen = p.Metadata.Cols * p.Metadata.RhoInv; // ligero.go:736-739
+    int depth = 0;
+    while ((1 << depth) < merkleLen) depth++;
+    if (off + (size_t)p.Metadata.Queries * depth * 32 + 32 != len) throw std::invalid_argument("UnmarshalBinary: length mismatch");
+    for (int q = 0; q < p.Metadata.Queries; q++) {
+        std::vector<core::Digest> path((size_t)depth);
+        for (auto &d : path) memcpy(d.data(), data + off, 32), off += 32;
+        p.MerklePaths.push_back(std::move(path));
+    }
+    p.Root.assign(data + off, data + off + 32);
+    return p;
+}
+
 std::vector<uint8_t> EncryptedProof::MarshalBinary() const {
     std::vector<uint8_t> buf(MarshaledSize());
     MarshalInto(buf.data(), buf.size(), false);

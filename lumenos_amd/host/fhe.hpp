@@ -211,6 +211,11 @@ struct EncryptedProof { // fhe/ligero.go:185-192
     void MarshalInto(uint8_t *out, size_t cap, bool pageLocked) const;
     std::vector<uint8_t> MarshalBinary() const; // pageable memory: bounce-buffered, slower
     WireBuffer MarshalBinaryPinned() const;     // page-locked memory: the fast path
+    // EncryptedProof.UnmarshalBinary / ReadFrom (ligero.go:654-753): the three slices' images go to the device
+    // as they are (lumen_ct_deserialize takes them apart there and checks the framing); level-1 ciphertexts of
+    // the backend's parameters (a ring-switched proof is read by the client's small-ring parameters, not here).
+    // `meta`: the MetaData the ciphertexts carry (what SetCiphertextFormat frames them with).
+    static EncryptedProof UnmarshalBinary(const uint8_t *data, size_t len, ServerBFV &backend, const MetaData &meta);
 };
 
 class LigeroCommitter;

@@ -162,6 +162,25 @@ int main(int argc, char **argv) {
             "MarshalBinaryPinned and MarshalBinary disagree");
     const size_t ct1 = lo_ct_serialized_size_fmt(&fmt, 2, (uint32_t)N);
     REQUIRE(ct1 == json.size() + 8 + 2 * (8 + 2 * (8 + (size_t)N * 8)), "serialised size");
+    if (!ringSwitchLogN) {
+        // ligero_test.go:118-126: UnmarshalBinary of the marshaled proof gives the same proof back -- the images
+        // of the three slices are taken apart on the device
+        fhe::EncryptedProof back = fhe::EncryptedProof::UnmarshalBinary(wire.data(), wire.size(), server, proof.QueriedCols.Meta);
+        REQUIRE(back.Metadata.Rows == rows && back.Metadata.Cols == cols && back.Metadata.RhoInv == rhoInv &&
+                    back.Metadata.Queries == 309, "unmarshaled metadata");
+        REQUIRE(back.MatR.Download() == proof.MatR.Download() && back.MatZ.Download() == proof.MatZ.Download() &&
+                    back.QueriedCols.Download() == proof.QueriedCols.Download(), "unmarshaled ciphertexts differ");
+        REQUIRE(back.Root == proof.Root && back.MerklePaths == proof.MerklePaths, "unmarshaled root / paths differ");
+        std::vector<uint8_t> broken(marshaled);
+        broken[11 + 5] ^= 0x20; // a byte of the first ciphertext's MetaData block
+        bool refused = false;
+        try {
+            fhe::EncryptedProof::UnmarshalBinary(broken.data(), broken.size(), server, proof.QueriedCols.Meta);
+        } catch (const std::exception &e) {
+            refused = strstr(e.what(), "differ from the serialisation format") != nullptr;
+        }
+        REQUIRE(refused, "a proof with a damaged framing must be refused");
+    }
     const size_t nSmall = ringSwitchLogN ? (size_t)1 << ringSwitchLogN : 0;
     const size_t ct0 = json.size() + 8 + 2 * (8 + 8 + nSmall * 8); // a ring-switched ciphertext: level 0, degree n
     const size_t ctR = ringSwitchLogN ? ct0 : ct1;

@@ -157,6 +157,18 @@ def test_leaf_format_any_byte_alignment(oracle, small, lens):
             # the wire image of the whole slice -- what EncryptedProof.WriteTo emits for MatR (ligero.go:664-671) --
             # is assembled on the device: every ciphertext starts where the previous one ends, at any alignment
             assert ctx.ct_serialize(s) == b"".join(want)
+            # and back (ct.ReadFrom for a whole slice): the image taken apart on the device, framing checked
+            back = ctx.ct_deserialize(b"".join(want), 67, nl)
+            assert np.array_equal(back.download(), cts)
+            if sum(lens):
+                from lumenos_amd.hip import LumenError
+                bad = bytearray(b"".join(want))
+                pos = 5 * len(want[0]) + (0 if lens[0] else len(want[0]) - 8 * P.N - 1)  # a header byte of ciphertext 5
+                bad[pos] ^= 0x01
+                with pytest.raises(LumenError, match="differ from the serialisation format"):
+                    ctx.ct_deserialize(bytes(bad), 67, nl)
+            with pytest.raises(Exception, match="bytes in the current format"):
+                ctx.ct_deserialize(b"".join(want)[:-1], 67, nl)
             # ... and the asynchronous form into page-locked memory at an odd offset, on a clone's stream
             from lumenos_amd.hip import pinned_bytes
             each = ctx.ct_serialized_size(nl)

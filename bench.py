@@ -784,6 +784,20 @@ def main():
         for a_, b_ in zip(outs[:3], back):  # the round trip of ligero_test.go:118-126, on the device
             assert np.array_equal(a_.download(0, 2), b_.download(0, 2)) and np.array_equal(
                 a_.download(a_.count - 1, 1), b_.download(b_.count - 1, 1)), "unmarshalled ciphertexts differ"
+        # the client's "Decrypt proof" (EncryptedProof.Decrypt, ligero.go:381-502: slot 0 of every MatR / MatZ
+        # ciphertext, all `rows` slots of the 309 opened columns; 48.05 s on the reference's client at this shape)
+        rng_k = np.random.default_rng(6)
+        job.ctx.load_secret_key(np.stack([rng_k.integers(0, q, size=job.N, dtype=np.uint64) for q in job.P.q]))
+        job.ctx.encoder_set(lp.encoder_psi(job.P.T, job.P.log_n))
+        job.ctx.decrypt(back[2], job.rows)
+        decrypt_s = None
+        for _ in range(3):
+            job.ctx.sync()
+            t0_ = time.perf_counter()
+            job.ctx.decrypt(back[0], 1), job.ctx.decrypt(back[1], 1), job.ctx.decrypt(back[2], job.rows)
+            dt_ = time.perf_counter() - t0_
+            decrypt_s = dt_ if decrypt_s is None else min(decrypt_s, dt_)
+        for b_ in back:
             b_.free()
         for s_ in outs[:3]:
             s_.free()
@@ -797,6 +811,8 @@ def main():
         assert hashlib_sha(job.wire) == want, "the fused order produced different proof bytes"
         gb_in = job.cols * 2 * job.L * job.N * 8 / 1e9
         io = {"marshal_s": round(marshal_s, 4), "unmarshal_s": round(unmarshal_s, 4),
+              # client side of the wire, for a client that owns a GPU: unmarshal_s above + this = "Decrypt proof"
+              "decrypt_proof_s": round(decrypt_s, 4),
               "io_inclusive_s": round(best["total_s"], 4),
               "io_inclusive_fused_order_s": round(fused["total_s"], 4),
               # what precedes the metric in the reference's server (cmd/server/main.go:188-208, "Encrypt matrix":

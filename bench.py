@@ -644,6 +644,162 @@ def timed_steps(job, dist, steps, warmup, barrier):
     return (time.perf_counter() - t0) / steps
 
 
+def profile_kernels(job, dist, cfg):
+    """Dominant-kernel roofline: one more (untimed) step with HIP events around every launch on the context's
+    stream.  Returns (roofline, per-kernel table, limb transforms executed in the step)."""
+    job.ctx.prof_reset()
+    job.ctx.prof_enable(True)
+    job.step(dist)
+    job.ctx.prof_enable(False)
+    tab = {k: job.ctx.prof_read(k) for k in job.ctx.prof_names()}
+    pmc = pmc_table(cfg)
+    stages = {}
+    for k, (ms, launches, units) in sorted(tab.items()):
+        e = {"ms": round(ms, 3), "launches": launches, "units": units}
+        ab = algorithmic_bytes(job, k, launches, units)
+        if ab and ms > 0:  # SURVEY 8d bytes / HIP-event time of the launches, against the 8 TB/s HBM peak
+            e["alg_gbps"] = round(ab / (ms * 1e-3) / 1e9, 1)
+            e["hbm_frac"] = round(ab / (ms * 1e-3) / 8e12, 4)
+        stages[k] = e
+    ntt_kernels = {k: v for k, v in tab.items() if k in NTT_KERNELS}
+    executed = sum(v[2] for v in ntt_kernels.values())
+    roofline = None
+    if ntt_kernels:
+        dom = max(ntt_kernels, key=lambda k: ntt_kernels[k][0])
+        ms, launches, units = ntt_kernels[dom]
+        alg_bytes_per_launch = 16.0 * job.N * units / launches  # 16*N B per limb transform (SURVEY 8d)
+        achieved = alg_bytes_per_launch / (ms / launches * 1e-3) / 1e9
+        pe = pmc_entry(pmc, dom)
+        sq = (pe or {}).get("sq_per_launch") or {}
+        bfly = units / launches * job.N / 2 * job.log_n  # butterflies of one launch
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                    "traffic": round(pe["hbm_bytes_per_launch"]) if pe and pe.get("hbm_bytes_per_launch") else None,
+                    "avg_launch_ms": round(ms / launches, 4), "limb_ntts_per_launch": units // launches,
+                    # what actually bounds the kernel: 64-bit modular butterflies on the VALU (no MFMA).  From
+                    # the committed SQ counters of this build (null if the profile is of another build):
+                    # fraction of SIMD cycles issuing VALU work, and wave-level VALU instructions per butterfly
+                    "valu_frac": round(pe["valu_busy_frac"], 4) if pe and pe.get("valu_busy_frac") else None,
+                    "valu_insts_per_butterfly": round(sq["SQ_INSTS_VALU"] * 64.0 / bfly, 2)
+                    if sq.get("SQ_INSTS_VALU") else None,
+                    "note": "VALU-bound integer kernel: the >= 50 % HBM target of north_star is not reachable at "
+                            "10 multiply-adds per 64-bit Shoup product; see DESIGN.md section 6"}
+    return roofline, stages, executed
+
+
+def plain_ntt_rates(job):
+    """The plain limb transform north_star names (k_limb_ntt, no fused load/store work): steady-state rate on the
+    resident input matrix (98 304 transforms per pass at D; the set is transformed and transformed back, so the
+    residues are left as they were)."""
+    reps, n_tr = 12, job.matrix.count * 2 * job.L
+    rates = {}
+    job.ctx.set_ntt(job.matrix, False)
+    job.ctx.set_ntt(job.matrix, True)  # warm; a bit-exact round trip
+    for name, inv in (("forward", False), ("inverse", True)):
+        total_ms = 0.0
+        for _ in range(reps):  # untimed passes of the other direction in between restore the data
+            if inv:
+                job.ctx.set_ntt(job.matrix, False)
+            job.ctx.timer_start()
+            job.ctx.set_ntt(job.matrix, inv)
+            total_ms += job.ctx.timer_stop()
+            if not inv:
+                job.ctx.set_ntt(job.matrix, True)
+        rates[name] = n_tr * reps / (total_ms * 1e-3)
+    return {"kernel": "k_limb_ntt", "log_n": job.log_n, "limb_ntts_per_launch": n_tr,
+            "forward_per_s": round(rates["forward"], 1), "inverse_per_s": round(rates["inverse"], 1),
+            "forward_hbm_frac": round(rates["forward"] * 16.0 * job.N / 8e12, 4),
+            "inverse_hbm_frac": round(rates["inverse"] * 16.0 * job.N / 8e12, 4),
+            "ct_ntts_forward_per_s": round(rates["forward"] / (2 * job.L), 1)}
+
+
+def io_leg(job, cfg):
+    """What surrounds the metric on a real server and client, measured (never `value`): Marshal / Unmarshal of the
+    proof, the client's Decrypt proof, the server's Encrypt matrix, and whole steps that start and end in host
+    memory."""
+    job.io_setup()
+    outs = job.step(keep=True)
+    job.marshal(*outs)  # first touch of the wire image and the staging paths
+    marshal_s = min(job.marshal(*outs) for _ in range(3))
+    unmarshal_s, back = job.unmarshal()
+    for a_, b_ in zip(outs[:3], back):  # the round trip of ligero_test.go:118-126, on the device
+        assert np.array_equal(a_.download(0, 2), b_.download(0, 2)) and np.array_equal(
+            a_.download(a_.count - 1, 1), b_.download(b_.count - 1, 1)), "unmarshalled ciphertexts differ"
+    # the client's "Decrypt proof" (EncryptedProof.Decrypt, ligero.go:381-502: slot 0 of every MatR / MatZ
+    # ciphertext, all `rows` slots of the 309 opened columns; 48.05 s on the reference's client at this shape)
+    rng_k = np.random.default_rng(6)
+    job.ctx.load_secret_key(np.stack([rng_k.integers(0, q, size=job.N, dtype=np.uint64) for q in job.P.q]))
+    job.ctx.encoder_set(lp.encoder_psi(job.P.T, job.P.log_n))
+    job.ctx.decrypt(back[2], job.rows)
+    decrypt_s = None
+    for _ in range(3):
+        job.ctx.sync()
+        t0_ = time.perf_counter()
+        job.ctx.decrypt(back[0], 1), job.ctx.decrypt(back[1], 1), job.ctx.decrypt(back[2], job.rows)
+        dt_ = time.perf_counter() - t0_
+        decrypt_s = dt_ if decrypt_s is None else min(decrypt_s, dt_)
+    for b_ in back:
+        b_.free()
+    for s_ in outs[:3]:
+        s_.free()
+    job.step_io()  # warm-up
+    runs = [job.step_io() for _ in range(2)]
+    best = min(runs, key=lambda r: r["total_s"])
+    want = hashlib_sha(job.wire)
+    enc_s = job.encrypt_matrix()
+    job.step_io_fused()
+    fused = min([job.step_io_fused() for _ in range(2)], key=lambda r: r["total_s"])
+    assert hashlib_sha(job.wire) == want, "the fused order produced different proof bytes"
+    gb_in = job.cols * 2 * job.L * job.N * 8 / 1e9
+    return {"marshal_s": round(marshal_s, 4), "unmarshal_s": round(unmarshal_s, 4),
+          # client side of the wire, for a client that owns a GPU: unmarshal_s above + this = "Decrypt proof"
+          "decrypt_proof_s": round(decrypt_s, 4),
+          "io_inclusive_s": round(best["total_s"], 4),
+          "io_inclusive_fused_order_s": round(fused["total_s"], 4),
+          # what precedes the metric in the reference's server (cmd/server/main.go:188-208, "Encrypt matrix":
+          # 66.84 s at 16384x4096): the raw witness columns from host memory, Encoder.Encode + EncryptNew on the device
+          "encrypt_matrix_s": round(enc_s, 4),
+          "io": {"upload_s": round(best["upload_s"], 4), "marshal_tail_s": round(best["marshal_tail_s"], 4),
+                 "upload_GB": round(gb_in, 2), "upload_GBps": round(gb_in / best["upload_s"], 1),
+                 "proof_wire_GB": round(job.wire_len / 1e9, 3),
+                 "marshal_GBps": round(job.wire_len / 1e9 / marshal_s, 1),
+                 "reference_marshal_s": {"16384x4096": 2.254, "8192x4096": 1.135, "4096x2048": 0.347,
+                                         "2048x1024": 0.156}.get(cfg),  # results/baseline/server/bench_*.txt:34
+                 "note": "marshal_s: EncryptedProof.MarshalBinary of results resident in HBM -- wire images of MatR, "
+                         "MatZ and the queried columns assembled on the device (k_ct_wire), one DMA each into "
+                         "page-locked memory, Merkle paths + root appended (the reference's 'Marshal proof' span). "
+                         "io_inclusive_s: input ciphertexts from page-locked host memory (one DMA, not overlappable "
+                         "in the fhe API's order: Encode needs every column), the step, and the same marshalling "
+                         "overlapped with it on a clone context (column slices, lumen_ctx_wait); ends with the "
+                         "proof's wire bytes in host memory. io_inclusive_fused_order_s: the same bytes (checked) in "
+                         "the order a server that owns the whole request can use -- Prove's challenges do not depend "
+                         "on the Merkle root (ligero.go:198-199), so the inner products of a column slice start when "
+                         "it lands and Encode runs once the last one has: the upload hides behind compute"}}
+
+
+def other_configs(job, args, sec_per_step, local_rank, barrier):
+    """Short passes over the other BASELINE.json configurations, so that the driver's one command attests them."""
+    others = {}
+    if args.config == "16384x4096":  # BASELINE config 5 on the resident job: + RingSwitchNew -> LogN = 10
+        job.enable_ring_switch(10)
+        sec = timed_steps(job, None, args.other_steps, 1, barrier)
+        others["16384x4096+ring-switch->LogN=10"] = {
+            "value": round(sec, 4), "unit": "s", "steps": args.other_steps,
+            "reference_s": 417.6, "ring_switch_added_s": round(sec - sec_per_step, 4)}
+        job.ring_switch_logn = 0
+    main_ctx = job.ctx
+    for cfg in ("2048x1024", "4096x2048", "8192x4096"):
+        if cfg == args.config:
+            continue
+        oj = Job(cfg, 0, 1, local_rank)
+        sec = timed_steps(oj, None, args.other_steps, 1, lambda: oj.ctx.sync())
+        others[cfg] = {"value": round(sec, 4), "unit": "s", "steps": args.other_steps,
+                       "reference_s": PUBLISHED_SECONDS[cfg], "L": oj.L, "LogN": oj.log_n}
+        oj.close()
+    assert job.ctx is main_ctx
+    return others
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -710,150 +866,12 @@ def main():
         elapsed = float(t.item())
     sec_per_step = elapsed / args.steps
 
-    # ---- dominant-kernel roofline: one more (untimed) step with HIP events around every launch
-    roofline, stages, executed = None, None, None
-    if not args.no_kernel_profile:
-        job.ctx.prof_reset()
-        job.ctx.prof_enable(True)
-        job.step(dist)
-        job.ctx.prof_enable(False)
-        tab = {k: job.ctx.prof_read(k) for k in job.ctx.prof_names()}
-        pmc = pmc_table(args.config)
-        stages = {}
-        for k, (ms, launches, units) in sorted(tab.items()):
-            e = {"ms": round(ms, 3), "launches": launches, "units": units}
-            ab = algorithmic_bytes(job, k, launches, units)
-            if ab and ms > 0:  # SURVEY 8d bytes / HIP-event time of the launches, against the 8 TB/s HBM peak
-                e["alg_gbps"] = round(ab / (ms * 1e-3) / 1e9, 1)
-                e["hbm_frac"] = round(ab / (ms * 1e-3) / 8e12, 4)
-            stages[k] = e
-        ntt_kernels = {k: v for k, v in tab.items() if k in NTT_KERNELS}
-        executed = sum(v[2] for v in ntt_kernels.values())
-        if ntt_kernels:
-            dom = max(ntt_kernels, key=lambda k: ntt_kernels[k][0])
-            ms, launches, units = ntt_kernels[dom]
-            alg_bytes_per_launch = 16.0 * job.N * units / launches  # 16*N B per limb transform
-            achieved = alg_bytes_per_launch / (ms / launches * 1e-3) / 1e9
-            pe = pmc_entry(pmc, dom)
-            sq = (pe or {}).get("sq_per_launch") or {}
-            bfly = units / launches * job.N / 2 * job.log_n  # butterflies of one launch
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                        "traffic": round(pe["hbm_bytes_per_launch"]) if pe and pe.get("hbm_bytes_per_launch") else None,
-                        "avg_launch_ms": round(ms / launches, 4), "limb_ntts_per_launch": units // launches,
-                        # what actually bounds the kernel: 64-bit modular butterflies on the VALU (no MFMA).  From
-                        # the committed SQ counters of this build (null if the profile is of another build):
-                        # fraction of SIMD cycles issuing VALU work, and wave-level VALU instructions per butterfly
-                        "valu_frac": round(pe["valu_busy_frac"], 4) if pe and pe.get("valu_busy_frac") else None,
-                        "valu_insts_per_butterfly": round(sq["SQ_INSTS_VALU"] * 64.0 / bfly, 2)
-                        if sq.get("SQ_INSTS_VALU") else None,
-                        "note": "VALU-bound integer kernel: the >= 50 % HBM target of north_star is not reachable at "
-                                "10 multiply-adds per 64-bit Shoup product; see DESIGN.md section 6"}
-    # ---- the plain limb transform north_star names (k_limb_ntt, no fused load/store work): steady-state rate on
-    # the resident input matrix (98 304 transforms per pass; the set is transformed and transformed back)
-    ntt_kernel = None
-    if world == 1 and not args.no_kernel_profile:
-        reps, n_tr = 12, job.matrix.count * 2 * job.L
-        rates = {}
-        job.ctx.set_ntt(job.matrix, False)
-        job.ctx.set_ntt(job.matrix, True)  # warm; leaves the residues as they were (bit-exact round trip)
-        for name, inv in (("forward", False), ("inverse", True)):
-            # forward then inverse restore the data, so alternate untimed passes of the other direction
-            total_ms = 0.0
-            for _ in range(reps):
-                if inv:
-                    job.ctx.set_ntt(job.matrix, False)
-                job.ctx.timer_start()
-                job.ctx.set_ntt(job.matrix, inv)
-                total_ms += job.ctx.timer_stop()
-                if not inv:
-                    job.ctx.set_ntt(job.matrix, True)
-            rates[name] = n_tr * reps / (total_ms * 1e-3)
-        ntt_kernel = {"kernel": "k_limb_ntt", "log_n": job.log_n, "limb_ntts_per_launch": n_tr,
-                      "forward_per_s": round(rates["forward"], 1), "inverse_per_s": round(rates["inverse"], 1),
-                      "forward_hbm_frac": round(rates["forward"] * 16.0 * job.N / 8e12, 4),
-                      "inverse_hbm_frac": round(rates["inverse"] * 16.0 * job.N / 8e12, 4),
-                      "ct_ntts_forward_per_s": round(rates["forward"] / (2 * job.L), 1)}
-    io = None
-    if world == 1 and not args.no_io:
-        job.io_setup()
-        outs = job.step(keep=True)
-        job.marshal(*outs)  # first touch of the wire image and the staging paths
-        marshal_s = min(job.marshal(*outs) for _ in range(3))
-        unmarshal_s, back = job.unmarshal()
-        for a_, b_ in zip(outs[:3], back):  # the round trip of ligero_test.go:118-126, on the device
-            assert np.array_equal(a_.download(0, 2), b_.download(0, 2)) and np.array_equal(
-                a_.download(a_.count - 1, 1), b_.download(b_.count - 1, 1)), "unmarshalled ciphertexts differ"
-        # the client's "Decrypt proof" (EncryptedProof.Decrypt, ligero.go:381-502: slot 0 of every MatR / MatZ
-        # ciphertext, all `rows` slots of the 309 opened columns; 48.05 s on the reference's client at this shape)
-        rng_k = np.random.default_rng(6)
-        job.ctx.load_secret_key(np.stack([rng_k.integers(0, q, size=job.N, dtype=np.uint64) for q in job.P.q]))
-        job.ctx.encoder_set(lp.encoder_psi(job.P.T, job.P.log_n))
-        job.ctx.decrypt(back[2], job.rows)
-        decrypt_s = None
-        for _ in range(3):
-            job.ctx.sync()
-            t0_ = time.perf_counter()
-            job.ctx.decrypt(back[0], 1), job.ctx.decrypt(back[1], 1), job.ctx.decrypt(back[2], job.rows)
-            dt_ = time.perf_counter() - t0_
-            decrypt_s = dt_ if decrypt_s is None else min(decrypt_s, dt_)
-        for b_ in back:
-            b_.free()
-        for s_ in outs[:3]:
-            s_.free()
-        job.step_io()  # warm-up
-        runs = [job.step_io() for _ in range(2)]
-        best = min(runs, key=lambda r: r["total_s"])
-        want = hashlib_sha(job.wire)
-        enc_s = job.encrypt_matrix()
-        job.step_io_fused()
-        fused = min([job.step_io_fused() for _ in range(2)], key=lambda r: r["total_s"])
-        assert hashlib_sha(job.wire) == want, "the fused order produced different proof bytes"
-        gb_in = job.cols * 2 * job.L * job.N * 8 / 1e9
-        io = {"marshal_s": round(marshal_s, 4), "unmarshal_s": round(unmarshal_s, 4),
-              # client side of the wire, for a client that owns a GPU: unmarshal_s above + this = "Decrypt proof"
-              "decrypt_proof_s": round(decrypt_s, 4),
-              "io_inclusive_s": round(best["total_s"], 4),
-              "io_inclusive_fused_order_s": round(fused["total_s"], 4),
-              # what precedes the metric in the reference's server (cmd/server/main.go:188-208, "Encrypt matrix":
-              # 66.84 s at 16384x4096): the raw witness columns from host memory, Encoder.Encode + EncryptNew on the device
-              "encrypt_matrix_s": round(enc_s, 4),
-              "io": {"upload_s": round(best["upload_s"], 4), "marshal_tail_s": round(best["marshal_tail_s"], 4),
-                     "upload_GB": round(gb_in, 2), "upload_GBps": round(gb_in / best["upload_s"], 1),
-                     "proof_wire_GB": round(job.wire_len / 1e9, 3),
-                     "marshal_GBps": round(job.wire_len / 1e9 / marshal_s, 1),
-                     "reference_marshal_s": {"16384x4096": 2.254, "8192x4096": 1.135, "4096x2048": 0.347,
-                                             "2048x1024": 0.156}.get(args.config),  # results/baseline/server/bench_*.txt:34
-                     "note": "marshal_s: EncryptedProof.MarshalBinary of results resident in HBM -- wire images of MatR, "
-                             "MatZ and the queried columns assembled on the device (k_ct_wire), one DMA each into "
-                             "page-locked memory, Merkle paths + root appended (the reference's 'Marshal proof' span). "
-                             "io_inclusive_s: input ciphertexts from page-locked host memory (one DMA, not overlappable "
-                             "in the fhe API's order: Encode needs every column), the step, and the same marshalling "
-                             "overlapped with it on a clone context (column slices, lumen_ctx_wait); ends with the "
-                             "proof's wire bytes in host memory. io_inclusive_fused_order_s: the same bytes (checked) in "
-                             "the order a server that owns the whole request can use -- Prove's challenges do not depend "
-                             "on the Merkle root (ligero.go:198-199), so the inner products of a column slice start when "
-                             "it lands and Encode runs once the last one has: the upload hides behind compute"}}
+    roofline, stages, executed = (None, None, None) if args.no_kernel_profile else profile_kernels(job, dist, args.config)
+    ntt_kernel = plain_ntt_rates(job) if world == 1 and not args.no_kernel_profile else None
+    io = io_leg(job, args.config) if world == 1 and not args.no_io else None
     others = None
     if world == 1 and not args.no_other_configs and not args.ring_switch_logn:
-        others = {}
-        if args.config == "16384x4096":  # BASELINE config 5 on the resident job: + RingSwitchNew -> LogN = 10
-            job.enable_ring_switch(10)
-            sec = timed_steps(job, None, args.other_steps, 1, barrier)
-            others["16384x4096+ring-switch->LogN=10"] = {
-                "value": round(sec, 4), "unit": "s", "steps": args.other_steps,
-                "reference_s": 417.6, "ring_switch_added_s": round(sec - sec_per_step, 4)}
-            job.ring_switch_logn = 0
-        main_ctx = job.ctx
-        for cfg in ("2048x1024", "4096x2048", "8192x4096"):
-            if cfg == args.config:
-                continue
-            oj = Job(cfg, 0, 1, local_rank)
-            sec = timed_steps(oj, None, args.other_steps, 1, lambda: oj.ctx.sync())
-            others[cfg] = {"value": round(sec, 4), "unit": "s", "steps": args.other_steps,
-                           "reference_s": PUBLISHED_SECONDS[cfg], "L": oj.L, "LogN": oj.log_n}
-            oj.close()
-        assert job.ctx is main_ctx
+        others = other_configs(job, args, sec_per_step, local_rank, barrier)
     if rank == 0:
         census = limb_ntt_census(job.rows, job.cols, job.L, job.K, job.log_n)
         out = {

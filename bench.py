@@ -777,6 +777,47 @@ def io_leg(job, cfg):
                          "it lands and Encode runs once the last one has: the upload hides behind compute"}}
 
 
+def plain_prover_seconds(rows, cols, device):
+    """LigeroProveReference (fhe/ligero.go:799-953) -- the plain prover the reference's CLIENT runs to check the
+    decrypted proof ("Ligero local generation": 14 min 22 s at 16384 x 4096 on its 2 vCPUs,
+    results/baseline/client/bench_16384x4096_14.txt:36-45) -- on the same kernels: a context whose one modulus is
+    T holds the plain matrix column by column.  Witness columns from page-locked host memory,
+    core.Encode of every row, leaf digests + Merkle tree, the two matrix-vector products, the opened columns."""
+    from lumenos_amd.hip import Context, pinned_empty
+    T = lp.T_REFERENCE
+    log_n = (rows // 2).bit_length() - 1
+    S = cols * RHO_INV
+    ctx = Context(log_n, [T], [], [lp.encoder_psi(T, log_n)], T, device=device)
+    ctx.field_set(np.array(lp.field_roots_forward(T, S), dtype=np.uint64))
+    ctx.leaf_format_set(b"", b"", b"")  # a leaf is the column's bytes (ligero.go:866-872)
+    rng = np.random.default_rng(8)
+    host = pinned_empty((cols, 2, 1, rows // 2))
+    host[:] = rng.integers(0, T, size=host.shape, dtype=np.uint64)
+    zero = np.zeros((2, 1, rows // 2), dtype=np.uint64)
+    r = rng.integers(0, 2**63, size=rows, dtype=np.uint64)
+    b = rng.integers(0, T, size=rows, dtype=np.uint64)
+    idx = rng.integers(0, S, size=lp.calculate_queries(SECURITY_BITS, RHO_INV)).astype(np.uint32)
+    m = ctx.new_set(cols, 1)
+    best = None
+    for _ in range(3):
+        ctx.sync()
+        t0 = time.perf_counter()
+        m.upload(host)
+        enc = ctx.encode(m, zero, RHO_INV)
+        dig = ctx.leaf_digests(enc)
+        ctx.merkle_build(dig)
+        ctx.plain_inner_products(m, r)
+        ctx.plain_inner_products(m, b)
+        ctx.gather(enc, idx).download()
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        enc.free()
+        best = dt if best is None else min(best, dt)
+    m.free()
+    ctx.close()
+    return best
+
+
 def other_configs(job, args, sec_per_step, local_rank, barrier):
     """Short passes over the other BASELINE.json configurations, so that the driver's one command attests them."""
     others = {}
@@ -797,6 +838,10 @@ def other_configs(job, args, sec_per_step, local_rank, barrier):
                        "reference_s": PUBLISHED_SECONDS[cfg], "L": oj.L, "LogN": oj.log_n}
         oj.close()
     assert job.ctx is main_ctx
+    # the client's plain prover on the same kernels, at the configuration's shape
+    ref = {"16384x4096": 861.9, "8192x4096": None, "4096x2048": None, "2048x1024": 3.89}.get(args.config)
+    others["plain_prover_" + args.config] = {"value": round(plain_prover_seconds(job.rows, job.cols, local_rank), 4),
+                                             "unit": "s", "reference_client_s": ref}
     return others
 
 

@@ -171,6 +171,9 @@ struct Plan {
     std::vector<Pass> passes;
     std::vector<uint32_t> out_pos; // physical slot -> final logical position
     uint64_t n_mul = 0, n_bfly = 0;
+    // highest field-table entry the schedule reads (RootForward(8)^3 counts as entry 8): nttInner's hard-coded
+    // base cases read RootForwardUint64(4) / (8) whatever the table's size (ntt.go:60,134-143)
+    uint32_t max_tw = 0;
     // device copies, one per pass
     struct Dev {
         uint32_t ngroups, gsize, nlayers;
@@ -344,6 +347,8 @@ Plan *build_plan(uint32_t count, uint32_t size, uint32_t fieldN) {
     std::iota(w.v.begin(), w.v.end(), 0u);
     w.walk(0, count, size);
     Plan *plan = new Plan();
+    for (const Op &o : w.ops)
+        if (o.is_mul) plan->max_tw = std::max(plan->max_tw, o.tw < 0 ? 8u : (uint32_t)o.tw);
     plan->out_pos.assign(count, 0);
     for (uint32_t k = 0; k < count; k++) plan->out_pos[w.v[k]] = k;
     for (const Op &o : w.ops) (o.is_mul ? plan->n_mul : plan->n_bfly)++;
@@ -466,6 +471,12 @@ int get_plan(lumen_ctx *ctx, uint32_t count, uint32_t size, Plan **out) {
         return 0;
     }
     std::shared_ptr<Plan> p(build_plan(count, size, ctx->fieldN));
+    // With a table of 4 or 8 roots (a matrix of 2 or 4 columns at rhoInv = 2) the base cases index past it: the
+    // reference panics (index out of range); refused here instead of reading next to the table.
+    LM_CHECK(ctx, p->max_tw < ctx->fieldN,
+             "a transform of %u values reads RootForward(%u) but the field table has %u entries: the reference panics "
+             "here (hard-coded base cases of fhe/ntt.go); use a plaintext field of at least 16 roots", size, p->max_tw,
+             ctx->fieldN);
     if (int rc = upload_plan(ctx, p.get(), count)) return rc;
     ctx->ext[key] = p;
     *out = p.get();

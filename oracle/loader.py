@@ -259,6 +259,10 @@ class Params:
         self.o.lib.lo_rng_seed(C.byref(self._rng), s)
 
     def _r(self):
+        # xoshiro with an all-zero state returns zeros for ever, and the rejection samplers then never return
+        # (a test that forgets P.seed() hangs instead of failing): seed it on first use
+        if not any(self._rng):
+            self.seed(0x5EED)
         return C.cast(C.byref(self._rng), C.c_void_p)
 
     # transforms
@@ -272,10 +276,21 @@ class Params:
         self.o.lib.lo_limb_intt(self.h, mi, _p64(a))
         return a
 
+    def _check_table(self, size, roots):
+        """nttInner's hard-coded base cases read RootForwardUint64(4) / (8) whatever the table's size
+        (fhe/ntt.go:60,134-143): with fewer roots the reference panics (index out of range)."""
+        if size >= 4 and len(roots) <= 8:  # the highest entry any schedule reads is RootForward(8)
+            tr = self.o.twiddle_trace(size, len(roots))
+            need = max([8 if t < 0 else int(t) for t in tr], default=0)
+            if need >= len(roots):
+                raise IndexError(f"fhe.NTT of {size} values reads RootForward({need}): the field table has {len(roots)} "
+                                 "entries (the reference panics here)")
+
     def ct_ntt(self, cts, size, roots):
         """cts: [count][2][nl][N] -> transformed copy (fhe.NTT)."""
         cts = np.ascontiguousarray(cts, dtype=np.uint64).copy()
         count, _, nl, N = cts.shape
+        self._check_table(size, roots)
         self.o.lib.lo_ct_ntt(self.h, _p64(cts), count, nl, size, _p64(roots), len(roots))
         return cts
 
@@ -284,6 +299,7 @@ class Params:
         cols, _, nl, N = matrix.shape
         out = np.zeros((cols * rho_inv, 2, nl, N), dtype=np.uint64)
         zero_ct = np.ascontiguousarray(zero_ct, dtype=np.uint64)
+        self._check_table(cols * rho_inv, roots)
         self.o.lib.lo_ct_encode(self.h, _p64(matrix), cols, nl, rho_inv, _p64(zero_ct), _p64(roots), len(roots), _p64(out))
         return out
 

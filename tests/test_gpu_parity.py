@@ -934,3 +934,58 @@ def test_full_size_encrypt_rescale_decrypt_round_trip(full_d):
     lvl1 = ctx.rescale(cts, 2)
     got = ctx.decrypt(lvl1, P.N, P.rescale_scale(P.L, 2))
     assert np.array_equal(got, vals)
+
+
+@pytest.mark.parametrize("cols,rho", [(2, 1), (1, 2), (2, 2), (8, 4), (16, 1), (4, 8), (64, 4)])
+def test_encode_other_rates_and_smallest_shapes(oracle, small, cols, rho):
+    """fhe.Encode for rhoInv other than the reference's constant 2 (cmd/server/main.go:23) and for the
+    smallest matrices the control flow of nttInner distinguishes (sizes 2, 4, 8: the hard-coded base cases,
+    ntt.go:24-244; 16, 32: the first six-step splits; rho = 1: no padding column at all)."""
+    P, ctx = small
+    S = cols * rho
+    m = random_cts(P, cols, 2, seed=1000 + 17 * cols + rho)
+    zero = random_cts(P, 1, 2, seed=2000 + cols)[0]
+    # the base cases of 4 and 8 values read RootForward(4) / (8) whatever the table's size: with the field the
+    # reference would build for such a matrix (core.NewPrimeField(T, cols * rhoInv) of 4 or 8 roots) it panics
+    # with an index out of range; the library refuses the call, the oracle's wrapper raises
+    if S in (4, 8):
+        from lumenos_amd.hip import LumenError
+        tight = oracle.field_roots(T_REF, S)
+        ctx.field_set(tight)
+        with pytest.raises(LumenError, match="the reference panics"):
+            ctx.encode(ctx.upload(m), zero, rho)
+        with pytest.raises(IndexError, match="the reference panics"):
+            P.ct_encode(m, rho, zero, tight)
+    roots = oracle.field_roots(T_REF, max(S, 16))
+    ctx.field_set(roots)
+    got = ctx.encode(ctx.upload(m), zero, rho)
+    assert got.count == S
+    assert np.array_equal(got.download(), P.ct_encode(m, rho, zero, roots)), (cols, rho)
+
+
+def test_empty_sets_through_the_batch_entry_points(oracle, small):
+    """[]*rlwe.Ciphertext of length zero is legal Go everywhere on the path (a rank that owns no queried
+    column gathers nothing; a proof slice may be empty): every batch entry point accepts a set of zero
+    ciphertexts, launches nothing and returns an empty result."""
+    from lumenos_amd.hip import pinned_bytes
+    P, ctx = small
+    e4, e2 = ctx.new_set(0, P.L), ctx.new_set(0, 2)
+    assert e4.count == 0 and e4.download().shape == (0, 2, P.L, P.N)
+    assert ctx.rescale(e4, 2).count == 0
+    assert ctx.gather(ctx.upload(random_cts(P, 3, 2, seed=1)), np.zeros(0, dtype=np.uint32)).count == 0
+    assert ctx.ct_serialize(e2) == b""
+    assert ctx.ct_serialize_into(e2, pinned_bytes(8), wait=False) == 0
+    assert ctx.ct_deserialize(b"", 0, 2).count == 0
+    assert ctx.leaf_digests(e2).shape == (0, 32)
+    pt = np.zeros((P.L, P.N), dtype=np.uint64)
+    sk = P.keygen_secret()
+    for g in P.inner_sum_galois_elements(8):
+        ctx.load_galois_key(g, P.keygen_galois(sk, g))
+    assert ctx.mul_plain(e4, pt).count == 0
+    assert ctx.inner_sum(e4, 8).count == 0
+    assert ctx.matrix_inner_sum(e4, pt, 8).count == 0
+    key = P.keygen_ringswitch(sk, P.keygen_secret_small(8), 8)
+    ctx.load_ringswitch_key(8, key)
+    assert ctx.ring_switch(e2).shape == (0, 2, 256)
+    ctx.set_ntt(e4, False)
+    ctx.sync()

@@ -989,3 +989,86 @@ def test_empty_sets_through_the_batch_entry_points(oracle, small):
     assert ctx.ring_switch(e2).shape == (0, 2, 256)
     ctx.set_ntt(e4, False)
     ctx.sync()
+
+
+@pytest.mark.parametrize("num_q,num_p", [(22, 2), (9, 1), (15, 2)])
+def test_maximum_limb_count_and_wide_gadget(oracle, num_q, num_p):
+    """The ABI's limits: L + K = LUMEN_MAX_LIMBS = 24 limbs, and gadget products of more than 7 digits (beta = 11,
+    9, 8: the accumulated sum then takes the Barrett step of the reduction instead of conditional subtractions --
+    the reference's own chains stop at beta = 6).  Limb transforms, rescale from the top to level 1 and to a middle
+    level, ct x pt, InnerSum, matrixInnerSumEval, witness encryption and decryption at depth, bit for bit."""
+    P = make_params(oracle, 10, num_q, num_p=num_p)
+    assert P.L + P.K <= 24 and P.beta() == -(-num_q // num_p)
+    P.seed(2200 + num_q)
+    ctx = make_context(P)
+    sk = P.keygen_secret()
+    pk = P.keygen_public(sk)
+    cts = random_cts(P, 3, P.L, seed=num_q)
+    s = ctx.upload(cts)
+    ctx.set_ntt(s, True)
+    got = s.download()
+    for l in (0, P.L // 2, P.L - 1):
+        assert np.array_equal(got[1, 1, l], P.limb_intt(cts[1, 1, l], l)), l
+    ctx.set_ntt(s, False)
+    assert np.array_equal(s.download(), cts)
+    for target in (2, P.L // 2):
+        ref = cts[2]
+        while ref.shape[1] > target:
+            ref = P.rescale(ref)
+        assert np.array_equal(ctx.rescale(ctx.upload(cts[2:]), target).download()[0], ref), target
+    n = 8
+    gl = P.inner_sum_galois_elements(n)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    inner = ctx.inner_sum(ctx.upload(cts), n).download()
+    for c in range(3):
+        assert np.array_equal(inner[c], P.inner_sum(cts[c], n, evks)), c
+    rng = np.random.default_rng(num_q)
+    col = rng.integers(0, T_REF, size=n, dtype=np.uint64)
+    r = rng.integers(0, 2**63, size=n, dtype=np.uint64)
+    enc = P.encrypt(pk, P.encode(col))[None]
+    pt = P.encode(r)
+    out = ctx.matrix_inner_sum(ctx.upload(enc), pt, n).download()
+    assert np.array_equal(out, P.matrix_inner_sum(enc, pt, n, evks))
+    want = int(np.sum(col.astype(object) * (r.astype(object) % T_REF)) % T_REF)
+    assert int(P.decrypt(sk, out[0], 1, P.rescale_scale(P.L, 2))[0]) == want
+    # the input side and the client side at this depth
+    from lumenos_amd import params as lp
+    ctx.load_public_key(pk)
+    ctx.load_secret_key(sk)
+    ctx.encoder_set(lp.encoder_psi(T_REF, P.logN))
+    seed = np.arange(32, dtype=np.uint8)
+    vals = rng.integers(0, T_REF, size=(2, P.N), dtype=np.uint64)
+    e = ctx.encrypt_values(vals, seed, 3)
+    assert np.array_equal(e.download()[1], P.encrypt_det(pk, P.encode(vals[1]), seed, 4))
+    assert np.array_equal(ctx.decrypt(e, P.N), vals)  # all L limbs: mixed-radix CRT
+    ctx.close()
+
+
+def test_ragged_batches(oracle, keyed):
+    """Counts that are no multiple of any internal batch: 67 columns through the key switch (batches of 64 + 3),
+    300 ciphertexts through the ring switch (256 + 44), 131 through the rescale and the leaf digests."""
+    P, ctx, sk = keyed
+    n = 4
+    gl = P.inner_sum_galois_elements(n)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    cts = random_cts(P, 67, P.L, seed=6700)
+    pt = P.encode(np.arange(n, dtype=np.uint64) + 5)
+    got = ctx.matrix_inner_sum(ctx.upload(cts), pt, n).download()
+    want = P.matrix_inner_sum(cts, pt, n, evks)
+    assert np.array_equal(got, want)
+    l1 = random_cts(P, 300, 2, seed=300)
+    sk_small = P.keygen_secret_small(8)
+    key = P.keygen_ringswitch(sk, sk_small, 8)
+    ctx.load_ringswitch_key(8, key)
+    rs = ctx.ring_switch(ctx.upload(l1))
+    for c in (0, 255, 256, 299):
+        assert np.array_equal(rs[c], P.ring_switch(l1[c], key, 8)), c
+    big = random_cts(P, 131, P.L, seed=131)
+    lvl1 = ctx.rescale(ctx.upload(big), 2)
+    ref_l1, ref_dig = P.commit_leaves(big)
+    assert np.array_equal(lvl1.download(), ref_l1)
+    assert np.array_equal(ctx.leaf_digests(lvl1), ref_dig)

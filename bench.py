@@ -170,10 +170,10 @@ class Job:
         self.query_idx = rng.integers(0, self.S, size=self.queries).astype(np.uint32)
         self.ring_switch_logn = 0
         self._rand_limbs = rand_limbs
-        if ring_switch_logn:
-            self.enable_ring_switch(ring_switch_logn)
         # column shards (input columns; encoded columns are sharded by the transform itself)
         self.col_lo, self.col_hi = self.cols * rank // world, self.cols * (rank + 1) // world
+        if ring_switch_logn:
+            self.enable_ring_switch(ring_switch_logn)
         if self.lane_path:  # self.matrix IS the rank's block; its slice of the one Enc(0) for the lane Encode
             nw = self.N // world
             self.zero_lanes = np.ascontiguousarray(self.zero_ct[:, :, rank * nw:(rank + 1) * nw])
@@ -188,6 +188,9 @@ class Job:
         key = np.ascontiguousarray(self._rand_limbs(P.q + P.p, (rns, pw2, 2, self.N)).transpose(1, 2, 3, 0, 4))
         self.ctx.load_ringswitch_key(logn, key)
         self.ring_switch_logn = logn
+        from lumenos_amd.hip import pinned_empty
+        own = self.matrix.count if self.lane_path else self.col_hi - self.col_lo
+        self.h_rs = [pinned_empty((own, 2, 1 << logn)) for _ in range(2)]  # MatR / MatZ as they leave for the proof
 
     def close(self):
         for a in ("io_ctx", "up_ctx"):
@@ -411,8 +414,8 @@ class Job:
         mat_r = ctx.matrix_inner_sum(self.matrix, self.r_pt, self.rows)
         mat_z = ctx.matrix_inner_sum(self.matrix, self.b_pt, self.rows)
         if self.ring_switch_logn:
-            ctx.ring_switch(mat_r)
-            ctx.ring_switch(mat_z)
+            ctx.ring_switch(mat_r, self.h_rs[0])
+            ctx.ring_switch(mat_z, self.h_rs[1])
         own = self.query_idx[(self.query_idx >= rank * Sw) & (self.query_idx < (rank + 1) * Sw)] - rank * Sw
         q = ctx.gather(lvl1, own.astype(np.uint32))
         # ---- Commit, concluded: all-gather of the digests on device buffers, Merkle root on the device
@@ -445,8 +448,8 @@ class Job:
         mat_z = ctx.matrix_inner_sum(cols, self.b_pt, self.rows)
         cols.free()
         if self.ring_switch_logn:  # ligero.go:336-342: RingSwitchNew on every inner-product output
-            ctx.ring_switch(mat_r)
-            ctx.ring_switch(mat_z)
+            ctx.ring_switch(mat_r, self.h_rs[0])
+            ctx.ring_switch(mat_z, self.h_rs[1])
         # ---- Prove: query columns (fhe/ligero.go:261-280): already at level 1 from Commit
         q = ctx.gather(lvl1, owned_queries(self.query_idx, my_cols))
         # ---- Commit, concluded: digests -> (all-gather) -> Merkle tree (core/tree.go:113-163)

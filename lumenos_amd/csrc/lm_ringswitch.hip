@@ -20,6 +20,8 @@
 
 #include "lm_ks_dev.h"
 
+int lm_d2h(lumen_ctx *ctx, void *host, const void *dev, size_t bytes, bool wait);
+
 namespace {
 
 struct RsKey {
@@ -316,9 +318,10 @@ extern "C" int lumen_ring_switch(lumen_ctx *ctx, const lumen_set *in, uint64_t *
             return lm_fail(ctx, "ring degree 2^%u has no kernel instantiation", ctx->logN);
         }
         if (rc) return rc;
-        LM_HIP(ctx, hipMemcpyAsync(out + (size_t)first * 2 * n, small, (size_t)B * 2 * n * 8, hipMemcpyDeviceToHost,
-                                   ctx->stream));
-        LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // page-locked `out`: the copy is enqueued and the next batch's kernels run behind it (they reuse `small`
+        // in stream order); a pageable one goes through the bounce buffers
+        if (int rc2 = lm_d2h(ctx, out + (size_t)first * 2 * n, small, (size_t)B * 2 * n * 8, false)) return rc2;
     }
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

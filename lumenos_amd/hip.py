@@ -543,8 +543,11 @@ class Context:
         self._ck(self.lib.lumen_load_ringswitch_key(self.h, log_n_small, w, _p64(key)))
         self._rs_logn = log_n_small
 
-    def ring_switch(self, s):
-        out = np.zeros((s.count, 2, 1 << self._rs_logn), dtype=np.uint64)
+    def ring_switch(self, s, out=None):
+        """RingSwitchNew of every ciphertext of `s`: [count][2][n] residues (into `out` if given, e.g. page-locked)"""
+        if out is None:
+            out = np.zeros((s.count, 2, 1 << self._rs_logn), dtype=np.uint64)
+        assert out.shape == (s.count, 2, 1 << self._rs_logn) and out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"]
         self._ck(self.lib.lumen_ring_switch(self.h, s.h, _p64(out)))
         return out
 

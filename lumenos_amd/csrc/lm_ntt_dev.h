@@ -29,6 +29,18 @@
 // LDS layout: one pad slot per 8 coefficients.  Conflict-free for the three access shapes of the
 // passes (64 consecutive coefficients; 8 runs of 8 coefficients 64 apart; one run of 8 per lane).
 #define LM_PAD(i) ((i) + ((i) >> 3))
+// Padded index of element base + (k << LOG_STRIDE): for strides of at least 8 the pad term is affine in k --
+// (base + 8m) >> 3 = (base >> 3) + m whatever the low bits of base -- so the 2^R elements of a work item sit at
+// ONE padded base plus compile-time constants that the ds_read / ds_write offset field takes (the compiler does
+// not see this by itself and builds a separate address register per element).  Smaller strides (runs of
+// consecutive coefficients starting at a multiple of 8) fold already.
+template <int LOG_STRIDE>
+__device__ __forceinline__ uint32_t lm_pad_at(uint32_t base, uint32_t pbase, int k) {
+    if constexpr (LOG_STRIDE >= 3)
+        return pbase + (uint32_t)k * ((1u << LOG_STRIDE) + (1u << (LOG_STRIDE - 3)));
+    else
+        return LM_PAD(base + ((uint32_t)k << LOG_STRIDE));
+}
 #define LM_MAX_PASSES 8
 
 struct lm_ninv_t {
@@ -445,7 +457,7 @@ __device__ __forceinline__ void lm_fwd_first(u64 *s, const tw_t *tw, const lm_qc
         for (int k = 0; k < (1 << R); k++) e[k] = ld(w + ((uint32_t)k << log_tl));
         lm_fwd_stages<R, true>(e, T, c);
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) s[LM_PAD(w + ((uint32_t)k << log_tl))] = e[k];
+        for (int k = 0; k < (1 << R); k++) s[lm_pad_at<log_tl>(w, LM_PAD(w), k)] = e[k];
     }
 }
 
@@ -465,13 +477,14 @@ __device__ __forceinline__ void lm_fwd_mid(u64 *s, const tw_t *tw, const lm_qc &
         const uint32_t blk = w >> log_tl, off = w & ((1u << log_tl) - 1);
         const uint32_t base = (blk << (log_tl + R)) + off;
         u64 e[1 << R];
+        const uint32_t pb = LM_PAD(base);
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_tl))];
+        for (int k = 0; k < (1 << R); k++) e[k] = s[lm_pad_at<log_tl>(base, pb, k)];
         if (LM_TW_PREFETCH && m + 1 < D::reps) T[(m + 1) & 1].load(tw, S0, D::local(tid, m + 1) >> log_tl);
         if (!LM_TW_PREFETCH && m) T[m & 1].load(tw, S0, blk);
         lm_fwd_stages<R, UW>(e, T[m & 1], c);
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_tl))] = e[k];
+        for (int k = 0; k < (1 << R); k++) s[lm_pad_at<log_tl>(base, pb, k)] = e[k];
     }
 }
 
@@ -551,11 +564,12 @@ __device__ __forceinline__ void lm_fwd_mid_item(u64 *s, const lm_twset<R, UW> &T
     const uint32_t blk = w >> log_tl, off = w & ((1u << log_tl) - 1);
     const uint32_t base = (blk << (log_tl + R)) + off;
     u64 e[1 << R];
+    const uint32_t pb = LM_PAD(base);
 #pragma unroll
-    for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << log_tl))];
+    for (int k = 0; k < (1 << R); k++) e[k] = s[lm_pad_at<log_tl>(base, pb, k)];
     lm_fwd_stages<R, UW>(e, T, c);
 #pragma unroll
-    for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << log_tl))] = e[k];
+    for (int k = 0; k < (1 << R); k++) s[lm_pad_at<log_tl>(base, pb, k)] = e[k];
 }
 template <class Loader, class Storer>
 __device__ __forceinline__ void lm_fwd14_xpass(u64 *sm, const tw_t *tw, const lm_qc &c, uint32_t tid, Loader &ld,
@@ -646,13 +660,14 @@ __device__ __forceinline__ void lm_inv_mid(u64 *s, const tw_t *tw, const lm_qc &
         const uint32_t blk = w >> LT, off = w & ((1u << LT) - 1);
         const uint32_t base = (blk << (LT + R)) + off;
         u64 e[1 << R];
+        const uint32_t pb = LM_PAD(base);
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(base + ((uint32_t)k << LT))];
+        for (int k = 0; k < (1 << R); k++) e[k] = s[lm_pad_at<LT>(base, pb, k)];
         if (LM_INV_TW_PREFETCH && m + 1 < D::reps) T[(m + 1) & 1].load(tw, LOGN, LT, D::local(tid, m + 1) >> LT);
         if (!LM_INV_TW_PREFETCH && m) T[0].load(tw, LOGN, LT, blk);
         lm_inv_stages<R, UW, false, false>(e, T[LM_INV_TW_PREFETCH ? (m & 1) : 0], c);
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) s[LM_PAD(base + ((uint32_t)k << LT))] = e[k];
+        for (int k = 0; k < (1 << R); k++) s[lm_pad_at<LT>(base, pb, k)] = e[k];
     }
 }
 
@@ -675,7 +690,7 @@ __device__ __forceinline__ void lm_inv_last(const u64 *s, const tw_t *tw, const 
         if (items < NT && w >= items) break;
         u64 e[1 << R];
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) e[k] = s[LM_PAD(w + ((uint32_t)k << log_t0))];
+        for (int k = 0; k < (1 << R); k++) e[k] = s[lm_pad_at<log_t0>(w, LM_PAD(w), k)];
         // a storer with a member pre(w) is told the work item before its butterflies run: whatever it
         // reads from global memory for coefficients w + (k << log_t0), k < 2^R, is then in flight under them
         if constexpr (lm_has_pre<Storer>::value) st.pre(w);

@@ -19,6 +19,11 @@
  *     P(x=1) values in results/baseline/client/bench_*.txt:22,
  *   - queries = 309 (results/baseline/server/bench_*.txt:19),
  *   - Q-chain lengths 10/11/12/12 (bench_*.txt:16),
+ *   - every SIZE the reference logs (tests/test_oracle_kat.py): "Marshaled keys length" with and without the
+ *     ring switch (results/{baseline,experimental}/client/bench_*.txt:19-20) -- which pins the number of Galois
+ *     keys (12/14/15/16), the gadget shape beta x 1 (no power-of-two digits, also for the ring-switch key) --
+ *     and the 24 "Marshaled MatR / MatZ / QueriedCols / proof" lines (results/*/server/bench_*.txt:31-37), which
+ *     bound the framing of a serialised ciphertext (MetaData block: 269..311 bytes),
  *   - SHA-256 (FIPS 180-4 vectors), ChaCha20 (RFC 8439 vectors),
  *   - the decrypted-value equalities the reference's tests assert
  *     (fhe/code_test.go:110-116, fhe/ligero_test.go:150-174), re-run here on

@@ -22,7 +22,7 @@
  *   - every SIZE the reference logs (tests/test_oracle_kat.py): "Marshaled keys length" with and without the
  *     ring switch (results/{baseline,experimental}/client/bench_*.txt:19-20) -- which pins the number of Galois
  *     keys (12/14/15/16), the gadget shape beta x 1 (no power-of-two digits, also for the ring-switch key) --
- *     and the 24 "Marshaled MatR / MatZ / QueriedCols / proof" lines (results/*/server/bench_*.txt:31-37), which
+ *     and the 24 "Marshaled MatR / MatZ / QueriedCols / proof" lines (results/{baseline,experimental}/server/bench_*.txt:31-37), which
  *     bound the framing of a serialised ciphertext (MetaData block: 269..311 bytes),
  *   - SHA-256 (FIPS 180-4 vectors), ChaCha20 (RFC 8439 vectors),
  *   - the decrypted-value equalities the reference's tests assert

@@ -1,6 +1,9 @@
 /* A plain-C99 consumer of include/lumenos_hip.h: what a cgo translation unit sees.  Creates a context
  * from explicit moduli, runs NTT -> INTT on random ciphertexts and checks the round trip, exercises
- * the error convention (non-zero status + lumen_last_error).  Built and run by tests/test_abi.py. */
+ * the error convention (non-zero status + lumen_last_error), then the proof's way out and back in as a
+ * shim would drive it: a serialisation format, the wire image of a slice into page-locked memory on a
+ * clone context behind lumen_ctx_wait, lumen_ct_deserialize of those bytes, a gather.  Built and run by
+ * tests/test_abi.py. */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -65,6 +68,43 @@ int main(void) {
     lumen_set *bad = NULL;
     if (!lumen_set_create(ctx, 1, 5, &bad)) return fprintf(stderr, "num_limbs > L was accepted\n"), 8;
     if (!strlen(lumen_last_error(ctx))) return fprintf(stderr, "no error message\n"), 9;
+
+    /* the proof's way out and back: format -> wire image (asynchronously, on a clone that waits for the
+     * producer on the device) -> the same residues from the bytes; a gather with a repeated index */
+    {
+        uint8_t head[13], poly[8] = {1, 0, 0, 0, 0, 0, 0, 0}, limb[3] = {7, 7, 7};
+        size_t i;
+        lumen_ctx *twin = NULL;
+        lumen_set *back = NULL, *picked = NULL;
+        const uint32_t idx[3] = {2, 0, 2};
+        for (i = 0; i < sizeof head; i++) head[i] = (uint8_t)(0x40 + i);
+        rc = lumen_leaf_format_set(ctx, head, sizeof head, poly, sizeof poly, limb, sizeof limb);
+        const size_t each = lumen_ct_serialized_size(ctx, 1);
+        if (rc || each != sizeof head + 2 * (sizeof poly + sizeof limb + (size_t)n * 8))
+            return fprintf(stderr, "format: %s (each = %zu)\n", lumen_last_error(ctx), each), 10;
+        uint8_t *wire = lumen_host_alloc(each * count);
+        if (!wire) return fprintf(stderr, "lumen_host_alloc\n"), 11;
+        rc = lumen_ctx_clone(ctx, &twin) || lumen_ctx_wait(twin, ctx) ||
+             lumen_ct_serialize_async(twin, s, 0, count, wire, each * count) || lumen_sync(twin);
+        if (rc) return fprintf(stderr, "wire image: %s / %s\n", lumen_last_error(ctx), twin ? lumen_last_error(twin) : ""), 12;
+        if (memcmp(wire, head, sizeof head) || memcmp(wire + sizeof head + sizeof poly, limb, sizeof limb) ||
+            memcmp(wire + sizeof head + sizeof poly + sizeof limb, a, (size_t)n * 8))
+            return fprintf(stderr, "wire image is not head | poly_head | limb_head | limb\n"), 13;
+        rc = lumen_ct_deserialize(ctx, wire, each * count, count, 1, &back) || lumen_set_download(ctx, back, 0, count, b);
+        if (rc || memcmp(a, b, words * 8)) return fprintf(stderr, "deserialize: %s\n", lumen_last_error(ctx)), 14;
+        wire[3] ^= 1; /* a damaged framing is refused */
+        lumen_set *junk = NULL;
+        if (!lumen_ct_deserialize(ctx, wire, each * count, count, 1, &junk)) return fprintf(stderr, "damaged framing accepted\n"), 15;
+        rc = lumen_gather(ctx, back, idx, 3, &picked) || lumen_set_download(ctx, picked, 0, 3, b);
+        if (rc || memcmp(b, a + (size_t)2 * 2 * n, (size_t)2 * n * 8) || memcmp(b + (size_t)2 * n, a, (size_t)2 * n * 8) ||
+            memcmp(b + (size_t)4 * n, a + (size_t)4 * n, (size_t)2 * n * 8))
+            return fprintf(stderr, "gather: %s\n", lumen_last_error(ctx)), 16;
+        lumen_set_destroy(ctx, picked);
+        lumen_set_destroy(ctx, back);
+        lumen_ctx_destroy(twin);
+        lumen_host_free(wire);
+        lumen_leaf_format_set(ctx, NULL, 0, NULL, 0, NULL, 0);
+    }
 
     lumen_set_destroy(ctx, s);
     lumen_ctx_destroy(ctx);

@@ -303,3 +303,91 @@ def test_wire_image_of_more_than_one_chunk_at_headline_size(oracle, config):
     finally:
         ctx.leaf_format_set()
         s.free()
+
+
+# results/baseline/client/bench_*.txt:22 "Received encrypted proof for P(x=1)=..."
+P1_PUBLISHED = {"A_2048x1024": (2048, 59828798142202325), "B_4096x2048": (4096, 78852759954010476),
+                "C_8192x4096": (8192, 125815544481056462), "D_16384x4096": (16384, 5538402014578059)}
+
+
+def test_published_p1_through_the_encrypted_pipeline(oracle, config):
+    """The one value the reference publishes about every benchmark run, P(x = 1), reproduced THROUGH THE
+    CIPHERTEXTS at each configuration's full size and own parameters: the ChaCha20 witness (core/utils.go:46-82)
+    -> Encoder.Encode + EncryptNew of all its columns on the device -> matrixInnerSumEval with the evaluation
+    vector b_i = (z^cols)^i for z = 1 (cmd/client/main.go:41, fhe/ligero.go:210-216) -> decryption of slot 0 of
+    every MatZ ciphertext on the device -> sum_j MatZ[j] * z^j = P(1), as Proof.Verify's evaluation claim
+    computes it (ligero.go:569).  4096 columns x 16384 rows x 14 key switches at D: every kernel of the Prove
+    path at the headline size, checked by a number on the reference's disk."""
+    name, P, ctx, sk = config
+    rows, want = P1_PUBLISHED[name]
+    cols = CONFIGS[name][0]
+    pk = P.keygen_public(sk)
+    ctx.load_public_key(pk)
+    ctx.load_secret_key(sk)
+    ctx.encoder_set(psi_T(P.logN))
+    matrix = oracle.witness(rows, cols, T_REF)  # [rows][cols]
+    assert int(np.sum(matrix.astype(object))) % T_REF == want  # the plain KAT (tests/test_oracle_kat.py)
+    columns = np.ascontiguousarray(matrix.T)
+    seed = np.frombuffer(bytes(range(32)), dtype=np.uint8)
+    cts = ctx.encrypt_values(columns, seed, 0)
+    gl = P.inner_sum_galois_elements(rows)
+    for g in gl:
+        ctx.load_galois_key(g, P.keygen_galois(sk, g))
+    b = np.ones(rows, dtype=np.uint64)  # z = 1: (z^cols)^i = 1
+    mat_z = ctx.matrix_inner_sum(cts, P.encode(b), rows)
+    assert mat_z.count == cols and mat_z.nl == 2
+    vals = ctx.decrypt(mat_z, 1, P.rescale_scale(P.L, 2))[:, 0]
+    assert int(np.sum(vals.astype(object))) % T_REF == want, "P(1) through the encrypted inner products"
+    # and column by column against the witness
+    assert np.array_equal(vals, (np.sum(matrix.astype(object), axis=0) % T_REF).astype(np.uint64))
+
+
+def test_commit_at_full_size_every_leaf_decrypts_to_the_plain_encoding(oracle, config):
+    """Commit's data path at every configuration's FULL size and own parameters (D: 4096 input columns -> 8192
+    leaves of 16384 slots): witness -> device encryption -> fhe.Encode (one Enc(0) padding column) -> Rescale
+    to level 1 -> every leaf ciphertext decrypted on the device must be the plain Reed-Solomon encoding of the
+    witness rows (what TestEncode asserts at its one shape, fhe/code_test.go:110-116).  The plain side is
+    core.Encode of every row run on the same kernels (a context whose one modulus is T), itself
+    held to the oracle on a sample of rows; the Merkle root over the leaves' digests equals the oracle's tree
+    over the same digests."""
+    from lumenos_amd import params as lp
+    from lumenos_amd.hip import Context
+    name, P, ctx, sk = config
+    rows = P1_PUBLISHED[name][0]
+    cols, rho = CONFIGS[name][0], 2
+    S = cols * rho
+    pk = P.keygen_public(sk)
+    ctx.load_public_key(pk)
+    ctx.load_secret_key(sk)
+    ctx.encoder_set(psi_T(P.logN))
+    matrix = oracle.witness(rows, cols, T_REF)
+    columns = np.ascontiguousarray(matrix.T)
+    seed = np.frombuffer(bytes(range(7, 39)), dtype=np.uint8)
+    cts = ctx.encrypt_values(columns, seed, 0)
+    zero = ctx.encrypt_pk(None, 1, seed, cols).download()[0]
+    roots = oracle.field_roots(T_REF, S)
+    ctx.field_set(roots)
+    enc = ctx.encode(cts, zero, rho)
+    cts.free()
+    lvl1 = ctx.rescale(enc, 2)
+    enc.free()
+    dig = ctx.leaf_digests(lvl1)
+    assert ctx.merkle_build(dig)[1] == oracle.merkle(dig)[1]
+    # the plain encoding of all rows on the device
+    log_half = (rows // 2).bit_length() - 1
+    pctx = Context(log_half, [T_REF], [], [lp.encoder_psi(T_REF, log_half)], T_REF)
+    pctx.field_set(roots)
+    pm = pctx.upload(columns.reshape(cols, 2, 1, rows // 2))
+    want = pctx.encode(pm, np.zeros((2, 1, rows // 2), dtype=np.uint64), rho).download().reshape(S, rows)
+    pctx.close()
+    for i in (0, 1, rows // 2, rows - 1):  # the plain path against the oracle's core.Encode
+        assert np.array_equal(want[:, i], oracle.plain_encode(matrix[i], rho, T_REF, roots)), i
+    scale = P.rescale_scale(P.L, 2)
+    bad = 0
+    for first in range(0, S, 1024):  # in slices: 8192 x 16384 decoded values are 1 GB
+        view = lvl1.slice(first, min(1024, S - first))
+        got = ctx.decrypt(view, rows, scale)
+        view.free()
+        bad += int(np.any(got != want[first:first + got.shape[0]], axis=1).sum())
+    assert bad == 0, f"{bad} of {S} leaves do not decrypt to the plain encoding"
+    lvl1.free()

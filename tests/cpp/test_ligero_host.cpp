@@ -219,12 +219,16 @@ int main(int argc, char **argv) {
             std::vector<uint8_t> one0(ct0);
             REQUIRE(proof.MatRSwitched.size() == (size_t)cols * 2 * nSmall && proof.MatZSwitched.size() == proof.MatRSwitched.size(),
                     "ring-switched slices have the wrong size");
+            // (the oracle's switch costs a few ms of CPU per ciphertext: every column up to 1024, every 8th beyond)
+            const int stride = cols <= 1024 ? 1 : 8;
             for (int w = 0; w < 2; w++)
                 for (int j = 0; j < cols; j++) {
-                    lo_ring_switch(op, (w ? hZ : hR).data() + (size_t)j * 4 * N, 2, rsKey.data(), 13, (uint32_t)ringSwitchLogN, want.data());
                     const uint64_t *got = (w ? proof.MatZSwitched : proof.MatRSwitched).data() + (size_t)j * 2 * nSmall;
-                    REQUIRE(!memcmp(got, want.data(), want.size() * 8), "RingSwitchNew(Mat%c[%d]) differs from the oracle", w ? 'Z' : 'R', j);
-                    lo_ct_serialize_fmt(want.data(), 1, (uint32_t)nSmall, &fmt0, one0.data());
+                    if (j % stride == 0 || j == cols - 1) {
+                        lo_ring_switch(op, (w ? hZ : hR).data() + (size_t)j * 4 * N, 2, rsKey.data(), 13, (uint32_t)ringSwitchLogN, want.data());
+                        REQUIRE(!memcmp(got, want.data(), want.size() * 8), "RingSwitchNew(Mat%c[%d]) differs from the oracle", w ? 'Z' : 'R', j);
+                    }
+                    lo_ct_serialize_fmt(got, 1, (uint32_t)nSmall, &fmt0, one0.data());
                     REQUIRE(!memcmp(one0.data(), marshaled.data() + 11 + ((size_t)w * cols + j) * ct0, ct0),
                             "marshaled bytes of the ring-switched Mat%c[%d] differ", w ? 'Z' : 'R', j);
                 }

@@ -81,6 +81,8 @@ SHAPES = [
     ((12, 4096, 2048, 11, 0), ("269 MB", "269 MB", "41 MB", "579 MB")),
     ((12, 4096, 2048, 11, 10), ("34 MB", "34 MB", "41 MB", "109 MB")),
     ((13, 8192, 4096, 12, 0), ("1.1 GB", "1.1 GB", "81 MB", "2.2 GB")),
+    ((14, 16384, 4096, 12, 0), ("2.1 GB", "2.1 GB", "162 MB", "4.5 GB")),  # the configuration the metric is quoted on
+    ((14, 16384, 4096, 12, 10), ("68 MB", "68 MB", "162 MB", "299 MB")),   # BASELINE config 5: + ring switch to LogN 10
 ]
 
 
@@ -91,8 +93,9 @@ def test_ligero_e2e_host_mirror(shape, sizes):
     with the oracle.  The two small shapes take more limbs than the heuristic gives (a 16- or 64-column Encode
     is as deep in scalar multiplications per limb as the heuristic assumes only from 1024 columns up); the
     others are the reference's own test shape (2048x1024, LogN=12: TestLigeroE2E / TestLigeroPPD, BASELINE
-    config 1) and BASELINE configs B and 3 (4096x2048, 8192x4096 with rows = N) on exactly the chain
-    fhe.GenerateBGVParamsForNTT derives: L = 10 / 11 / 12 -- each must print the reference's span names and
+    config 1), BASELINE configs B and 3 (4096x2048, 8192x4096 with rows = N) and the headline configuration
+    itself (16384x4096, LogN=14: configs 4 and, with the ring switch, 5) on exactly the chain
+    fhe.GenerateBGVParamsForNTT derives: L = 10 / 11 / 12 / 12 -- each must print the reference's span names and
     the marshaled sizes the reference logged for that shape, which holds the serialisation framing
     (MetaData block + length words) to the published proofs; with a ring-switch degree the run is the
     "experimental" configuration (MatR / MatZ ring-switched to LogN = 10) against ITS logged sizes."""

@@ -890,7 +890,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.dist_backend)  # "nccl" is RCCL on ROCm
+        import datetime
+        # "nccl" is RCCL on ROCm; a rank that dies must not leave the others waiting in a collective for ever
+        dist.init_process_group(args.dist_backend, timeout=datetime.timedelta(minutes=10))
 
     job = Job(args.config, rank, world, local_rank, args.ring_switch_logn, args.allow_replicated)
 

@@ -40,11 +40,12 @@
 extern "C" {
 #endif
 
-#define LUMEN_ABI_VERSION 3
+#define LUMEN_ABI_VERSION 4
 #define LUMEN_MAX_LIMBS 24
 
 typedef struct lumen_ctx lumen_ctx;
 typedef struct lumen_set lumen_set;
+typedef struct lumen_group lumen_group;
 
 /* What fhe.NewBackendBFV (fhe/bfv.go:23-28) captures from bgv.Parameters:
  * ring degree, the Q and P moduli chains, the plaintext modulus, and for
@@ -145,7 +146,9 @@ int lumen_encode_shard(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *
  *     --lumen_encode (on the lane shard, with the same slice of the one Enc(0))--> lane shard of the S
  *     encoded columns --all-to-all--> W blocks of own encoded columns --lumen_lanes_assemble--> full width.
  * A rank uploads 1/W of the matrix and no work is replicated.  Lane sets are accepted by create /
- * destroy / slice / upload / download / fill_random / gather and lumen_encode only. */
+ * destroy / slice / upload / download / fill_random / gather and lumen_encode only.
+ * These are the building blocks; a host program uses the group entry points further down
+ * (lumen_group_encode runs the whole sequence, exchange included, inside the library). */
 int lumen_set_create_lanes(lumen_ctx *ctx, uint32_t count, uint32_t num_limbs, uint32_t log_world, lumen_set **out);
 uint32_t lumen_set_log_world(const lumen_set *set);
 /* full-width columns [n] -> lane set of W*n ciphertexts, block g (lane ciphertexts [g*n, (g+1)*n)) for rank g */
@@ -298,6 +301,78 @@ int lumen_ring_switch(lumen_ctx *ctx, const lumen_set *in, uint64_t *out);
  * of a set into a new set (duplicates allowed). */
 int lumen_gather(lumen_ctx *ctx, const lumen_set *src, const uint32_t *idx, uint32_t n,
                  lumen_set **out);
+
+/* ---- several GPUs behind ONE call sequence: the reference is one Go process that owns the whole
+ * request (cmd/server/main.go:187-266) and spreads its work over goroutine pools (fhe/ligero.go:136-162,
+ * 231-242); a lumen_group is that process's set of W = 2^log_world "ranks", one lumen_ctx per GPU, with the
+ * exchange steps of the sharded Commit inside the library:
+ *     rank r holds input columns [r*cols/W, (r+1)*cols/W) and everything derived from them (MatR / MatZ
+ *     blocks r), the encoded columns [r*S/W, (r+1)*S/W) with their level-1 leaves, and during Encode the lane
+ *     shard r (coefficients [r*N/W, (r+1)*N/W) of every limb of every ciphertext).
+ * Transport, chosen at creation:
+ *     LUMEN_TRANSPORT_COPY  stream-ordered device copies (hipMemcpyAsync on one device, hipMemcpyPeerAsync
+ *                           across devices) pulled by the destination rank's stream; every rank must be a
+ *                           context of this process.  The only transport possible when several ranks share a
+ *                           device (the one-GPU test mode: RCCL refuses two ranks on one device).
+ *     LUMEN_TRANSPORT_RCCL  RCCL over xGMI, loaded at run time (librccl.so.1): grouped ncclSend / ncclRecv
+ *                           for the two all-to-alls, ncclAllGather for the digests.  One communicator per
+ *                           rank: ncclCommInitAll for a process that owns all W devices (lumen_group_create),
+ *                           ncclCommInitRank for one process per GPU (lumen_group_create_rank).
+ *     LUMEN_TRANSPORT_AUTO  RCCL when the W contexts sit on W distinct devices, COPY otherwise.
+ * Every array argument below has lumen_group_local() entries, one per context of THIS process, in the order
+ * the contexts were given (ascending global rank).  Collectives are enqueued on the contexts' own streams
+ * and ordered against the work already enqueued there; nothing blocks the host unless it returns host data.
+ * Errors: non-zero return, text through lumen_last_error(NULL) on the calling thread. */
+#define LUMEN_TRANSPORT_AUTO 0
+#define LUMEN_TRANSPORT_COPY 1
+#define LUMEN_TRANSPORT_RCCL 2
+/* one process, all W ranks: ctxs[r] is rank r (contexts of the same parameters; clones of one context are
+ * fine and share its keys when they share its device). */
+int lumen_group_create(lumen_ctx *const *ctxs, uint32_t log_world, uint32_t transport, lumen_group **out);
+/* one process per GPU (what `torch.distributed.run bench.py` starts): rank 0 draws a 128-byte id
+ * (ncclGetUniqueId), the host hands it to every rank by any means, each rank joins with its own context. */
+int lumen_group_unique_id(uint8_t id[128]);
+int lumen_group_create_rank(lumen_ctx *ctx, uint32_t rank, uint32_t log_world, const uint8_t id[128],
+                            lumen_group **out);
+void lumen_group_destroy(lumen_group *g);
+uint32_t lumen_group_world(const lumen_group *g);
+uint32_t lumen_group_local(const lumen_group *g);
+/* "copy", "copy-peer" (several devices), "rccl" */
+const char *lumen_group_transport(const lumen_group *g);
+/* ranks the RCCL communicator reports (ncclCommCount); 0 for the copy transports */
+uint32_t lumen_group_rccl_ranks(const lumen_group *g);
+/* waits for everything enqueued on every local context */
+int lumen_group_sync(lumen_group *g);
+/* block p of send[.] (its p-th run of count/W ciphertexts: every layout is ct-major, so a contiguous slice)
+ * goes to rank p; block q of recv[.] comes from rank q.  send[i] and recv[i] have the same size. */
+int lumen_group_all_to_all(lumen_group *g, const lumen_set *const *send, lumen_set *const *recv);
+/* fhe.Encode (fhe/code.go:8-34) of a matrix whose columns are spread over the ranks: matrix[i] = the local
+ * rank's block of cols/W full-width columns; encoded[i] receives ITS block of S/W encoded columns, full width.
+ * zero_ct: the ONE fresh encryption of zero (code.go:15-22), host [2][nl][N], the same on every rank.
+ * Inside: lumen_lanes_split, all-to-all, Encode on the lane shard, all-to-all, lumen_lanes_assemble; for
+ * W = 1 plain lumen_encode.  Byte-identical to lumen_encode of the whole matrix on one GPU. */
+int lumen_group_encode(lumen_group *g, const lumen_set *const *matrix, const uint64_t *zero_ct,
+                       uint32_t rho_inv, lumen_set **encoded);
+/* Commit's one exchange (north_star: "a single RCCL all-gather ... to assemble the Merkle leaves"): ends the
+ * lumen_leaf_digests_begin job of every local context (same leaf count n on every rank) and all-gathers the
+ * digests in rank order = column order; afterwards every rank holds the W*n digests in device memory.
+ * lumen_group_merkle_root builds core.NewTree's root over them on the first local rank's device (only the
+ * root crosses PCIe); lumen_group_digests copies the W*n*32 bytes to the host, for the process that keeps
+ * the tree to answer Merkle paths (core/tree.go:113-163 via lumen_merkle_build). */
+int lumen_group_all_gather_digests(lumen_group *g);
+int lumen_group_merkle_root(lumen_group *g, uint8_t root[32]);
+int lumen_group_digests(lumen_group *g, uint8_t *digests, size_t cap, uint32_t *n_leaves);
+/* the query loop of Prove (fhe/ligero.go:268-279) over column-sharded leaves: src[i] = the local rank's block
+ * of S/W level-1 columns, idx = n GLOBAL column indices (duplicates allowed).  The owners gather their
+ * columns and send them to rank 0, which returns them in query order as *out (a set of rank 0's context);
+ * on a process that does not hold rank 0, *out = NULL. */
+int lumen_group_gather(lumen_group *g, const lumen_set *const *src, const uint32_t *idx, uint32_t n,
+                       lumen_set **out);
+/* HIP-event time of the collectives since the last reset: name = "all_to_all", "all_gather", "gather_to_root";
+ * ms = sum over calls of the slowest local rank's time on its stream (it includes waiting for the peers to
+ * arrive), bytes = what ONE rank sent to other ranks, summed over calls. */
+int lumen_group_stats(lumen_group *g, const char *name, double *ms, uint64_t *bytes, uint64_t *calls);
+int lumen_group_stats_reset(lumen_group *g);
 
 /* ---- timing on the context's stream (bench.py / roofline) */
 int lumen_timer_start(lumen_ctx *ctx);

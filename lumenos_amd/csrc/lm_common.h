@@ -294,3 +294,7 @@ void lm_build_tw(uint64_t q, uint64_t psi, uint32_t logN, std::vector<tw_t> &fwd
 int lm_rescale_polys(lumen_ctx *ctx, const u64 *src, uint32_t nl, u64 *dst, uint32_t target,
                      uint32_t npoly, u64 *work, u64 *tbuf);
 lm_modmap lm_map_q(uint32_t nl);
+// fhe.Encode with Enc(0) resident on the device; never blocks the host (lm_ctntt.hip)
+int lm_encode_dev(lumen_ctx *ctx, const lumen_set *matrix, const u64 *dzero, uint32_t rho_inv, lumen_set **encoded);
+// pooled timing events of a context (lm_ctx.hip)
+hipEvent_t lm_ev_get(lumen_ctx *ctx);

@@ -871,9 +871,9 @@ extern "C" int lumen_ct_ntt(lumen_ctx *ctx, lumen_set *values, uint32_t size) {
     return 0;
 }
 
-extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *zero_ct,
-                            uint32_t rho_inv, lumen_set **encoded) {
-    LM_CHECK(nullptr, ctx && matrix && zero_ct && encoded, "lumen_encode: NULL argument");
+// fhe.Encode with the one Enc(0) already in device memory (dzero: [2][nl][N >> logw] words, readable on the
+// context's stream): nothing here blocks the host, which is what lumen_group_encode needs to keep W devices fed
+int lm_encode_dev(lumen_ctx *ctx, const lumen_set *matrix, const u64 *dzero, uint32_t rho_inv, lumen_set **encoded) {
     LM_ENTER(ctx);
     LM_CHECK(ctx, rho_inv >= 1, "rho_inv must be >= 1");
     const uint32_t cols = matrix->count, S = cols * rho_inv, nl = matrix->nl;
@@ -882,11 +882,6 @@ extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint6
     // a lane shard (matrix->logw > 0) encodes like the whole: every lane sees the same butterflies, and the
     // zero ciphertext handed over is the same slice of the one Enc(0)
     const size_t ctw = lm_ctw(ctx, matrix);
-    // the single Enc(0) of code.go:15-22, broadcast to slots cols..S-1 by the first pass
-    u64 *dzero = (u64 *)lm_scratch(ctx, "zero_ct", ctw * sizeof(u64));
-    if (!dzero) return 1;
-    LM_HIP(ctx, hipMemcpyAsync(dzero, zero_ct, ctw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // zero_ct is caller memory
     lumen_set *out = nullptr;
     if (int rc = lumen_set_create_lanes(ctx, S, nl, matrix->logw, &out)) return rc;
     lm_set_guard og(ctx, out);
@@ -906,6 +901,20 @@ extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint6
     }
     *encoded = og.release();
     return 0;
+}
+
+extern "C" int lumen_encode(lumen_ctx *ctx, const lumen_set *matrix, const uint64_t *zero_ct,
+                            uint32_t rho_inv, lumen_set **encoded) {
+    LM_CHECK(nullptr, ctx && matrix && zero_ct && encoded, "lumen_encode: NULL argument");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, matrix->count > 0, "matrix is empty");
+    // the single Enc(0) of code.go:15-22, broadcast to slots cols..S-1 by the first pass
+    const size_t ctw = lm_ctw(ctx, matrix);
+    u64 *dzero = (u64 *)lm_scratch(ctx, "zero_ct", ctw * sizeof(u64));
+    if (!dzero) return 1;
+    LM_HIP(ctx, hipMemcpyAsync(dzero, zero_ct, ctw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // zero_ct is caller memory
+    return lm_encode_dev(ctx, matrix, dzero, rho_inv, encoded);
 }
 
 // Multi-GPU Commit: every rank runs the passes that mix all ciphertexts, but only its own

@@ -74,7 +74,7 @@ void *lm_stage(lumen_ctx *ctx, size_t bytes) {
     return ctx->stage_host;
 }
 
-static hipEvent_t ev_get(lumen_ctx *ctx) {
+hipEvent_t lm_ev_get(lumen_ctx *ctx) {
     if (!ctx->ev_pool.empty()) {
         hipEvent_t e = ctx->ev_pool.back();
         ctx->ev_pool.pop_back();
@@ -87,12 +87,12 @@ static hipEvent_t ev_get(lumen_ctx *ctx) {
 
 lm_prof_scope::lm_prof_scope(lumen_ctx *c, const char *n, uint64_t u) : ctx(c), name(n), units(u) {
     if (!ctx->prof) return;
-    a = ev_get(ctx);
+    a = lm_ev_get(ctx);
     hipEventRecord(a, ctx->stream);
 }
 lm_prof_scope::~lm_prof_scope() {
     if (!ctx->prof || !a) return;
-    hipEvent_t b = ev_get(ctx);
+    hipEvent_t b = lm_ev_get(ctx);
     hipEventRecord(b, ctx->stream);
     ctx->prof_pending.push_back({name, a, b, units});
 }

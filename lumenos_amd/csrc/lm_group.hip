@@ -1,0 +1,712 @@
+// Several GPUs behind one call sequence (include/lumenos_hip.h "lumen_group").
+//
+// The reference is ONE process that owns the whole request (cmd/server/main.go:187-266) and fans its work out
+// over goroutine pools (fhe/ligero.go:136-162, 231-242).  A lumen_group is that process's view of W = 2^k
+// ranks, one lumen_ctx per GPU, with the exchange steps of the sharded Commit inside the library:
+//   * two all-to-alls around the lane-sharded Encode (the ciphertext-axis transform never mixes lanes,
+//     fhe/ntt.go:245-279), every travelling block a contiguous slice of a ct-major set;
+//   * one all-gather of the S x 32-byte leaf digests (north_star's "single RCCL all-gather");
+//   * the queried columns collected on rank 0 (309 level-1 ciphertexts).
+// Transports: stream-ordered device copies pulled by the destination's stream (one device: hipMemcpyAsync;
+// several devices of one process: hipMemcpyPeerAsync), or RCCL over xGMI -- grouped ncclSend / ncclRecv and
+// ncclAllGather on the contexts' own streams.  RCCL is loaded at run time (dlopen): the library has no
+// link-time dependency on it, a one-GPU host never loads it, and a process that already carries an RCCL
+// (PyTorch's) shares that copy (same soname).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "lm_common.h"
+
+namespace {
+
+struct rccl_api {
+    void *handle = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why; // why loading failed
+};
+
+std::mutex g_rccl_mu;
+rccl_api g_rccl;
+
+// dlopen once per process; returns nullptr (with g_rccl.why set) when RCCL is not available
+rccl_api *rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.handle) return &g_rccl;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) {
+        const char *e = dlerror();
+        g_rccl.why = std::string("dlopen(librccl.so.1) failed: ") + (e ? e : "unknown");
+        return nullptr;
+    }
+    rccl_api a;
+    a.handle = h;
+    bool ok = true;
+#define LM_SYM(field, sym)                                        \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, sym)); \
+    if (!a.field) ok = false, a.why += std::string(" ") + sym;
+    LM_SYM(GetVersion, "ncclGetVersion")
+    LM_SYM(GetUniqueId, "ncclGetUniqueId")
+    LM_SYM(CommInitRank, "ncclCommInitRank")
+    LM_SYM(CommInitAll, "ncclCommInitAll")
+    LM_SYM(CommDestroy, "ncclCommDestroy")
+    LM_SYM(CommCount, "ncclCommCount")
+    LM_SYM(Send, "ncclSend")
+    LM_SYM(Recv, "ncclRecv")
+    LM_SYM(AllGather, "ncclAllGather")
+    LM_SYM(GroupStart, "ncclGroupStart")
+    LM_SYM(GroupEnd, "ncclGroupEnd")
+    LM_SYM(GetErrorString, "ncclGetErrorString")
+#undef LM_SYM
+    if (!ok) {
+        g_rccl.why = "librccl lacks:" + a.why;
+        dlclose(h);
+        return nullptr;
+    }
+    g_rccl = a;
+    return &g_rccl;
+}
+
+struct stat_entry {
+    double ms = 0;
+    uint64_t bytes = 0, calls = 0;
+};
+
+} // namespace
+
+struct lumen_group {
+    std::recursive_mutex mu;
+    uint32_t logw = 0, W = 1;
+    std::vector<lumen_ctx *> ctx;   // local contexts, ascending global rank
+    std::vector<uint32_t> rank;     // their global ranks
+    int transport = LUMEN_TRANSPORT_COPY;
+    bool multi_device = false;
+    rccl_api *rccl = nullptr;
+    std::vector<ncclComm_t> comm;   // one per local context (RCCL)
+    uint32_t rccl_ranks = 0;
+    // dependency events, one pair per local context, created on its device
+    std::vector<hipEvent_t> ev_ready, ev_done;
+    // the all-gathered leaf digests: W * n_leaves_per_rank * 32 bytes in every local context's scratch
+    std::vector<uint8_t *> d_digests;
+    uint32_t n_per_rank = 0;
+    // timing of the collectives
+    struct pending {
+        std::string name;
+        uint64_t call;
+        uint32_t local;
+        hipEvent_t a, b;
+        uint64_t bytes;
+    };
+    std::vector<pending> pend;
+    std::map<std::string, stat_entry> stats;
+    uint64_t call_seq = 0;
+};
+
+namespace {
+
+// locks the group and every local context (always in the same order) and leaves the calling thread's
+// last-error state clean, like LM_ENTER does for one context
+struct group_lock {
+    std::unique_lock<std::recursive_mutex> g;
+    std::vector<std::unique_lock<std::recursive_mutex>> c;
+    explicit group_lock(lumen_group *grp) : g(grp->mu) {
+        for (lumen_ctx *x : grp->ctx) c.emplace_back(x->mu);
+        (void)hipGetLastError();
+    }
+};
+
+#define G_HIP(call)                                                                                                  \
+    do {                                                                                                             \
+        hipError_t e_ = (call);                                                                                      \
+        if (e_ != hipSuccess)                                                                                        \
+            return lm_fail(nullptr, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);      \
+    } while (0)
+#define G_NCCL(g, call)                                                                                              \
+    do {                                                                                                             \
+        ncclResult_t r_ = (call);                                                                                    \
+        if (r_ != ncclSuccess)                                                                                       \
+            return lm_fail(nullptr, "%s failed: %s (%s:%d)", #call, (g)->rccl->GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+int use(lumen_group *g, uint32_t i) {
+    G_HIP(hipSetDevice(g->ctx[i]->device));
+    return 0;
+}
+
+// timing bracket of one collective on local rank i's stream
+void time_begin(lumen_group *g, const char *name, uint32_t i, uint64_t bytes) {
+    lumen_group::pending p;
+    p.name = name, p.call = g->call_seq, p.local = i, p.bytes = bytes;
+    p.a = lm_ev_get(g->ctx[i]);
+    p.b = nullptr;
+    hipEventRecord(p.a, g->ctx[i]->stream);
+    g->pend.push_back(p);
+}
+void time_end(lumen_group *g, uint32_t i) {
+    for (auto it = g->pend.rbegin(); it != g->pend.rend(); ++it)
+        if (it->local == i && it->call == g->call_seq && !it->b) {
+            it->b = lm_ev_get(g->ctx[i]);
+            hipEventRecord(it->b, g->ctx[i]->stream);
+            return;
+        }
+}
+
+void stats_resolve(lumen_group *g) {
+    // per call: the slowest local rank's time; bytes as sent by one rank
+    std::map<std::pair<std::string, uint64_t>, std::pair<double, uint64_t>> per_call;
+    for (auto &p : g->pend) {
+        float ms = 0;
+        (void)hipSetDevice(g->ctx[p.local]->device);
+        if (p.b && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &e = per_call[{p.name, p.call}];
+            e.first = std::max(e.first, (double)ms);
+            e.second = std::max(e.second, p.bytes);
+        } else {
+            (void)hipGetLastError();
+        }
+        g->ctx[p.local]->ev_pool.push_back(p.a);
+        if (p.b) g->ctx[p.local]->ev_pool.push_back(p.b);
+    }
+    g->pend.clear();
+    for (auto &kv : per_call) {
+        auto &s = g->stats[kv.first.first];
+        s.ms += kv.second.first, s.bytes += kv.second.second, s.calls += 1;
+    }
+}
+
+// "everything enqueued so far on every local rank" -> ev_ready; then dst's stream waits for all of them
+int ready_all(lumen_group *g) {
+    for (uint32_t i = 0; i < g->ctx.size(); i++) {
+        if (use(g, i)) return 1;
+        G_HIP(hipEventRecord(g->ev_ready[i], g->ctx[i]->stream));
+    }
+    return 0;
+}
+int wait_ready(lumen_group *g, uint32_t j) {
+    for (uint32_t i = 0; i < g->ctx.size(); i++)
+        if (i != j) G_HIP(hipStreamWaitEvent(g->ctx[j]->stream, g->ev_ready[i], 0));
+    return 0;
+}
+// the sources may reuse what was read once every destination has pulled its part
+int done_all(lumen_group *g, const std::vector<uint32_t> &dsts) {
+    for (uint32_t i = 0; i < g->ctx.size(); i++) {
+        if (use(g, i)) return 1;
+        for (uint32_t j : dsts)
+            if (i != j) G_HIP(hipStreamWaitEvent(g->ctx[i]->stream, g->ev_done[j], 0));
+    }
+    return 0;
+}
+
+int copy_between(lumen_group *g, uint32_t dst_local, void *dst, uint32_t src_local, const void *src, size_t bytes) {
+    lumen_ctx *d = g->ctx[dst_local], *s = g->ctx[src_local];
+    if (!bytes) return 0;
+    if (d->device == s->device)
+        G_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, d->stream));
+    else
+        G_HIP(hipMemcpyPeerAsync(dst, d->device, src, s->device, bytes, d->stream));
+    return 0;
+}
+
+bool same_params(const lumen_ctx *a, const lumen_ctx *b) {
+    return a->logN == b->logN && a->L == b->L && a->K == b->K && a->T == b->T &&
+           !memcmp(a->mod, b->mod, sizeof(uint64_t) * (a->L + a->K));
+}
+
+int group_finish_create(lumen_group *g) {
+    const uint32_t n = (uint32_t)g->ctx.size();
+    g->ev_ready.assign(n, nullptr), g->ev_done.assign(n, nullptr), g->d_digests.assign(n, nullptr);
+    for (uint32_t i = 0; i < n; i++) {
+        if (use(g, i)) return 1;
+        G_HIP(hipEventCreateWithFlags(&g->ev_ready[i], hipEventDisableTiming));
+        G_HIP(hipEventCreateWithFlags(&g->ev_done[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" void lumen_group_destroy(lumen_group *g) {
+    if (!g) return;
+    {
+        group_lock lk(g);
+        for (uint32_t i = 0; i < g->ctx.size(); i++) {
+            (void)hipSetDevice(g->ctx[i]->device);
+            lm_sync_all(g->ctx[i]);
+        }
+        stats_resolve(g);
+        for (uint32_t i = 0; i < g->comm.size(); i++)
+            if (g->comm[i]) {
+                (void)hipSetDevice(g->ctx[i]->device);
+                g->rccl->CommDestroy(g->comm[i]);
+            }
+        for (hipEvent_t e : g->ev_ready)
+            if (e) hipEventDestroy(e);
+        for (hipEvent_t e : g->ev_done)
+            if (e) hipEventDestroy(e);
+    }
+    delete g;
+}
+
+extern "C" int lumen_group_create(lumen_ctx *const *ctxs, uint32_t log_world, uint32_t transport, lumen_group **out) {
+    LM_CHECK(nullptr, ctxs && out, "lumen_group_create: NULL argument");
+    *out = nullptr;
+    LM_CHECK(nullptr, log_world <= 6, "lumen_group_create: log_world %u out of range [0, 6]", log_world);
+    LM_CHECK(nullptr, transport <= LUMEN_TRANSPORT_RCCL, "lumen_group_create: unknown transport %u", transport);
+    const uint32_t W = 1u << log_world;
+    std::set<int> devices;
+    for (uint32_t r = 0; r < W; r++) {
+        LM_CHECK(nullptr, ctxs[r], "lumen_group_create: context of rank %u is NULL", r);
+        for (uint32_t q = 0; q < r; q++) LM_CHECK(nullptr, ctxs[q] != ctxs[r], "lumen_group_create: ranks %u and %u are the same context", q, r);
+        LM_CHECK(nullptr, same_params(ctxs[0], ctxs[r]), "lumen_group_create: rank %u has other parameters than rank 0", r);
+        devices.insert(ctxs[r]->device);
+    }
+    LM_CHECK(nullptr, W == 1 || (ctxs[0]->N >> log_world) >= 64,
+             "lumen_group_create: a lane shard of 1/%u of N = %u is narrower than 64 coefficients", W, ctxs[0]->N);
+    const bool distinct = devices.size() == W;
+    if (transport == LUMEN_TRANSPORT_AUTO) transport = (distinct && W > 1) ? LUMEN_TRANSPORT_RCCL : LUMEN_TRANSPORT_COPY;
+    LM_CHECK(nullptr, transport != LUMEN_TRANSPORT_RCCL || distinct,
+             "lumen_group_create: RCCL needs every rank on its own device (%zu devices for %u ranks); use LUMEN_TRANSPORT_COPY", devices.size(), W);
+    std::unique_ptr<lumen_group, void (*)(lumen_group *)> guard(new lumen_group(), lumen_group_destroy);
+    lumen_group *g = guard.get();
+    g->logw = log_world, g->W = W, g->transport = (int)transport, g->multi_device = devices.size() > 1;
+    for (uint32_t r = 0; r < W; r++) g->ctx.push_back(ctxs[r]), g->rank.push_back(r);
+    group_lock lk(g);
+    if (group_finish_create(g)) return 1;
+    if (transport == LUMEN_TRANSPORT_RCCL) {
+        g->rccl = rccl_load();
+        LM_CHECK(nullptr, g->rccl, "lumen_group_create: RCCL transport unavailable: %s", g_rccl.why.c_str());
+        std::vector<int> devs;
+        for (lumen_ctx *c : g->ctx) devs.push_back(c->device);
+        g->comm.assign(W, nullptr);
+        G_NCCL(g, g->rccl->CommInitAll(g->comm.data(), (int)W, devs.data()));
+        int cnt = 0;
+        G_NCCL(g, g->rccl->CommCount(g->comm[0], &cnt));
+        g->rccl_ranks = (uint32_t)cnt;
+        LM_CHECK(nullptr, g->rccl_ranks == W, "lumen_group_create: the RCCL communicator reports %u ranks, expected %u", g->rccl_ranks, W);
+    } else if (g->multi_device) {
+        // peer access where the hardware offers it (xGMI): hipMemcpyPeerAsync then copies device to device
+        for (uint32_t i = 0; i < W; i++)
+            for (uint32_t j = 0; j < W; j++) {
+                const int di = g->ctx[i]->device, dj = g->ctx[j]->device;
+                int can = 0;
+                if (di == dj || hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess || !can) continue;
+                (void)hipSetDevice(di);
+                (void)hipDeviceEnablePeerAccess(dj, 0); // "already enabled" is fine
+                (void)hipGetLastError();
+            }
+    }
+    *out = guard.release();
+    return 0;
+}
+
+extern "C" int lumen_group_unique_id(uint8_t id[128]) {
+    LM_CHECK(nullptr, id, "lumen_group_unique_id: NULL argument");
+    rccl_api *r = rccl_load();
+    LM_CHECK(nullptr, r, "lumen_group_unique_id: RCCL unavailable: %s", g_rccl.why.c_str());
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    ncclResult_t rc = r->GetUniqueId(&u);
+    LM_CHECK(nullptr, rc == ncclSuccess, "ncclGetUniqueId failed: %s", r->GetErrorString(rc));
+    memcpy(id, &u, 128);
+    return 0;
+}
+
+extern "C" int lumen_group_create_rank(lumen_ctx *ctx, uint32_t rank, uint32_t log_world, const uint8_t id[128],
+                                       lumen_group **out) {
+    LM_CHECK(nullptr, ctx && id && out, "lumen_group_create_rank: NULL argument");
+    *out = nullptr;
+    LM_CHECK(nullptr, log_world <= 6 && rank < (1u << log_world), "lumen_group_create_rank: rank %u of 2^%u", rank, log_world);
+    const uint32_t W = 1u << log_world;
+    LM_CHECK(nullptr, W == 1 || (ctx->N >> log_world) >= 64,
+             "lumen_group_create_rank: a lane shard of 1/%u of N = %u is narrower than 64 coefficients", W, ctx->N);
+    std::unique_ptr<lumen_group, void (*)(lumen_group *)> guard(new lumen_group(), lumen_group_destroy);
+    lumen_group *g = guard.get();
+    g->logw = log_world, g->W = W, g->transport = LUMEN_TRANSPORT_RCCL;
+    g->ctx.push_back(ctx), g->rank.push_back(rank);
+    group_lock lk(g);
+    if (group_finish_create(g)) return 1;
+    g->rccl = rccl_load();
+    LM_CHECK(nullptr, g->rccl, "lumen_group_create_rank: RCCL unavailable: %s", g_rccl.why.c_str());
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    g->comm.assign(1, nullptr);
+    if (use(g, 0)) return 1;
+    G_NCCL(g, g->rccl->CommInitRank(&g->comm[0], (int)W, u, (int)rank));
+    int cnt = 0;
+    G_NCCL(g, g->rccl->CommCount(g->comm[0], &cnt));
+    g->rccl_ranks = (uint32_t)cnt;
+    LM_CHECK(nullptr, g->rccl_ranks == W, "lumen_group_create_rank: the RCCL communicator reports %u ranks, expected %u", g->rccl_ranks, W);
+    *out = guard.release();
+    return 0;
+}
+
+extern "C" uint32_t lumen_group_world(const lumen_group *g) { return g ? g->W : 0; }
+extern "C" uint32_t lumen_group_local(const lumen_group *g) { return g ? (uint32_t)g->ctx.size() : 0; }
+extern "C" uint32_t lumen_group_rccl_ranks(const lumen_group *g) { return g ? g->rccl_ranks : 0; }
+extern "C" const char *lumen_group_transport(const lumen_group *g) {
+    if (!g) return "";
+    return g->transport == LUMEN_TRANSPORT_RCCL ? "rccl" : (g->multi_device ? "copy-peer" : "copy");
+}
+
+extern "C" int lumen_group_sync(lumen_group *g) {
+    LM_CHECK(nullptr, g, "lumen_group_sync: NULL group");
+    group_lock lk(g);
+    for (uint32_t i = 0; i < g->ctx.size(); i++) {
+        if (use(g, i)) return 1;
+        G_HIP(hipStreamSynchronize(g->ctx[i]->stream));
+    }
+    return 0;
+}
+
+// ---- all-to-all on contiguous blocks.  send_ptr[i] / recv_ptr[i]: base of local rank i's W blocks of blk bytes.
+static int all_to_all_raw(lumen_group *g, const std::vector<const u64 *> &send, const std::vector<u64 *> &recv, size_t blk_words) {
+    const uint32_t n = (uint32_t)g->ctx.size(), W = g->W;
+    g->call_seq++;
+    const uint64_t sent = (uint64_t)blk_words * 8 * (W - 1);
+    if (g->transport == LUMEN_TRANSPORT_RCCL) {
+        for (uint32_t i = 0; i < n; i++) {
+            if (use(g, i)) return 1;
+            time_begin(g, "all_to_all", i, sent);
+        }
+        G_NCCL(g, g->rccl->GroupStart());
+        for (uint32_t i = 0; i < n; i++) {
+            if (use(g, i)) return 1;
+            for (uint32_t p = 0; p < W; p++) {
+                G_NCCL(g, g->rccl->Send(send[i] + (size_t)p * blk_words, blk_words, ncclUint64, (int)p, g->comm[i], g->ctx[i]->stream));
+                G_NCCL(g, g->rccl->Recv(recv[i] + (size_t)p * blk_words, blk_words, ncclUint64, (int)p, g->comm[i], g->ctx[i]->stream));
+            }
+        }
+        G_NCCL(g, g->rccl->GroupEnd());
+        for (uint32_t i = 0; i < n; i++) {
+            if (use(g, i)) return 1;
+            time_end(g, i);
+        }
+        return 0;
+    }
+    // copy transport: every rank is local (n == W, local index == rank)
+    for (uint32_t i = 0; i < n; i++) {
+        if (use(g, i)) return 1;
+        time_begin(g, "all_to_all", i, sent);
+    }
+    if (ready_all(g)) return 1;
+    std::vector<uint32_t> all;
+    for (uint32_t j = 0; j < n; j++) {
+        if (use(g, j) || wait_ready(g, j)) return 1;
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t i = (j + k) % n; // start with the rank's own block, then spread over the peers
+            if (copy_between(g, j, recv[j] + (size_t)i * blk_words, i, send[i] + (size_t)j * blk_words, blk_words * 8)) return 1;
+        }
+        G_HIP(hipEventRecord(g->ev_done[j], g->ctx[j]->stream));
+        all.push_back(j);
+    }
+    if (done_all(g, all)) return 1;
+    for (uint32_t i = 0; i < n; i++) {
+        if (use(g, i)) return 1;
+        time_end(g, i);
+    }
+    return 0;
+}
+
+extern "C" int lumen_group_all_to_all(lumen_group *g, const lumen_set *const *send, lumen_set *const *recv) {
+    LM_CHECK(nullptr, g && send && recv, "lumen_group_all_to_all: NULL argument");
+    group_lock lk(g);
+    const uint32_t n = (uint32_t)g->ctx.size(), W = g->W;
+    std::vector<const u64 *> sp;
+    std::vector<u64 *> rp;
+    for (uint32_t i = 0; i < n; i++) {
+        LM_CHECK(nullptr, send[i] && recv[i], "lumen_group_all_to_all: set %u is NULL", i);
+        LM_CHECK(nullptr, send[i]->words == recv[i]->words && send[i]->words == send[0]->words,
+                 "lumen_group_all_to_all: send and receive sets differ in size (%zu / %zu words at local rank %u, %zu at 0)",
+                 send[i]->words, recv[i]->words, i, send[0]->words);
+        LM_CHECK(nullptr, send[i]->count % W == 0 && recv[i]->count % W == 0,
+                 "lumen_group_all_to_all: %u / %u ciphertexts are not %u equal blocks", send[i]->count, recv[i]->count, W);
+        LM_CHECK(nullptr, (const void *)send[i]->d != (const void *)recv[i]->d, "lumen_group_all_to_all: in-place exchange");
+        sp.push_back(send[i]->d), rp.push_back(recv[i]->d);
+    }
+    if (!send[0]->words) return 0;
+    return all_to_all_raw(g, sp, rp, send[0]->words / W);
+}
+
+// ---- fhe.Encode over column-sharded input (include/lumenos_hip.h)
+namespace {
+struct set_bin { // temporaries of a group call: destroyed (through their contexts) when the call ends
+    std::vector<std::pair<lumen_ctx *, lumen_set *>> v;
+    lumen_set *keep(lumen_ctx *c, lumen_set *s) {
+        v.emplace_back(c, s);
+        return s;
+    }
+    ~set_bin() {
+        for (auto &p : v) {
+            (void)hipSetDevice(p.first->device);
+            lumen_set_destroy(p.first, p.second);
+        }
+    }
+};
+} // namespace
+
+extern "C" int lumen_group_encode(lumen_group *g, const lumen_set *const *matrix, const uint64_t *zero_ct,
+                                  uint32_t rho_inv, lumen_set **encoded) {
+    LM_CHECK(nullptr, g && matrix && zero_ct && encoded, "lumen_group_encode: NULL argument");
+    group_lock lk(g);
+    const uint32_t n = (uint32_t)g->ctx.size(), W = g->W, logw = g->logw;
+    for (uint32_t i = 0; i < n; i++) {
+        encoded[i] = nullptr;
+        LM_CHECK(nullptr, matrix[i], "lumen_group_encode: matrix block %u is NULL", i);
+        LM_CHECK(nullptr, matrix[i]->logw == 0, "lumen_group_encode: block %u is a lane shard, full-width columns are required", i);
+        LM_CHECK(nullptr, matrix[i]->count == matrix[0]->count && matrix[i]->nl == matrix[0]->nl && matrix[i]->count > 0,
+                 "lumen_group_encode: block %u holds %u columns of %u limbs, block 0 %u of %u", i, matrix[i]->count, matrix[i]->nl,
+                 matrix[0]->count, matrix[0]->nl);
+    }
+    if (W == 1) return lumen_encode(g->ctx[0], matrix[0], zero_ct, rho_inv, &encoded[0]);
+    const uint32_t own = matrix[0]->count, cols = own * W, S = cols * rho_inv, nl = matrix[0]->nl;
+    const uint32_t N = g->ctx[0]->N, Nw = N >> logw;
+    // every rank's slice of the ONE Enc(0): staged through the context's pinned buffer, no host block
+    std::vector<u64 *> dzero(n);
+    for (uint32_t i = 0; i < n; i++) {
+        lumen_ctx *c = g->ctx[i];
+        if (use(g, i)) return 1;
+        const size_t words = (size_t)2 * nl * Nw;
+        u64 *h = (u64 *)lm_stage(c, words * 8);
+        dzero[i] = (u64 *)lm_scratch(c, "zero_ct", words * 8);
+        if (!h || !dzero[i]) return 1;
+        for (uint32_t row = 0; row < 2 * nl; row++)
+            memcpy(h + (size_t)row * Nw, zero_ct + (size_t)row * N + (size_t)g->rank[i] * Nw, (size_t)Nw * 8);
+        G_HIP(hipMemcpyAsync(dzero[i], h, words * 8, hipMemcpyHostToDevice, c->stream));
+        G_HIP(hipEventRecord(c->ev_stage, c->stream));
+    }
+    set_bin bin;
+    std::vector<const lumen_set *> a(n);
+    std::vector<lumen_set *> b(n);
+    // own columns -> W lane blocks -> all-to-all -> the rank's lane shard of ALL columns
+    for (uint32_t i = 0; i < n; i++) {
+        lumen_set *blk = nullptr, *lanes = nullptr;
+        if (use(g, i) || lumen_lanes_split(g->ctx[i], matrix[i], logw, &blk)) return 1;
+        bin.keep(g->ctx[i], blk);
+        if (lumen_set_create_lanes(g->ctx[i], cols, nl, logw, &lanes)) return 1;
+        bin.keep(g->ctx[i], lanes);
+        a[i] = blk, b[i] = lanes;
+    }
+    if (lumen_group_all_to_all(g, a.data(), b.data())) return 1;
+    // Encode on the lane shard, then block h of every shard -> rank h
+    for (uint32_t i = 0; i < n; i++) {
+        lumen_set *enc = nullptr, *recv = nullptr;
+        if (use(g, i) || lm_encode_dev(g->ctx[i], b[i], dzero[i], rho_inv, &enc)) return 1;
+        bin.keep(g->ctx[i], enc);
+        if (lumen_set_create_lanes(g->ctx[i], S, nl, logw, &recv)) return 1;
+        bin.keep(g->ctx[i], recv);
+        a[i] = enc, b[i] = recv;
+    }
+    if (lumen_group_all_to_all(g, a.data(), b.data())) return 1;
+    std::vector<lumen_set *> mine(n, nullptr);
+    for (uint32_t i = 0; i < n; i++) {
+        if (use(g, i) || lumen_lanes_assemble(g->ctx[i], b[i], &mine[i])) {
+            for (uint32_t k = 0; k < i; k++) lumen_set_destroy(g->ctx[k], mine[k]);
+            return 1;
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) encoded[i] = mine[i];
+    return 0; // `bin` gives the temporaries back (each destroy waits for its own context's stream only)
+}
+
+// ---- Commit's exchange: all-gather of the leaf digests
+extern "C" int lumen_group_all_gather_digests(lumen_group *g) {
+    LM_CHECK(nullptr, g, "lumen_group_all_gather_digests: NULL group");
+    group_lock lk(g);
+    const uint32_t n = (uint32_t)g->ctx.size(), W = g->W;
+    uint32_t per = 0;
+    std::vector<const uint8_t *> src(n);
+    for (uint32_t i = 0; i < n; i++) {
+        lumen_ctx *c = g->ctx[i];
+        LM_CHECK(nullptr, c->aux_digests, "lumen_group_all_gather_digests: local rank %u has no lumen_leaf_digests_begin job in flight", i);
+        if (i == 0) per = c->aux_digests;
+        LM_CHECK(nullptr, c->aux_digests == per, "lumen_group_all_gather_digests: local rank %u hashed %u leaves, rank 0 %u", i, c->aux_digests, per);
+    }
+    g->call_seq++;
+    const size_t part = (size_t)per * 32;
+    for (uint32_t i = 0; i < n; i++) {
+        lumen_ctx *c = g->ctx[i];
+        if (use(g, i)) return 1;
+        auto it = c->scratch.find("digests_async");
+        LM_CHECK(nullptr, it != c->scratch.end() && it->second.first, "digest buffer missing");
+        src[i] = (const uint8_t *)it->second.first;
+        g->d_digests[i] = (uint8_t *)lm_scratch(c, "group_digests", part * W);
+        if (!g->d_digests[i]) return 1;
+        // the job ends on the device: the main stream waits for the side stream, the host does not
+        c->aux_digests = 0;
+        c->aux_lo = c->aux_hi = nullptr;
+        G_HIP(hipEventRecord(c->ev_aux, c->stream_aux));
+        G_HIP(hipStreamWaitEvent(c->stream, c->ev_aux, 0));
+        time_begin(g, "all_gather", i, (uint64_t)part * (W - 1));
+    }
+    g->n_per_rank = per;
+    if (g->transport == LUMEN_TRANSPORT_RCCL) {
+        G_NCCL(g, g->rccl->GroupStart());
+        for (uint32_t i = 0; i < n; i++) {
+            if (use(g, i)) return 1;
+            G_NCCL(g, g->rccl->AllGather(src[i], g->d_digests[i], part, ncclUint8, g->comm[i], g->ctx[i]->stream));
+        }
+        G_NCCL(g, g->rccl->GroupEnd());
+    } else {
+        if (ready_all(g)) return 1;
+        std::vector<uint32_t> all;
+        for (uint32_t j = 0; j < n; j++) {
+            if (use(g, j) || wait_ready(g, j)) return 1;
+            for (uint32_t i = 0; i < n; i++)
+                if (copy_between(g, j, g->d_digests[j] + (size_t)i * part, i, src[i], part)) return 1;
+            G_HIP(hipEventRecord(g->ev_done[j], g->ctx[j]->stream));
+            all.push_back(j);
+        }
+        if (done_all(g, all)) return 1;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        if (use(g, i)) return 1;
+        time_end(g, i);
+    }
+    return 0;
+}
+
+extern "C" int lumen_group_merkle_root(lumen_group *g, uint8_t root[32]) {
+    LM_CHECK(nullptr, g && root, "lumen_group_merkle_root: NULL argument");
+    group_lock lk(g);
+    LM_CHECK(nullptr, g->n_per_rank && g->d_digests[0], "lumen_group_merkle_root: no gathered digests (lumen_group_all_gather_digests first)");
+    if (use(g, 0)) return 1;
+    return lumen_merkle_root_device(g->ctx[0], g->d_digests[0], g->n_per_rank * g->W, root);
+}
+
+extern "C" int lumen_group_digests(lumen_group *g, uint8_t *digests, size_t cap, uint32_t *n_leaves) {
+    LM_CHECK(nullptr, g && digests, "lumen_group_digests: NULL argument");
+    group_lock lk(g);
+    LM_CHECK(nullptr, g->n_per_rank && g->d_digests[0], "lumen_group_digests: no gathered digests (lumen_group_all_gather_digests first)");
+    const size_t bytes = (size_t)g->n_per_rank * g->W * 32;
+    LM_CHECK(nullptr, cap >= bytes, "lumen_group_digests: buffer of %zu bytes, %zu needed", cap, bytes);
+    if (use(g, 0)) return 1;
+    G_HIP(hipMemcpyAsync(digests, g->d_digests[0], bytes, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    G_HIP(hipStreamSynchronize(g->ctx[0]->stream));
+    if (n_leaves) *n_leaves = g->n_per_rank * g->W;
+    return 0;
+}
+
+// ---- the query loop over column-sharded leaves
+extern "C" int lumen_group_gather(lumen_group *g, const lumen_set *const *src, const uint32_t *idx, uint32_t nq,
+                                  lumen_set **out) {
+    LM_CHECK(nullptr, g && src && out && (idx || !nq), "lumen_group_gather: NULL argument");
+    *out = nullptr;
+    group_lock lk(g);
+    const uint32_t n = (uint32_t)g->ctx.size(), W = g->W;
+    for (uint32_t i = 0; i < n; i++) {
+        LM_CHECK(nullptr, src[i], "lumen_group_gather: block %u is NULL", i);
+        LM_CHECK(nullptr, src[i]->count == src[0]->count && src[i]->nl == src[0]->nl && src[i]->logw == 0,
+                 "lumen_group_gather: block %u differs in shape from block 0", i);
+    }
+    const bool have_root = g->rank[0] == 0;
+    if (W == 1) return lumen_gather(g->ctx[0], src[0], idx, nq, out);
+    const uint32_t per = src[0]->count, nl = src[0]->nl;
+    const size_t ctw = (size_t)2 * nl * g->ctx[0]->N;
+    // who owns what: queries of rank p, in query order
+    std::vector<std::vector<uint32_t>> local_idx(W);
+    std::vector<uint32_t> perm(nq), off(W + 1, 0);
+    for (uint32_t k = 0; k < nq; k++) {
+        LM_CHECK(nullptr, per && idx[k] / per < W, "lumen_group_gather: column %u out of range (%u x %u columns)", idx[k], W, per);
+        local_idx[idx[k] / per].push_back(idx[k] % per);
+    }
+    for (uint32_t p = 0; p < W; p++) off[p + 1] = off[p] + (uint32_t)local_idx[p].size();
+    {
+        std::vector<uint32_t> seen(W, 0);
+        for (uint32_t k = 0; k < nq; k++) {
+            const uint32_t p = idx[k] / per;
+            perm[k] = off[p] + seen[p]++;
+        }
+    }
+    g->call_seq++;
+    set_bin bin;
+    std::vector<lumen_set *> q(n, nullptr);
+    for (uint32_t i = 0; i < n; i++) {
+        const auto &li = local_idx[g->rank[i]];
+        if (li.empty()) continue;
+        if (use(g, i) || lumen_gather(g->ctx[i], src[i], li.data(), (uint32_t)li.size(), &q[i])) return 1;
+        bin.keep(g->ctx[i], q[i]);
+    }
+    lumen_set *stage = nullptr;
+    if (have_root) {
+        if (use(g, 0) || lumen_set_create(g->ctx[0], nq, nl, &stage)) return 1;
+        bin.keep(g->ctx[0], stage);
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        if (use(g, i)) return 1;
+        const uint64_t sent = g->rank[i] == 0 ? 0 : (uint64_t)local_idx[g->rank[i]].size() * ctw * 8;
+        time_begin(g, "gather_to_root", i, sent);
+    }
+    if (g->transport == LUMEN_TRANSPORT_RCCL) {
+        if (have_root && q[0]) { // rank 0's own columns: a device copy
+            if (use(g, 0)) return 1;
+            G_HIP(hipMemcpyAsync(stage->d, q[0]->d, q[0]->words * 8, hipMemcpyDeviceToDevice, g->ctx[0]->stream));
+        }
+        G_NCCL(g, g->rccl->GroupStart());
+        for (uint32_t i = 0; i < n; i++) {
+            if (use(g, i)) return 1;
+            if (g->rank[i] != 0 && q[i])
+                G_NCCL(g, g->rccl->Send(q[i]->d, q[i]->words, ncclUint64, 0, g->comm[i], g->ctx[i]->stream));
+        }
+        if (have_root) {
+            if (use(g, 0)) return 1;
+            for (uint32_t p = 1; p < W; p++)
+                if (off[p + 1] > off[p])
+                    G_NCCL(g, g->rccl->Recv(stage->d + (size_t)off[p] * ctw, (size_t)(off[p + 1] - off[p]) * ctw, ncclUint64, (int)p,
+                                            g->comm[0], g->ctx[0]->stream));
+        }
+        G_NCCL(g, g->rccl->GroupEnd());
+    } else {
+        if (ready_all(g)) return 1;
+        if (use(g, 0) || wait_ready(g, 0)) return 1;
+        for (uint32_t i = 0; i < n; i++)
+            if (q[i] && copy_between(g, 0, stage->d + (size_t)off[i] * ctw, i, q[i]->d, q[i]->words * 8)) return 1;
+        G_HIP(hipEventRecord(g->ev_done[0], g->ctx[0]->stream));
+        if (done_all(g, {0})) return 1;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        if (use(g, i)) return 1;
+        time_end(g, i);
+    }
+    if (have_root) {
+        if (use(g, 0)) return 1;
+        if (lumen_gather(g->ctx[0], stage, perm.data(), nq, out)) return 1;
+    }
+    return 0;
+}
+
+extern "C" int lumen_group_stats(lumen_group *g, const char *name, double *ms, uint64_t *bytes, uint64_t *calls) {
+    LM_CHECK(nullptr, g && name, "lumen_group_stats: NULL argument");
+    group_lock lk(g);
+    stats_resolve(g);
+    stat_entry e;
+    auto it = g->stats.find(name);
+    if (it != g->stats.end()) e = it->second;
+    if (ms) *ms = e.ms;
+    if (bytes) *bytes = e.bytes;
+    if (calls) *calls = e.calls;
+    return 0;
+}
+
+extern "C" int lumen_group_stats_reset(lumen_group *g) {
+    LM_CHECK(nullptr, g, "lumen_group_stats_reset: NULL group");
+    group_lock lk(g);
+    stats_resolve(g);
+    g->stats.clear();
+    return 0;
+}

@@ -15,7 +15,7 @@ _u64p = C.POINTER(C.c_uint64)
 _u32p = C.POINTER(C.c_uint32)
 _u8p = C.POINTER(C.c_uint8)
 LUMEN_MAX_LIMBS = 24
-LUMEN_ABI_VERSION = 3
+LUMEN_ABI_VERSION = 4
 
 
 class LumenError(RuntimeError):
@@ -96,6 +96,23 @@ SYMBOLS = {
     "lumen_ringswitch_digits": (C.c_uint32, [_vp, C.c_uint32]),
     "lumen_load_ringswitch_key": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _u64p]),
     "lumen_ring_switch": (C.c_int, [_vp, _vp, _u64p]),
+    "lumen_group_create": (C.c_int, [_vpp, C.c_uint32, C.c_uint32, _vpp]),
+    "lumen_group_unique_id": (C.c_int, [_u8p]),
+    "lumen_group_create_rank": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _u8p, _vpp]),
+    "lumen_group_destroy": (None, [_vp]),
+    "lumen_group_world": (C.c_uint32, [_vp]),
+    "lumen_group_local": (C.c_uint32, [_vp]),
+    "lumen_group_transport": (C.c_char_p, [_vp]),
+    "lumen_group_rccl_ranks": (C.c_uint32, [_vp]),
+    "lumen_group_sync": (C.c_int, [_vp]),
+    "lumen_group_all_to_all": (C.c_int, [_vp, _vpp, _vpp]),
+    "lumen_group_encode": (C.c_int, [_vp, _vpp, _u64p, C.c_uint32, _vpp]),
+    "lumen_group_all_gather_digests": (C.c_int, [_vp]),
+    "lumen_group_merkle_root": (C.c_int, [_vp, _u8p]),
+    "lumen_group_digests": (C.c_int, [_vp, _u8p, C.c_size_t, _u32p]),
+    "lumen_group_gather": (C.c_int, [_vp, _vpp, _u32p, C.c_uint32, _vpp]),
+    "lumen_group_stats": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "lumen_group_stats_reset": (C.c_int, [_vp]),
     "lumen_timer_start": (C.c_int, [_vp]),
     "lumen_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "lumen_prof_enable": (C.c_int, [_vp, C.c_int]),
@@ -578,6 +595,121 @@ class Context:
         ms, n, u = C.c_double(), C.c_uint64(), C.c_uint64()
         self._ck(self.lib.lumen_prof_read(self.h, kernel.encode(), C.byref(ms), C.byref(n), C.byref(u)))
         return ms.value, n.value, u.value
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+TRANSPORT = {"auto": 0, "copy": 1, "rccl": 2}
+
+
+class Group:
+    """lumen_group: W = 2^k ranks, one Context per GPU, with the exchange steps of the sharded Commit inside the
+    library (include/lumenos_hip.h).  Group(ctxs) owns all ranks in this process (a Go server's topology);
+    Group.join(ctx, rank, world, uid) is one process per GPU (torch.distributed.run).  Every list argument has
+    one entry per LOCAL context."""
+
+    def __init__(self, ctxs, transport="auto", _handle=None, _world=None):
+        self.lib = load()
+        self.ctxs = list(ctxs)
+        if _handle is not None:
+            self.h, self.world = _handle, _world
+            return
+        W = len(self.ctxs)
+        assert W >= 1 and W & (W - 1) == 0, "a group has a power-of-two number of ranks"
+        arr = (C.c_void_p * W)(*[c.h for c in self.ctxs])
+        h = C.c_void_p()
+        if self.lib.lumen_group_create(arr, W.bit_length() - 1, TRANSPORT[transport], C.byref(h)):
+            raise LumenError(self.lib.lumen_last_error(None).decode())
+        self.h, self.world = h, W
+
+    @staticmethod
+    def unique_id():
+        lib = load()
+        uid = np.zeros(128, dtype=np.uint8)
+        if lib.lumen_group_unique_id(uid.ctypes.data_as(_u8p)):
+            raise LumenError(lib.lumen_last_error(None).decode())
+        return uid
+
+    @classmethod
+    def join(cls, ctx, rank, world, uid):
+        lib = load()
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        assert uid.size == 128 and world & (world - 1) == 0
+        h = C.c_void_p()
+        if lib.lumen_group_create_rank(ctx.h, rank, world.bit_length() - 1, uid.ctypes.data_as(_u8p), C.byref(h)):
+            raise LumenError(lib.lumen_last_error(None).decode())
+        return cls([ctx], _handle=h, _world=world)
+
+    def _ck(self, rc):
+        if rc:
+            raise LumenError(self.lib.lumen_last_error(None).decode())
+
+    @property
+    def transport(self):
+        return self.lib.lumen_group_transport(self.h).decode()
+
+    @property
+    def rccl_ranks(self):
+        return int(self.lib.lumen_group_rccl_ranks(self.h))
+
+    def _handles(self, sets):
+        assert len(sets) == len(self.ctxs)
+        return (C.c_void_p * len(sets))(*[s.h for s in sets])
+
+    def sync(self):
+        self._ck(self.lib.lumen_group_sync(self.h))
+
+    def all_to_all(self, send, recv):
+        self._ck(self.lib.lumen_group_all_to_all(self.h, self._handles(send), self._handles(recv)))
+
+    def encode(self, matrix, zero_ct, rho_inv):
+        """matrix[i]: local rank i's block of full-width input columns -> its block of encoded columns"""
+        zero_ct = np.ascontiguousarray(zero_ct, dtype=np.uint64)
+        out = (C.c_void_p * len(self.ctxs))()
+        self._ck(self.lib.lumen_group_encode(self.h, self._handles(matrix), _p64(zero_ct), rho_inv, out))
+        return [DeviceSet(c, C.c_void_p(out[i])) for i, c in enumerate(self.ctxs)]
+
+    def all_gather_digests(self):
+        """ends every local context's leaf_digests_begin job and all-gathers the digests on the devices"""
+        self._ck(self.lib.lumen_group_all_gather_digests(self.h))
+        for c in self.ctxs:
+            c._pending_leaves = 0
+
+    def merkle_root(self):
+        root = np.zeros(32, dtype=np.uint8)
+        self._ck(self.lib.lumen_group_merkle_root(self.h, root.ctypes.data_as(_u8p)))
+        return root.tobytes()
+
+    def digests(self, n_leaves):
+        out = np.zeros((n_leaves, 32), dtype=np.uint8)
+        n = C.c_uint32()
+        self._ck(self.lib.lumen_group_digests(self.h, out.ctypes.data_as(_u8p), out.size, C.byref(n)))
+        assert n.value == n_leaves, (n.value, n_leaves)
+        return out
+
+    def gather(self, src, idx):
+        """queried columns (global indices) collected on rank 0 in query order; None where rank 0 is not local"""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        h = C.c_void_p()
+        self._ck(self.lib.lumen_group_gather(self.h, self._handles(src), idx.ctypes.data_as(_u32p), len(idx), C.byref(h)))
+        return DeviceSet(self.ctxs[0], h) if h.value else None
+
+    def stats(self, name):
+        ms, b, n = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.lumen_group_stats(self.h, name.encode(), C.byref(ms), C.byref(b), C.byref(n)))
+        return ms.value, b.value, n.value
+
+    def stats_reset(self):
+        self._ck(self.lib.lumen_group_stats_reset(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.lumen_group_destroy(self.h)
+            self.h = None
 
     def __del__(self):
         try:

@@ -1,0 +1,139 @@
+"""The multi-GPU group API (include/lumenos_hip.h "lumen_group") on ONE GPU: W contexts on device 0
+play the W ranks of a single host process -- the reference's topology, one process that owns the request
+(cmd/server/main.go:187-266) -- and the exchange steps run inside the library (copy transport: RCCL refuses two
+ranks on one device).  Everything is held to the single-context result, itself bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+from tests.helpers import T_REF, make_context, make_params, random_cts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small(oracle):
+    P = make_params(oracle, 10, 3)
+    ctx = make_context(P)
+    yield P, ctx
+    ctx.close()
+
+
+def ranks_of(ctx, world):
+    """rank 0 is the context itself, the others its clones (same device: they share tables and keys)"""
+    return [ctx] + [ctx.clone() for _ in range(world - 1)]
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_group_all_to_all_routes_blocks(small, world):
+    from lumenos_amd.hip import Group
+    P, ctx = small
+    ctxs = ranks_of(ctx, world)
+    g = Group(ctxs, transport="copy")
+    assert g.transport == "copy" and g.world == world and g.rccl_ranks == 0
+    n, nl = 3 * world, 2
+    host = [random_cts(P, n, nl, seed=300 + r) for r in range(world)]
+    send = [c.upload(h) for c, h in zip(ctxs, host)]
+    recv = [c.new_set(n, nl) for c in ctxs]
+    g.all_to_all(send, recv)
+    b = n // world
+    for r in range(world):
+        want = np.concatenate([host[s][r * b:(r + 1) * b] for s in range(world)])
+        assert np.array_equal(recv[r].download(), want), r
+    ms, sent, calls = g.stats("all_to_all")
+    assert calls == 1 and sent == (world - 1) * b * 2 * nl * P.N * 8 and (ms > 0 or world == 1)
+    g.close()
+    for c in ctxs[1:]:
+        c.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_group_commit_matches_single_context(oracle, small, world):
+    """Encode -> rescale -> leaf digests -> all-gather -> Merkle root -> query gather over W ranks: the same
+    encoded columns, the same root, the same opened columns as one context."""
+    from lumenos_amd.hip import Group
+    P, ctx = small
+    cols, rho, nl = 64, 2, 3
+    S, c, Sw = cols * rho, cols // world, cols * rho // world
+    roots = oracle.field_roots(T_REF, S)
+    ctx.field_set(roots)
+    m = random_cts(P, cols, nl, seed=191)
+    zero = random_cts(P, 1, nl, seed=192)[0]
+    full = ctx.encode(ctx.upload(m), zero, rho)
+    assert np.array_equal(full.download(), P.ct_encode(m, rho, zero, roots))
+    lvl1 = ctx.rescale(full, 2)
+    dig = ctx.leaf_digests(lvl1)
+    _, root = ctx.merkle_build(dig)
+    idx = np.array([5, S - 1, 0, 5, Sw % S, 77 % S, (2 * Sw - 1) % S], dtype=np.uint32)
+    opened = ctx.gather(lvl1, idx).download()
+
+    ctxs = ranks_of(ctx, world)
+    g = Group(ctxs, transport="copy")
+    own = [cx.upload(m[r * c:(r + 1) * c]) for r, cx in enumerate(ctxs)]
+    enc = g.encode(own, zero, rho)
+    for r in range(world):
+        assert enc[r].count == Sw and enc[r].log_world == 0
+        assert np.array_equal(enc[r].download(), full.download(r * Sw, Sw)), r
+    l1 = [cx.rescale(e, 2) for cx, e in zip(ctxs, enc)]
+    for cx, s in zip(ctxs, l1):
+        cx.leaf_digests_begin(s)
+    g.all_gather_digests()
+    assert g.merkle_root() == root
+    assert np.array_equal(g.digests(S), dig)
+    q = g.gather(l1, idx)
+    assert q.count == len(idx) and np.array_equal(q.download(), opened)
+    if world > 1:
+        assert g.stats("all_to_all")[2] == 2 and g.stats("all_gather")[2] == 1 and g.stats("gather_to_root")[2] == 1
+    g.close()
+    for cx in ctxs[1:]:
+        cx.close()
+
+
+def test_group_refuses_what_it_cannot_serve(oracle, small):
+    from lumenos_amd.hip import Group, LumenError
+    P, ctx = small
+    twin = ctx.clone()
+    with pytest.raises(LumenError, match="RCCL needs every rank on its own device"):
+        Group([ctx, twin], transport="rccl")
+    with pytest.raises(LumenError, match="same context"):
+        Group([ctx, ctx], transport="copy")
+    g = Group([ctx, twin], transport="auto")  # two ranks on one device: copies
+    assert g.transport == "copy"
+    a, b = ctx.new_set(4, 2), twin.new_set(6, 2)
+    with pytest.raises(LumenError, match="differ in size"):
+        g.all_to_all([a, b], [ctx.new_set(4, 2), twin.new_set(6, 2)])
+    with pytest.raises(LumenError, match="no lumen_leaf_digests_begin job"):
+        g.all_gather_digests()
+    with pytest.raises(LumenError, match="no gathered digests"):
+        g.merkle_root()
+    g.close()
+    other = make_context(make_params(oracle, 10, 2))
+    with pytest.raises(LumenError, match="other parameters"):
+        Group([ctx, other], transport="copy")
+    other.close()
+    twin.close()
+
+
+def test_group_rccl_world_of_one(small):
+    """RCCL in-process on the one GPU there is: the library loads librccl at run time, ncclCommInitAll over one
+    device, the all-to-all is a send/recv to self and the all-gather a copy -- what a one-GPU box can check of the
+    transport the W-device group uses (the W > 1 data path is the same calls with more peers)."""
+    from lumenos_amd.hip import Group
+    P, ctx = small
+    g = Group([ctx], transport="rccl")
+    assert g.transport == "rccl" and g.rccl_ranks == 1
+    host = random_cts(P, 5, 2, seed=7)
+    send, recv = ctx.upload(host), ctx.new_set(5, 2)
+    g.all_to_all([send], [recv])
+    assert np.array_equal(recv.download(), host)
+    dig = ctx.leaf_digests(send)
+    ctx.leaf_digests_begin(send)
+    g.all_gather_digests()
+    assert np.array_equal(g.digests(5), dig) and g.merkle_root() == ctx.merkle_build(dig)[1]
+    g.close()
+    # one process per GPU: the unique id travels through the host, every rank joins with its own context
+    uid = Group.unique_id()
+    g1 = Group.join(ctx, 0, 1, uid)
+    assert g1.transport == "rccl" and g1.rccl_ranks == 1
+    g1.all_to_all([send], [recv])
+    g1.sync()
+    g1.close()

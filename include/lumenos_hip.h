@@ -78,6 +78,10 @@ int lumen_ctx_wait(lumen_ctx *ctx, lumen_ctx *other);
  * the in-process form for tests and tools: name = "LUMEN_KS_BATCH", "LUMEN_KS_LANES",
  * "LUMEN_KS_FUSED_DIGITS" (value < 0: derived default), "LUMEN_CT_BLOCKS", "LUMEN_DEBUG". */
 int lumen_ctx_set_tuning(lumen_ctx *ctx, const char *name, long value);
+/* Freed set storage is pooled per context and scratch buffers persist (a prover run allocates the same sizes
+ * every time; mapping 25 GB per call costs 0.2 s).  lumen_ctx_trim hands all of it back to the driver -- between
+ * jobs of different shapes, or when several contexts share one GPU.  Waits for the context's work first. */
+int lumen_ctx_trim(lumen_ctx *ctx);
 const char *lumen_last_error(const lumen_ctx *ctx); /* ctx may be NULL */
 int lumen_sync(lumen_ctx *ctx);
 /* number of ct x scalar multiplications issued: ServerBFV.MulCounter (bfv.go:44-46) */
@@ -281,7 +285,8 @@ int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, lumen_set *
  * (cmd/client/main.go:124-131): GadgetCiphertext.Value flattened
  *     [rns digit][power-of-two digit][b|a][limb: q_0..q_{L-1}, p_0..p_{K-1}][N],  NTT domain, standard form
  * with lumen_ringswitch_rns_digits() x lumen_ringswitch_digits(w) entries.  Level 0 reads RNS digit 0
- * only, so a caller may pass just that first block (evk.Value[0]).
+ * only, so a caller may pass just that first block (evk.Value[0]); key_words = the number of u64 words at
+ * `key`, which must be one of those two sizes (anything else is refused before a word is read).
  * base_two_w = BaseTwoDecomposition (13).  Which gadget product runs follows the key's LevelP, as in
  * rlwe.Evaluator.GadgetProductLazy [LATTIGO-RECALL]:
  *   K >= 2 special primes (what GenerateBGVParamsForNTT always produces, fhe/bfv.go:172-178): the hybrid
@@ -294,7 +299,7 @@ int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, lumen_set *
 uint32_t lumen_ringswitch_rns_digits(const lumen_ctx *ctx);
 uint32_t lumen_ringswitch_digits(const lumen_ctx *ctx, uint32_t base_two_w);
 int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, uint32_t base_two_w,
-                              const uint64_t *key);
+                              const uint64_t *key, size_t key_words);
 int lumen_ring_switch(lumen_ctx *ctx, const lumen_set *in, uint64_t *out);
 
 /* ---- query loop of Prove (fhe/ligero.go:268-279): gather ciphertexts idx[i]

@@ -321,6 +321,30 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
     delete ctx;
 }
 
+// gives the context's cached device memory back to the driver: the pool of freed set storage and every scratch
+// buffer (both are rebuilt on demand).  For a long-lived server between jobs of different shapes, and for a
+// process that runs several contexts on one GPU.  Waits for the context's streams first.
+extern "C" int lumen_ctx_trim(lumen_ctx *ctx) {
+    LM_CHECK(nullptr, ctx, "lumen_ctx_trim: NULL ctx");
+    LM_ENTER(ctx);
+    LM_CHECK(ctx, !ctx->aux_digests, "lumen_ctx_trim: a lumen_leaf_digests_begin job is in flight");
+    lm_sync_all(ctx);
+    for (auto it = ctx->scratch.begin(); it != ctx->scratch.end();) {
+        // the digest buffers are handed out by pointer (lumen_leaf_digests_end_device, the group's gathered
+        // leaves) and are a few hundred KB: they stay
+        if (it->first == "digests_async" || it->first == "group_digests") {
+            ++it;
+            continue;
+        }
+        hipFree(it->second.first);
+        it = ctx->scratch.erase(it);
+    }
+    for (auto &kv : ctx->pool) hipFree(kv.second);
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+    return 0;
+}
+
 extern "C" const char *lumen_last_error(const lumen_ctx *ctx) {
     return ctx ? ctx->err.c_str() : lm_global_err.c_str();
 }

@@ -178,7 +178,7 @@ extern "C" uint32_t lumen_ringswitch_digits(const lumen_ctx *ctx, uint32_t base_
 }
 
 extern "C" int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, uint32_t base_two_w,
-                                         const uint64_t *key) {
+                                         const uint64_t *key, size_t key_words) {
     LM_CHECK(nullptr, ctx && key, "lumen_load_ringswitch_key: NULL argument");
     LM_ENTER(ctx);
     LM_CHECK(ctx, ctx->K <= 2, "ring switch supports at most 2 special primes (have %u)", ctx->K);
@@ -189,6 +189,12 @@ extern "C" int lumen_load_ringswitch_key(lumen_ctx *ctx, uint32_t log_n_small, u
     const bool hybrid = K >= 2;
     LM_CHECK(ctx, hybrid || (base_two_w >= 1 && base_two_w <= 32), "BaseTwoDecomposition %u out of range", base_two_w);
     const uint32_t nd = lumen_ringswitch_digits(ctx, base_two_w);
+    // the whole key [rns][pw2][2][L+K][N] or its RNS digit 0 alone: anything else (an older layout, a truncated
+    // block) would be read past its end
+    const size_t digit0 = (size_t)nd * 2 * LK * N, whole = digit0 * lumen_ringswitch_rns_digits(ctx);
+    LM_CHECK(ctx, key_words == whole || key_words == digit0,
+             "ring-switch key of %zu words: expected %zu ([rns = %u][pw2 = %u][2][L+K = %u][N = %u]) or its RNS digit 0 alone (%zu)",
+             key_words, whole, lumen_ringswitch_rns_digits(ctx), nd, LK, N, digit0);
     auto sp = std::make_shared<RsKey>();
     sp->nd = nd, sp->w = hybrid ? 0 : base_two_w, sp->logn = log_n_small;
     // RNS digit 0 of the key ([rns][pw2][2][L+K][N]: its first pw2 * 2 * (L+K) * N words), limbs {q_0, P}

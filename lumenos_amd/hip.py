@@ -45,6 +45,7 @@ SYMBOLS = {
     "lumen_host_alloc": (_vp, [C.c_size_t]),
     "lumen_host_free": (None, [_vp]),
     "lumen_last_error": (C.c_char_p, [_vp]),
+    "lumen_ctx_trim": (C.c_int, [_vp]),
     "lumen_ctx_wait": (C.c_int, [_vp, _vp]),
     "lumen_ctx_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_long]),
     "lumen_sync": (C.c_int, [_vp]),
@@ -94,7 +95,7 @@ SYMBOLS = {
     "lumen_plain_inner_products": (C.c_int, [_vp, _vp, _u64p, _u64p]),
     "lumen_ringswitch_rns_digits": (C.c_uint32, [_vp]),
     "lumen_ringswitch_digits": (C.c_uint32, [_vp, C.c_uint32]),
-    "lumen_load_ringswitch_key": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _u64p]),
+    "lumen_load_ringswitch_key": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _u64p, C.c_size_t]),
     "lumen_ring_switch": (C.c_int, [_vp, _vp, _u64p]),
     "lumen_group_create": (C.c_int, [_vpp, C.c_uint32, C.c_uint32, _vpp]),
     "lumen_group_unique_id": (C.c_int, [_u8p]),
@@ -296,6 +297,10 @@ class Context:
 
     def sync(self):
         self._ck(self.lib.lumen_sync(self.h))
+
+    def trim(self):
+        """hand the context's pooled set storage and scratch buffers back to the driver"""
+        self._ck(self.lib.lumen_ctx_trim(self.h))
 
     def wait_for(self, other):
         """this context's stream waits (on the device) for everything enqueued on `other` so far"""
@@ -557,7 +562,7 @@ class Context:
         shape = self.ringswitch_key_shape(w)
         if key.shape not in (shape, shape[1:]):
             raise ValueError(f"ring-switch key has shape {key.shape}, expected {shape} or {shape[1:]}")
-        self._ck(self.lib.lumen_load_ringswitch_key(self.h, log_n_small, w, _p64(key)))
+        self._ck(self.lib.lumen_load_ringswitch_key(self.h, log_n_small, w, _p64(key), key.size))
         self._rs_logn = log_n_small
 
     def ring_switch(self, s, out=None):

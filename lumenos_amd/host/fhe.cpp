@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <set>
 #include <stdexcept>
 
 #include <sys/random.h>
@@ -151,6 +152,24 @@ std::vector<uint64_t> Ciphertexts::Download() const {
     return out;
 }
 
+int ShardedCiphertexts::Len() const {
+    int n = 0;
+    for (const Ciphertexts &b : Blocks) n += b.Len();
+    return n;
+}
+const MetaData &ShardedCiphertexts::Meta() const {
+    static const MetaData none;
+    return Blocks.empty() ? none : Blocks[0].Meta;
+}
+std::vector<uint64_t> ShardedCiphertexts::Download() const {
+    std::vector<uint64_t> out;
+    for (const Ciphertexts &b : Blocks) {
+        const std::vector<uint64_t> part = b.Download();
+        out.insert(out.end(), part.begin(), part.end());
+    }
+    return out;
+}
+
 uint64_t RescaledScale(const Parameters &params, uint64_t scale, int fromLevel, int toLevel) {
     // Evaluator.Rescale: Scale <- Scale * q_l^-1 mod T for the dropped limb l
     const uint64_t T = params.T;
@@ -190,18 +209,23 @@ std::string MetaDataJSON(const MetaData &md, uint64_t plaintextModulus) {
     return buf;
 }
 
-void SetCiphertextFormat(ServerBFV &backend, const MetaData &md, int level) {
+// the framing ct.WriteTo gives a ciphertext of this MetaData and level, installed on one context
+static void set_format(lumen_ctx *ctx, const MetaData &md, int level, uint64_t T, uint32_t N) {
     auto le64 = [](std::vector<uint8_t> &v, uint64_t x) {
         for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i)));
     };
-    const std::string json = MetaDataJSON(md, backend.GetParameters().T);
+    const std::string json = MetaDataJSON(md, T);
     std::vector<uint8_t> head(json.begin(), json.end()), poly, limb;
     le64(head, 2); // structs.Vector[ring.Poly]: two polynomials
     le64(poly, (uint64_t)level + 1);
-    le64(limb, (uint64_t)backend.GetParameters().N());
-    backend.check(lumen_leaf_format_set(backend.Context(), head.data(), (uint32_t)head.size(), poly.data(),
-                                        (uint32_t)poly.size(), limb.data(), (uint32_t)limb.size()),
-                  "lumen_leaf_format_set");
+    le64(limb, (uint64_t)N);
+    if (lumen_leaf_format_set(ctx, head.data(), (uint32_t)head.size(), poly.data(), (uint32_t)poly.size(), limb.data(),
+                              (uint32_t)limb.size()))
+        throw std::runtime_error(std::string("lumen_leaf_format_set: ") + lumen_last_error(ctx));
+}
+
+void SetCiphertextFormat(ServerBFV &backend, const MetaData &md, int level) {
+    set_format(backend.Context(), md, level, backend.GetParameters().T, (uint32_t)backend.GetParameters().N());
 }
 
 // ------------------------------------------------------------------ host ring helpers
@@ -281,7 +305,8 @@ ServerBFV::ServerBFV(core::PrimeField *plaintextField, const Parameters &params,
     // the reference keys Lattigo's sampler from crypto/rand: all encryption randomness (u, e0, e1 of every
     // ciphertext this server makes) is the ChaCha20 stream under this key, so the key comes from the
     // kernel's CSPRNG and from nowhere else -- no user-space generator in between
-    OsRandom(enc_seed_, sizeof(enc_seed_));
+    enc_ = std::make_shared<EncryptorState>();
+    OsRandom(enc_->seed, sizeof(enc_->seed));
     // encoder tables ([LATTIGO-RECALL] bgv.Encoder: slot i of row 0 sits at 5^i, row 1 at -5^i)
     const uint64_t T = params.T, two_n = 2ull << params.LogN;
     psiT_ = PowMod(core::PrimitiveRoot(T), (T - 1) / two_n, T);
@@ -293,6 +318,18 @@ ServerBFV::ServerBFV(core::PrimeField *plaintextField, const Parameters &params,
         slot_index_[s | row] = (uint32_t)core::BitReverse64((two_n - pos - 1) >> 1, params.LogN);
         pos = (pos * 5) & (two_n - 1);
     }
+}
+
+ServerBFV::ServerBFV(ServerBFV &src, lumen_ctx *clone)
+    : ptField_(src.ptField_), params_(src.params_), pk_(src.pk_), ctx_(clone), psiT_(src.psiT_),
+      slot_index_(src.slot_index_), rs_(src.rs_), enc_(src.enc_) {
+    g_ring_degree[ctx_] = (uint32_t)params_.N();
+}
+
+std::unique_ptr<ServerBFV> ServerBFV::CopyNew() {
+    lumen_ctx *twin = nullptr;
+    check(lumen_ctx_clone(ctx_, &twin), "lumen_ctx_clone");
+    return std::unique_ptr<ServerBFV>(new ServerBFV(*this, twin));
 }
 
 ServerBFV::~ServerBFV() {
@@ -325,14 +362,13 @@ Plaintext ServerBFV::Encode(const std::vector<uint64_t> &values) const {
 
 std::vector<uint64_t> ServerBFV::EncryptNew(const Plaintext &pt) {
     // rlwe.Encryptor with a public key: (u*pk0 + e0 + pt, u*pk1 + e1), ternary u, Gaussian e (sigma 3.2).
-    // One ciphertext of the device encryptor: its samples are ChaCha20(enc_seed_, index), the same
+    // One ciphertext of the device encryptor: its samples are ChaCha20(seed, index) of the shared encryptor state, the same
     // stream EncryptNewBatch / EncryptColumnsNew draw from, never a host-side generator.  The path only
     // encrypts at MaxLevel (fhe/code.go:15-19: NewPlaintext(params, MaxLevel)).
     const size_t N = (size_t)params_.N(), L = params_.Q.size();
     if ((size_t)pt.Level + 1 != L) throw std::invalid_argument("EncryptNew: plaintext must be at MaxLevel");
     lumen_set *set = nullptr;
-    check(lumen_encrypt_pk(ctx_, pt.Value.data(), 1, enc_seed_, enc_next_, &set), "lumen_encrypt_pk");
-    enc_next_ += 1;
+    check(lumen_encrypt_pk(ctx_, pt.Value.data(), 1, enc_->seed, enc_->next.fetch_add(1), &set), "lumen_encrypt_pk");
     std::vector<uint64_t> ct(2 * L * N);
     const int rc = lumen_set_download(ctx_, set, 0, 1, ct.data());
     lumen_set_destroy(ctx_, set);
@@ -342,7 +378,7 @@ std::vector<uint64_t> ServerBFV::EncryptNew(const Plaintext &pt) {
 
 Ciphertexts ServerBFV::EncryptNewBatch(const std::vector<Plaintext> &pts) {
     // the EncryptNew loop of cmd/server/main.go:199-208 as one device call; column i of this server's
-    // lifetime draws its randomness from ChaCha20(enc_seed_, i)
+    // lifetime draws its randomness from ChaCha20(seed, i)
     const size_t N = (size_t)params_.N(), L = params_.Q.size();
     std::vector<uint64_t> flat(pts.size() * L * N);
     for (size_t i = 0; i < pts.size(); i++) {
@@ -350,8 +386,8 @@ Ciphertexts ServerBFV::EncryptNewBatch(const std::vector<Plaintext> &pts) {
         memcpy(&flat[i * L * N], pts[i].Value.data(), L * N * 8);
     }
     lumen_set *set = nullptr;
-    check(lumen_encrypt_pk(ctx_, flat.data(), (uint32_t)pts.size(), enc_seed_, enc_next_, &set), "lumen_encrypt_pk");
-    enc_next_ += pts.size();
+    check(lumen_encrypt_pk(ctx_, flat.data(), (uint32_t)pts.size(), enc_->seed, enc_->next.fetch_add(pts.size()), &set),
+          "lumen_encrypt_pk");
     MetaData md; // fresh encryption: Scale 1, NTT domain, batched 2 x N/2 slots
     md.LogCols = params_.LogN - 1;
     return Ciphertexts(ctx_, set, md);
@@ -362,9 +398,9 @@ Ciphertexts ServerBFV::EncryptColumnsNew(const std::vector<uint64_t> &values, in
     // in one device call: only the raw values cross PCIe
     if ((size_t)rows * count != values.size()) throw std::invalid_argument("EncryptColumnsNew: size mismatch");
     lumen_set *set = nullptr;
-    check(lumen_encrypt_values(ctx_, values.data(), (uint32_t)rows, (uint32_t)count, enc_seed_, enc_next_, &set),
+    check(lumen_encrypt_values(ctx_, values.data(), (uint32_t)rows, (uint32_t)count, enc_->seed,
+                               enc_->next.fetch_add((uint64_t)count), &set),
           "lumen_encrypt_values");
-    enc_next_ += (uint64_t)count;
     MetaData md;
     md.LogCols = params_.LogN - 1;
     return Ciphertexts(ctx_, set, md);
@@ -374,14 +410,63 @@ Ciphertexts ServerBFV::EncryptColumnsNew(const std::vector<uint64_t> &values, in
 RingSwitchServer::RingSwitchServer(ServerBFV &backend, const std::vector<uint64_t> &ringSwitchEvk, int logN,
                                    int baseTwoDecomposition)
     : logN_(logN) {
+    // the whole key the client posts, [rns][pw2][b|a][L+K][N], or its RNS digit 0 alone: nothing else is read
+    const Parameters &P = backend.GetParameters();
+    const size_t digit0 = (size_t)lumen_ringswitch_digits(backend.Context(), (uint32_t)baseTwoDecomposition) * 2 *
+                          (P.Q.size() + P.P.size()) * (size_t)P.N();
+    const size_t whole = digit0 * lumen_ringswitch_rns_digits(backend.Context());
+    if (ringSwitchEvk.size() != whole && ringSwitchEvk.size() != digit0)
+        throw std::invalid_argument("NewRingSwitchServer: ringSwitchEvk has " + std::to_string(ringSwitchEvk.size()) +
+                                    " words, expected " + std::to_string(whole) + " (or RNS digit 0 alone: " +
+                                    std::to_string(digit0) + ")");
     backend.check(lumen_load_ringswitch_key(backend.Context(), (uint32_t)logN, (uint32_t)baseTwoDecomposition,
-                                            ringSwitchEvk.data()),
+                                            ringSwitchEvk.data(), ringSwitchEvk.size()),
                   "lumen_load_ringswitch_key");
 }
 
 std::vector<uint64_t> RingSwitchServer::RingSwitchNew(const Ciphertexts &cts, ServerBFV &backend) const {
     std::vector<uint64_t> out((size_t)cts.Len() * 2 * ((size_t)1 << logN_));
     if (cts.Len()) backend.check(lumen_ring_switch(backend.Context(), cts.Handle(), out.data()), "lumen_ring_switch");
+    return out;
+}
+
+// ------------------------------------------------------------------ ServerGroup
+ServerGroup::ServerGroup(std::vector<ServerBFV *> ranks, uint32_t transport) : ranks_(std::move(ranks)) {
+    const size_t W = ranks_.size();
+    if (!W || (W & (W - 1))) throw std::invalid_argument("ServerGroup: the number of ranks must be a power of two");
+    uint32_t logw = 0;
+    while (((size_t)1 << logw) < W) logw++;
+    std::vector<lumen_ctx *> ctxs;
+    for (ServerBFV *s : ranks_) {
+        if (!s) throw std::invalid_argument("ServerGroup: NULL rank");
+        ctxs.push_back(s->Context());
+        s->enc_ = ranks_[0]->enc_; // one encryptor: every rank draws from rank 0's stream
+    }
+    check(lumen_group_create(ctxs.data(), logw, transport, &group_), "lumen_group_create");
+}
+ServerGroup::~ServerGroup() { lumen_group_destroy(group_); }
+void ServerGroup::check(int rc, const char *what) const {
+    if (rc) throw std::runtime_error(std::string(what) + ": " + lumen_last_error(nullptr));
+}
+void ServerGroup::Sync() const { check(lumen_group_sync(group_), "lumen_group_sync"); }
+
+ShardedCiphertexts ServerGroup::EncryptColumnsNew(const std::vector<uint64_t> &values, int rows, int count) {
+    const int W = World();
+    if ((size_t)rows * count != values.size()) throw std::invalid_argument("EncryptColumnsNew: size mismatch");
+    if (count % W) throw std::invalid_argument("EncryptColumnsNew: the columns do not split evenly over the ranks");
+    const int own = count / W;
+    const uint64_t first = ranks_[0]->enc_->next.fetch_add((uint64_t)count);
+    ShardedCiphertexts out;
+    for (int r = 0; r < W; r++) {
+        ServerBFV &s = Rank(r);
+        lumen_set *set = nullptr;
+        s.check(lumen_encrypt_values(s.Context(), values.data() + (size_t)r * own * rows, (uint32_t)rows, (uint32_t)own,
+                                     s.enc_->seed, first + (uint64_t)r * own, &set),
+                "lumen_encrypt_values");
+        MetaData md;
+        md.LogCols = s.GetParameters().LogN - 1;
+        out.Blocks.emplace_back(s.Context(), set, md);
+    }
     return out;
 }
 
@@ -393,6 +478,23 @@ Ciphertexts Encode(const Ciphertexts &matrix, int rows, int rhoInv, ServerBFV &b
     lumen_set *enc = nullptr;
     backend.check(lumen_encode(backend.Context(), matrix.Handle(), zeroCol.data(), (uint32_t)rhoInv, &enc), "lumen_encode");
     return Ciphertexts(backend.Context(), enc, matrix.Meta); // Add / Sub / Mul by a scalar keep the scale
+}
+
+ShardedCiphertexts Encode(const ShardedCiphertexts &matrix, int rows, int rhoInv, ServerGroup &group) {
+    const int W = group.World();
+    if ((int)matrix.Blocks.size() != W) throw std::invalid_argument("Encode: one block of columns per rank is required");
+    // code.go:15-22: ONE fresh encryption of the zero vector (rank 0's encoder and the group's encryptor stream);
+    // every rank takes its lanes of it
+    ServerBFV &lead = group.Rank(0);
+    Plaintext zeroColPt = lead.Encode(std::vector<uint64_t>((size_t)rows, 0));
+    const std::vector<uint64_t> zeroCol = lead.EncryptNew(zeroColPt);
+    std::vector<const lumen_set *> in;
+    for (const Ciphertexts &b : matrix.Blocks) in.push_back(b.Handle());
+    std::vector<lumen_set *> enc((size_t)W, nullptr);
+    group.check(lumen_group_encode(group.Handle(), in.data(), zeroCol.data(), (uint32_t)rhoInv, enc.data()), "lumen_group_encode");
+    ShardedCiphertexts out;
+    for (int r = 0; r < W; r++) out.Blocks.emplace_back(group.Rank(r).Context(), enc[(size_t)r], matrix.Meta());
+    return out;
 }
 
 void NTT(Ciphertexts &values, int size, ServerBFV &backend) {
@@ -447,7 +549,52 @@ std::pair<LigeroProver, std::vector<uint8_t>> LigeroCommitter::Commit(const Ciph
     LigeroProver prover;
     prover.Committer = this;
     prover.Matrix = &matrix;
-    prover.EncodedMatrix = std::move(level1);
+    prover.EncodedLevel1 = ShardedCiphertexts(std::move(level1));
+    prover.Tree = std::move(tree);
+    std::vector<uint8_t> root = prover.Tree.MerkleRoot();
+    return {std::move(prover), std::move(root)};
+}
+
+std::pair<LigeroProver, std::vector<uint8_t>> LigeroCommitter::Commit(const ShardedCiphertexts &matrix, ServerGroup &group,
+                                                                       core::Span *ctx) const {
+    const int W = group.World();
+    core::Span *span = core::Span::StartSpan("Encode", ctx);
+    ShardedCiphertexts encoded = Encode(matrix, Metadata.Rows, Metadata.RhoInv, group);
+    group.Sync();
+    span->End();
+    delete span;
+
+    span = core::Span::StartSpan("Merkle tree built", ctx);
+    // processLeafParallel (ligero.go:126-183) on every rank's block of encoded columns; the leaves are hashed on
+    // the ranks' side streams, then ONE all-gather puts the S digests on every rank
+    MetaData md = encoded.Meta();
+    md.Scale = RescaledScale(group.Rank(0).GetParameters(), md.Scale, encoded.Level(), 1);
+    ShardedCiphertexts level1;
+    for (int r = 0; r < W; r++) {
+        ServerBFV &s = group.Rank(r);
+        lumen_set *lvl1 = nullptr;
+        s.check(lumen_rescale(s.Context(), encoded.Blocks[(size_t)r].Handle(), 2, &lvl1), "lumen_rescale");
+        level1.Blocks.emplace_back(s.Context(), lvl1, md);
+        SetCiphertextFormat(s, md, 1);
+        s.check(lumen_leaf_digests_begin(s.Context(), lvl1), "lumen_leaf_digests_begin");
+    }
+    group.check(lumen_group_all_gather_digests(group.Handle()), "lumen_group_all_gather_digests");
+    std::vector<core::Digest> leaves((size_t)level1.Len());
+    uint32_t n = 0;
+    group.check(lumen_group_digests(group.Handle(), leaves[0].data(), leaves.size() * 32, &n), "lumen_group_digests");
+    if (n != leaves.size()) throw std::runtime_error("Commit: the all-gather returned another number of leaves");
+    core::MerkleTree tree = core::MerkleTree::FromLeafDigests(std::move(leaves)); // core.NewTree
+    // the same root built on the device from the gathered digests (what a rank that keeps no tree would use)
+    uint8_t droot[32];
+    group.check(lumen_group_merkle_root(group.Handle(), droot), "lumen_group_merkle_root");
+    if (memcmp(droot, tree.MerkleRoot().data(), 32)) throw std::runtime_error("Commit: device and host Merkle roots differ");
+    span->End();
+    delete span;
+
+    LigeroProver prover;
+    prover.Committer = this;
+    prover.MatrixShards = &matrix;
+    prover.EncodedLevel1 = std::move(level1);
     prover.Tree = std::move(tree);
     std::vector<uint8_t> root = prover.Tree.MerkleRoot();
     return {std::move(prover), std::move(root)};
@@ -505,8 +652,10 @@ EncryptedProof LigeroProver::Prove(core::Element point, ServerBFV &backend, core
     proof.QueryIndices = sampleQueryIndices(transcript, Committer->Metadata.Queries, extCols);
     std::vector<uint32_t> idx(proof.QueryIndices.begin(), proof.QueryIndices.end());
     lumen_set *q = nullptr;
-    backend.check(lumen_gather(backend.Context(), EncodedMatrix.Handle(), idx.data(), (uint32_t)idx.size(), &q), "lumen_gather");
-    proof.QueriedCols = Ciphertexts(backend.Context(), q, EncodedMatrix.Meta);
+    // the reference rescales the queried entries of its top-level EncodedMatrix in place (ligero.go:268-273); the
+    // level-1 columns Commit hashed are those very ciphertexts
+    backend.check(lumen_gather(backend.Context(), EncodedLevel1.Blocks.at(0).Handle(), idx.data(), (uint32_t)idx.size(), &q), "lumen_gather");
+    proof.QueriedCols = Ciphertexts(backend.Context(), q, EncodedLevel1.Meta());
     for (int i : proof.QueryIndices) proof.MerklePaths.push_back(Tree.GetMerklePath((unsigned)i));
     querySpan->End();
     delete querySpan;
@@ -518,6 +667,74 @@ EncryptedProof LigeroProver::Prove(core::Element point, ServerBFV &backend, core
         proof.RingSwitchLogN = rs->LogN();
         proof.MatRSwitched = rs->RingSwitchNew(matR, backend);
         proof.MatZSwitched = rs->RingSwitchNew(matZ, backend);
+    }
+    proof.MatR = ShardedCiphertexts(std::move(matR));
+    proof.MatZ = ShardedCiphertexts(std::move(matZ));
+    return proof;
+}
+
+EncryptedProof LigeroProver::Prove(core::Element point, ServerGroup &group, core::Transcript &transcript, core::Span *ctx) {
+    const int cols = Committer->Metadata.Cols, rows = Committer->Metadata.Rows, W = group.World();
+    if (!MatrixShards || (int)MatrixShards->Blocks.size() != W || (int)EncodedLevel1.Blocks.size() != W)
+        throw std::invalid_argument("Prove: this prover was not committed on a group of this size");
+    ServerBFV &lead = group.Rank(0);
+    // don't write root to transcript for compatibility with LigeroProveReference (ligero.go:198-199)
+    std::vector<uint64_t> r((size_t)rows);
+    transcript.SampleUints("r", r);
+    Plaintext rPt = lead.Encode(r);
+    std::vector<uint64_t> b((size_t)rows);
+    const core::Element zPow = lead.Field()->Pow((uint64_t)cols, point);
+    core::Element powB = 1;
+    for (uint64_t &bi : b) {
+        bi = powB;
+        powB = lead.Field()->Mul(powB, zPow);
+    }
+    Plaintext bPt = lead.Encode(b);
+
+    // every rank evaluates its own block of columns; the calls only enqueue, so the W GPUs run side by side
+    auto inner = [&](const Plaintext &pt) {
+        ShardedCiphertexts out;
+        for (int k = 0; k < W; k++) out.Blocks.push_back(matrixInnerSumEval(MatrixShards->Blocks[(size_t)k], pt, rows, group.Rank(k)));
+        group.Sync();
+        return out;
+    };
+    core::Span *spanR = core::Span::StartSpan("InnerProduct(Matrix, r)", ctx);
+    ShardedCiphertexts matR = inner(rPt);
+    spanR->End();
+    delete spanR;
+    core::Span *spanZ = core::Span::StartSpan("InnerProduct(Matrix, b)", ctx);
+    ShardedCiphertexts matZ = inner(bPt);
+    spanZ->End();
+    delete spanZ;
+
+    transcript.AppendField("point", point);
+
+    core::Span *querySpan = core::Span::StartSpan("Query columns", ctx);
+    const int extCols = cols * Committer->Metadata.RhoInv;
+    EncryptedProof proof;
+    proof.QueryIndices = sampleQueryIndices(transcript, Committer->Metadata.Queries, extCols);
+    std::vector<uint32_t> idx(proof.QueryIndices.begin(), proof.QueryIndices.end());
+    std::vector<const lumen_set *> blocks;
+    for (const Ciphertexts &c : EncodedLevel1.Blocks) blocks.push_back(c.Handle());
+    lumen_set *q = nullptr;
+    group.check(lumen_group_gather(group.Handle(), blocks.data(), idx.data(), (uint32_t)idx.size(), &q), "lumen_group_gather");
+    proof.QueriedCols = Ciphertexts(lead.Context(), q, EncodedLevel1.Meta());
+    for (int i : proof.QueryIndices) proof.MerklePaths.push_back(Tree.GetMerklePath((unsigned)i));
+    querySpan->End();
+    delete querySpan;
+
+    proof.Metadata = Committer->Metadata;
+    proof.Root = Tree.MerkleRoot();
+    proof.PlaintextModulus = lead.GetParameters().T;
+    if (lead.RingSwitch()) { // ligero.go:336-342 on every rank's block (the key is loaded on every rank's context)
+        proof.RingSwitchLogN = lead.RingSwitch()->LogN();
+        for (int k = 0; k < W; k++) {
+            ServerBFV &s = group.Rank(k);
+            const RingSwitchServer *rs = s.RingSwitch() ? s.RingSwitch() : lead.RingSwitch();
+            const std::vector<uint64_t> pr = rs->RingSwitchNew(matR.Blocks[(size_t)k], s), pz = rs->RingSwitchNew(matZ.Blocks[(size_t)k], s);
+            proof.MatRSwitched.insert(proof.MatRSwitched.end(), pr.begin(), pr.end());
+            proof.MatZSwitched.insert(proof.MatZSwitched.end(), pz.begin(), pz.end());
+        }
     }
     proof.MatR = std::move(matR);
     proof.MatZ = std::move(matZ);
@@ -645,18 +862,27 @@ static uint8_t *write_small_cts(uint8_t *o, const std::vector<uint64_t> &res, co
     return o;
 }
 
-static size_t slice_size(const Ciphertexts &c) {
-    return c.Len() ? lumen_ct_serialized_size(c.Context(), (uint32_t)c.Level() + 1) * (size_t)c.Len() : 0;
+// bytes of a slice in the framing of ITS OWN MetaData and level (the context's current format is whatever the
+// last Commit / Unmarshal left there): each ciphertext is MetaData | LE64(2) | 2 x (LE64(limbs) | limbs x (LE64(N) | N words))
+static size_t slice_size(const Ciphertexts &c, uint64_t T) {
+    if (!c.Len()) return 0;
+    const size_t N = g_ring_degree.at(c.Context()), nl = (size_t)c.Level() + 1;
+    return (MetaDataJSON(c.Meta, T).size() + 8 + 2 * (8 + nl * (8 + N * 8))) * (size_t)c.Len();
+}
+static size_t slice_size(const ShardedCiphertexts &s, uint64_t T) {
+    size_t n = 0;
+    for (const Ciphertexts &b : s.Blocks) n += slice_size(b, T);
+    return n;
 }
 
 size_t EncryptedProof::MarshaledSize() const {
     size_t n = 11;
     if (RingSwitchLogN)
-        n += small_ct_size(MatR.Meta, PlaintextModulus, RingSwitchLogN) * (MatRSwitched.size() + MatZSwitched.size()) /
+        n += small_ct_size(MatR.Meta(), PlaintextModulus, RingSwitchLogN) * (MatRSwitched.size() + MatZSwitched.size()) /
              ((size_t)2 << RingSwitchLogN);
     else
-        n += slice_size(MatR) + slice_size(MatZ);
-    n += slice_size(QueriedCols);
+        n += slice_size(MatR, PlaintextModulus) + slice_size(MatZ, PlaintextModulus);
+    n += slice_size(QueriedCols, PlaintextModulus);
     for (const auto &path : MerklePaths) n += path.size() * 32;
     return n + Root.size();
 }
@@ -667,33 +893,47 @@ void EncryptedProof::MarshalInto(uint8_t *out, size_t cap, bool pageLocked) cons
     Metadata.WriteTo(md); // ligero.go:660
     memcpy(out, md.data(), md.size());
     uint8_t *o = out + md.size();
-    lumen_ctx *ctx = QueriedCols.Context();
-    auto put = [&](const Ciphertexts &c) -> size_t { // ct.WriteTo(buf) for every ciphertext of the slice
-        const size_t bytes = slice_size(c);
+    std::set<lumen_ctx *> used; // every context a DMA into `out` was enqueued on
+    auto put1 = [&](const Ciphertexts &c) -> size_t { // ct.WriteTo(buf) for every ciphertext of the slice
+        const size_t bytes = slice_size(c, PlaintextModulus);
         if (bytes) {
+            // the framing of THIS slice's MetaData and level, not whatever format the context was left with
+            set_format(c.Context(), c.Meta, c.Level(), PlaintextModulus, g_ring_degree.at(c.Context()));
+            if (lumen_ct_serialized_size(c.Context(), (uint32_t)c.Level() + 1) * (size_t)c.Len() != bytes)
+                throw std::runtime_error("MarshalInto: the device's serialised size differs from the framing's");
             const int rc = pageLocked ? lumen_ct_serialize_async(c.Context(), c.Handle(), 0, (uint32_t)c.Len(), o, bytes)
                                       : lumen_ct_serialize(c.Context(), c.Handle(), 0, (uint32_t)c.Len(), o, bytes);
             if (rc) throw std::runtime_error(std::string("lumen_ct_serialize: ") + lumen_last_error(c.Context()));
+            used.insert(c.Context());
         }
         o += bytes;
+        return bytes;
+    };
+    auto put = [&](const ShardedCiphertexts &sc) -> size_t { // the blocks in rank order = column order
+        size_t bytes = 0;
+        for (const Ciphertexts &b : sc.Blocks) bytes += put1(b);
         return bytes;
     };
     size_t szR, szZ;
     if (RingSwitchLogN) {
         uint8_t *o0 = o;
-        o = write_small_cts(o, MatRSwitched, MatR.Meta, PlaintextModulus, RingSwitchLogN);
+        o = write_small_cts(o, MatRSwitched, MatR.Meta(), PlaintextModulus, RingSwitchLogN);
         szR = (size_t)(o - o0), o0 = o;
-        o = write_small_cts(o, MatZSwitched, MatZ.Meta, PlaintextModulus, RingSwitchLogN);
+        o = write_small_cts(o, MatZSwitched, MatZ.Meta(), PlaintextModulus, RingSwitchLogN);
         szZ = (size_t)(o - o0);
     } else {
         szR = put(MatR); // ligero.go:664-671
         szZ = put(MatZ); // ligero.go:674-681
     }
-    const size_t szQ = put(QueriedCols); // ligero.go:684-691
+    const size_t szQ = put1(QueriedCols); // ligero.go:684-691
     for (const auto &path : MerklePaths)
         for (const core::Digest &d : path) memcpy(o, d.data(), 32), o += 32; // ligero.go:694-698
     memcpy(o, Root.data(), Root.size()), o += Root.size();                    // ligero.go:700
-    if (pageLocked && ctx && lumen_sync(ctx)) throw std::runtime_error(std::string("lumen_sync: ") + lumen_last_error(ctx));
+    // the bytes are in place once EVERY context that moved a slice has drained (MatR / MatZ may live on clones
+    // or on other GPUs than the queried columns)
+    if (pageLocked)
+        for (lumen_ctx *c : used)
+            if (lumen_sync(c)) throw std::runtime_error(std::string("lumen_sync: ") + lumen_last_error(c));
     if (!core::Span::quiet) {
         printf("Marshaled MatR: %s\n", HumanizeBytes(szR).c_str());
         printf("Marshaled MatZ: %s\n", HumanizeBytes(szZ).c_str());
@@ -723,8 +963,8 @@ EncryptedProof EncryptedProof::UnmarshalBinary(const uint8_t *data, size_t len, 
         off += bytes;
         return Ciphertexts(ctx, s, meta);
     };
-    p.MatR = take(p.Metadata.Cols);      // ligero.go:712-718
-    p.MatZ = take(p.Metadata.Cols);      // ligero.go:720-726
+    p.MatR = ShardedCiphertexts(take(p.Metadata.Cols)); // ligero.go:712-718
+    p.MatZ = ShardedCiphertexts(take(p.Metadata.Cols)); // ligero.go:720-726
     p.QueriedCols = take(p.Metadata.Queries); // ligero.go:728-734
     const int merkleLen = p.Metadata.Cols * p.Metadata.RhoInv; // ligero.go:736-739
     int depth = 0;

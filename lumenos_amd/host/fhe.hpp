@@ -4,6 +4,7 @@
 // test written against it reads like fhe/ligero_test.go; where the Go code hands []*rlwe.Ciphertext
 // around, this mirror hands `Ciphertexts` (an HBM-resident lumen_set) around.
 #pragma once
+#include <atomic>
 #include <map>
 #include <memory>
 #include <string>
@@ -89,6 +90,20 @@ class Ciphertexts {
     lumen_set *set_ = nullptr;
 };
 
+// []*rlwe.Ciphertext spread over the ranks of a ServerGroup in contiguous blocks: block r (columns
+// [r*Len/W, (r+1)*Len/W)) is resident on rank r's GPU.  One block = an ordinary slice on one GPU; the proof's
+// MatR / MatZ are of this type either way, and the wire format is the blocks' ciphertexts in order.
+struct ShardedCiphertexts {
+    std::vector<Ciphertexts> Blocks;
+    ShardedCiphertexts() = default;
+    explicit ShardedCiphertexts(Ciphertexts one) { Blocks.push_back(std::move(one)); }
+    int Len() const;
+    int Level() const { return Blocks.empty() ? -1 : Blocks[0].Level(); }
+    const MetaData &Meta() const;
+    uint64_t Scale() const { return Meta().Scale; }
+    std::vector<uint64_t> Download() const; // the blocks in order: [Len][2][level+1][N]
+};
+
 // Scale after `for ct.Level() > target { Rescale }` from level `from`: scale * prod q_l^-1 mod T
 uint64_t RescaledScale(const Parameters &params, uint64_t scale, int fromLevel, int toLevel);
 // The MetaData block rlwe.Ciphertext.WriteTo puts in front of the polynomials, as recalled
@@ -123,8 +138,15 @@ class ServerBFV {
     void check(int rc, const char *what) const; // throws std::runtime_error with lumen_last_error
     void SetRingSwitchServer(RingSwitchServer *rs) { rs_ = rs; } // bfv.go:48-50
     RingSwitchServer *RingSwitch() const { return rs_; }          // bfv.go:52-54
+    // ServerBFV.CopyNew (bfv.go:56-58): Evaluator.ShallowCopy -- the same parameters, keys and ENCRYPTOR (the Go
+    // copy shares the pointer: seed and position in its stream), its own scratch: a lumen_ctx_clone on the same
+    // GPU.  What a goroutine that evaluates concurrently takes (ligero.go:142, 315), and what plays a rank of a
+    // ServerGroup when several ranks share one GPU.  The copy must not outlive the server it was made from.
+    std::unique_ptr<ServerBFV> CopyNew();
 
   private:
+    ServerBFV(ServerBFV &src, lumen_ctx *clone);
+    friend class ServerGroup;
     core::PrimeField *ptField_;
     Parameters params_;
     std::vector<uint64_t> pk_;
@@ -132,12 +154,44 @@ class ServerBFV {
     uint64_t psiT_ = 0;
     std::vector<uint32_t> slot_index_;
     RingSwitchServer *rs_ = nullptr;
-    uint8_t enc_seed_[32] = {0}; // ChaCha20 key of every sample this server draws: OsRandom, never a PRNG
-    uint64_t enc_next_ = 0;
+    // the encryptor's state, shared with every CopyNew and by the ranks of a ServerGroup: the ChaCha20 key of
+    // every sample drawn (OsRandom, never a PRNG) and the index of the next ciphertext in its stream
+    struct EncryptorState {
+        uint8_t seed[32] = {0};
+        std::atomic<uint64_t> next{0};
+    };
+    std::shared_ptr<EncryptorState> enc_;
 
   public:
-    // test hook: the seed must differ between instances (it is the only secret of the encryptor)
-    const uint8_t *EncSeedForTest() const { return enc_seed_; }
+    // test hooks: the seed must differ between instances (it is the only secret of the encryptor); rewinding the
+    // stream lets a test encrypt the same witness twice to the same bits (one GPU against a group)
+    const uint8_t *EncSeedForTest() const { return enc_->seed; }
+    void RewindEncryptorForTest(uint64_t next = 0) { enc_->next = next; }
+};
+
+// W = 2^k ServerBFVs behind one lumen_group (include/lumenos_hip.h): the ranks of ONE server process that owns
+// several GPUs -- the reference's server is a single process (cmd/server/main.go:187-266).  ranks[r] is rank r;
+// they hold the same parameters, public key and evaluation keys (one NewBackendBFV per GPU, or CopyNew()s of one
+// server when ranks share a GPU).  The group makes them ONE encryptor: every rank draws from rank 0's stream, so
+// a column encrypts to the same bits on whichever GPU it lands.
+class ServerGroup {
+  public:
+    explicit ServerGroup(std::vector<ServerBFV *> ranks, uint32_t transport = LUMEN_TRANSPORT_AUTO);
+    ~ServerGroup();
+    ServerGroup(const ServerGroup &) = delete;
+    int World() const { return (int)ranks_.size(); }
+    ServerBFV &Rank(int r) const { return *ranks_.at((size_t)r); }
+    lumen_group *Handle() const { return group_; }
+    std::string Transport() const { return lumen_group_transport(group_); }
+    void check(int rc, const char *what) const; // throws std::runtime_error with lumen_last_error(NULL)
+    void Sync() const;
+    // the witness encryption loop of cmd/server/main.go:188-208 over the ranks: column j (of `count`, `rows`
+    // values each) is encoded and encrypted on rank j / (count/W), with its own place in the encryptor's stream
+    ShardedCiphertexts EncryptColumnsNew(const std::vector<uint64_t> &values, int rows, int count);
+
+  private:
+    std::vector<ServerBFV *> ranks_;
+    lumen_group *group_ = nullptr;
 };
 
 // n bytes from the kernel CSPRNG (getrandom(2)); throws if unavailable
@@ -161,6 +215,9 @@ class RingSwitchServer {
 
 // fhe.Encode (fhe/code.go:8-34)
 Ciphertexts Encode(const Ciphertexts &matrix, int rows, int rhoInv, ServerBFV &backend);
+// the same over a group: matrix.Blocks[r] = rank r's columns; the lane-sharded transform between two all-to-alls
+// (lumen_group_encode), byte-identical to Encode on one GPU
+ShardedCiphertexts Encode(const ShardedCiphertexts &matrix, int rows, int rhoInv, ServerGroup &group);
 // fhe.NTT (fhe/ntt.go:12-18): in place on `values`
 void NTT(Ciphertexts &values, int size, ServerBFV &backend);
 
@@ -194,7 +251,8 @@ std::string HumanizeBytes(uint64_t s);
 
 struct EncryptedProof { // fhe/ligero.go:185-192
     LigeroMetadata Metadata;
-    Ciphertexts MatR, MatZ, QueriedCols;
+    ShardedCiphertexts MatR, MatZ; // one block on one GPU; with a ServerGroup block r is resident on rank r
+    Ciphertexts QueriedCols;
     // with a ring switch (ligero.go:336-342) MatR / MatZ are level-0 ciphertexts of the small ring instead:
     // host residues [cols][2][2^RingSwitchLogN] (what RingSwitchNew returns), MetaData as the inputs'
     std::vector<uint64_t> MatRSwitched, MatZSwitched;
@@ -223,10 +281,21 @@ class LigeroCommitter;
 struct LigeroProver { // fhe/ligero.go:32-37
     const LigeroCommitter *Committer = nullptr;
     const Ciphertexts *Matrix = nullptr;
-    Ciphertexts EncodedMatrix; // kept at level 1: the reference re-rescales queried columns to it
+    const ShardedCiphertexts *MatrixShards = nullptr; // the same when Commit ran on a ServerGroup
+    // DEVIATION from the reference's field (ligero.go:32-37, 117-123): there `EncodedMatrix` is the top-level
+    // encoded matrix, whose queried entries Prove rescales IN PLACE to level 1 and aliases into the proof
+    // (ligero.go:268-273).  Here Commit keeps the LEVEL-1 columns it hashed -- the only form Prove ever reads
+    // (25.8 GB of top-level ciphertexts at 16384 x 4096 against 4.3 GB) -- hence the other name: a caller reading
+    // it sees level-1 columns everywhere, not just at the queried indices.  Proof bytes are the same, and so is a
+    // second Prove on the same prover (the reference's `for Level() > 1` finds nothing left to do on the columns
+    // the first one touched): tests/cpp/test_ligero_host.cpp proves twice.
+    ShardedCiphertexts EncodedLevel1;
     core::MerkleTree Tree;
     // ligero.go:194-291
     EncryptedProof Prove(core::Element point, ServerBFV &backend, core::Transcript &transcript, core::Span *ctx);
+    // the same over the ranks of a group: inner products on every rank's own columns, the queried columns
+    // collected on rank 0 (lumen_group_gather); the proof's bytes are those of the one-GPU run
+    EncryptedProof Prove(core::Element point, ServerGroup &group, core::Transcript &transcript, core::Span *ctx);
 };
 
 class LigeroCommitter { // fhe/ligero.go:27-29, 40-63
@@ -235,6 +304,10 @@ class LigeroCommitter { // fhe/ligero.go:27-29, 40-63
     static LigeroCommitter NewLigeroCommitter(double securityBits, int rows, int cols, int rhoInv);
     // ligero.go:95-124: returns the prover state and the Merkle root
     std::pair<LigeroProver, std::vector<uint8_t>> Commit(const Ciphertexts &matrix, ServerBFV &backend,
+                                                         core::Span *ctx) const;
+    // the same over the ranks of a group: Encode between two all-to-alls, every rank rescales and
+    // hashes its block of encoded columns, ONE all-gather assembles the S leaf digests, the host keeps the tree
+    std::pair<LigeroProver, std::vector<uint8_t>> Commit(const ShardedCiphertexts &matrix, ServerGroup &group,
                                                          core::Span *ctx) const;
 };
 

@@ -1,9 +1,12 @@
 // C++ twin of TestLigeroE2E (fhe/ligero_test.go:70-176) against the host mirror in
 // lumenos_amd/host: the server side runs on the GPU through the C ABI, the client side
 // (keys, decryption) and the plain verifier arithmetic come from the CPU oracle (test infra).
-//   usage: test_ligero_host <logN> <rows> <cols> <numQ> [ringSwitchLogN]
-// With ringSwitchLogN the run is the reference's "experimental" configuration (cmd/client/main.go:112-131,
+//   usage: test_ligero_host <logN> <rows> <cols> <numQ> [ringSwitchLogN [world]]
+// With ringSwitchLogN (non-zero) the run is the reference's "experimental" configuration (cmd/client/main.go:112-131,
 // fhe/ligero.go:336-342): MatR / MatZ leave as level-0 ciphertexts of the small ring.
+// With world = W > 1 the same witness is then committed and proven a second time by a ServerGroup of W ranks
+// (the server and W-1 CopyNew()s on this one GPU, the exchange steps inside the library: lumen_group_*): the
+// Merkle root and every byte of the marshaled proof must equal the one-GPU run's, which has just been verified.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +43,7 @@ int main(int argc, char **argv) {
     const int cols = argc > 3 ? atoi(argv[3]) : 16;
     const int numQ = argc > 4 ? atoi(argv[4]) : 6;
     const int ringSwitchLogN = argc > 5 ? atoi(argv[5]) : 0;
+    const int world = argc > 6 ? atoi(argv[6]) : 1;
     core::Span::quiet = false;
 
     // run(): parameters, keys (ligero_test.go:36-68)
@@ -137,8 +141,8 @@ int main(int argc, char **argv) {
     REQUIRE(proof.MatR.Scale() == scale && proof.MatZ.Scale() == scale && proof.QueriedCols.Scale() == scale,
             "scale bookkeeping: MatR %llu MatZ %llu Queried %llu, expected %llu", (unsigned long long)proof.MatR.Scale(),
             (unsigned long long)proof.MatZ.Scale(), (unsigned long long)proof.QueriedCols.Scale(), (unsigned long long)scale);
-    REQUIRE(proof.MatR.Meta.IsNTT && proof.MatR.Meta.IsBatched && !proof.MatR.Meta.IsMontgomery &&
-                proof.MatR.Meta.LogRows == 1 && proof.MatR.Meta.LogCols == LogN - 1, "metadata flags");
+    REQUIRE(proof.MatR.Meta().IsNTT && proof.MatR.Meta().IsBatched && !proof.MatR.Meta().IsMontgomery &&
+                proof.MatR.Meta().LogRows == 1 && proof.MatR.Meta().LogCols == LogN - 1, "metadata flags");
     REQUIRE(proof.MatR.Level() == 1 && proof.QueriedCols.Level() == 1, "proof ciphertexts are at level 1");
 
     // the serialisation format Commit installed: MetaData JSON | LE64(2), LE64(limbs), LE64(N); the checker
@@ -160,6 +164,22 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> marshaled = proof.MarshalBinary();
     REQUIRE(marshaled.size() == wire.size() && !memcmp(marshaled.data(), wire.data(), wire.size()),
             "MarshalBinaryPinned and MarshalBinary disagree");
+    {
+        // a second Prove on the same prover (in the reference the queried entries of EncodedMatrix
+        // are at level 1 by then and its `for Level() > 1` loop finds nothing to do): the same proof, byte for byte
+        core::Span::quiet = true;
+        core::Transcript again("test");
+        fhe::EncryptedProof proof2 = comm.Prove(z, server, again, nullptr);
+        std::vector<uint8_t> marshaled2 = proof2.MarshalBinary();
+        core::Span::quiet = false;
+        REQUIRE(marshaled2 == marshaled, "a second Prove on the same prover gives other proof bytes");
+        // ... and MarshalBinary frames every slice with ITS OWN MetaData and level, whatever serialisation format
+        // the context was left with (here: the plain prover's empty one)
+        const uint8_t none = 0;
+        REQUIRE(!lumen_leaf_format_set(server.Context(), &none, 0, &none, 0, &none, 0), "lumen_leaf_format_set");
+        REQUIRE(proof.MarshalBinary() == marshaled, "MarshalBinary depends on the context's current format");
+        printf("second Prove and re-marshal under another context format: same %zu bytes\n", marshaled.size());
+    }
     const size_t ct1 = lo_ct_serialized_size_fmt(&fmt, 2, (uint32_t)N);
     REQUIRE(ct1 == json.size() + 8 + 2 * (8 + 2 * (8 + (size_t)N * 8)), "serialised size");
     if (!ringSwitchLogN) {
@@ -302,6 +322,53 @@ int main(int argc, char **argv) {
     REQUIRE(claim == value, "claimed value does not match the evaluation of the committed polynomial");
     printf("PASS TestLigeroE2E (host mirror): rows=%d cols=%d LogN=%d L=%d proof=%zu bytes\n", rows, cols, LogN, L,
            marshaled.size());
+
+    if (world > 1) {
+        // ---- the same request on a ServerGroup of `world` ranks: rank 0 is the server, the others its
+        // CopyNew()s (one GPU here: they share its keys; on a node every rank is a NewBackendBFV on its own GPU).
+        // The encryptor's stream is rewound so that the witness columns and the one Enc(0) of fhe.Encode come out as
+        // the bits of the run above.
+        std::vector<std::unique_ptr<fhe::ServerBFV>> copies;
+        std::vector<fhe::ServerBFV *> ranks{&server};
+        for (int k = 1; k < world; k++) {
+            copies.push_back(server.CopyNew());
+            ranks.push_back(copies.back().get());
+        }
+        REQUIRE(!lumen_ctx_trim(server.Context()), "lumen_ctx_trim"); // several contexts share this GPU's memory
+        fhe::ServerGroup group(ranks, LUMEN_TRANSPORT_AUTO);
+        printf("ServerGroup: %d ranks, transport %s\n", group.World(), group.Transport().c_str());
+        server.RewindEncryptorForTest(0);
+        span = core::Span::StartSpan("Encrypt matrix (group)", nullptr);
+        fhe::ShardedCiphertexts shards = group.EncryptColumnsNew(columns, rows, cols);
+        span->End();
+        server.RewindEncryptorForTest((uint64_t)cols + 1); // the single column the run above encrypted on the side
+        REQUIRE((int)shards.Blocks.size() == world && shards.Len() == cols, "sharded witness");
+        REQUIRE(shards.Download() == ciphertexts.Download(), "the group's encryptions differ from the server's");
+        span = core::Span::StartSpan("Commit FHE evaluation (group)", nullptr);
+        auto gcommit = ligero.Commit(shards, group, span);
+        span->End();
+        REQUIRE(gcommit.second == commit.second, "the group's Merkle root differs from the one-GPU root");
+        core::Transcript gT("test");
+        span = core::Span::StartSpan("Prove FHE evaluation (group)", nullptr);
+        fhe::EncryptedProof gproof = gcommit.first.Prove(z, group, gT, span);
+        span->End();
+        REQUIRE((int)gproof.MatR.Blocks.size() == world && gproof.MatR.Len() == cols, "MatR blocks");
+        REQUIRE(gproof.QueryIndices == proof.QueryIndices && gproof.MerklePaths == proof.MerklePaths, "queries / paths");
+        span = core::Span::StartSpan("Marshal proof (group)", nullptr);
+        fhe::WireBuffer gwire = gproof.MarshalBinaryPinned();
+        span->End();
+        REQUIRE(gwire.size() == wire.size(), "group proof has %zu bytes, one-GPU proof %zu", gwire.size(), wire.size());
+        size_t at = 0;
+        while (at < wire.size() && gwire.data()[at] == wire.data()[at]) at++;
+        REQUIRE(at == wire.size(), "group proof differs from the one-GPU proof at byte %zu", at);
+        for (const char *name : {"all_to_all", "all_gather", "gather_to_root"}) {
+            double ms = 0;
+            uint64_t bytes = 0, calls = 0;
+            REQUIRE(!lumen_group_stats(group.Handle(), name, &ms, &bytes, &calls), "lumen_group_stats");
+            printf("  %s: %llu call(s), %.3f ms, %.1f MB sent per rank\n", name, (unsigned long long)calls, ms, bytes / 1e6);
+        }
+        printf("PASS ServerGroup W=%d: same Merkle root, byte-identical proof (%zu bytes)\n", world, gwire.size());
+    }
     lo_params_free(op);
     return 0;
 }

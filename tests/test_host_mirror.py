@@ -40,6 +40,9 @@ def test_host_transcript_and_field_match_oracle(oracle):
     for sym in ("lumenos::fhe::Encode(", "lumenos::fhe::NTT(", "lumenos::fhe::LigeroCommitter::Commit(",
                 "lumenos::fhe::LigeroProver::Prove(", "lumenos::fhe::EncryptedProof::MarshalBinary(",
                 "lumenos::fhe::GenerateBGVParamsForNTT(", "lumenos::core::Transcript::SampleUint64(",
+                "lumenos::fhe::ServerGroup::ServerGroup(", "lumenos::fhe::ServerBFV::CopyNew(",
+                "lumenos::fhe::LigeroCommitter::Commit(lumenos::fhe::ShardedCiphertexts const&",
+                "lumenos::fhe::LigeroProver::Prove(unsigned long, lumenos::fhe::ServerGroup&",
                 "lumenos::core::MerkleTree::GetMerklePath(", "lumenos::core::RandomMatrixRowMajor("):
         assert sym in out, sym
     assert lib is not None
@@ -110,3 +113,28 @@ def test_ligero_e2e_host_mirror(shape, sizes):
         for label, want in zip(("Marshaled MatR", "Marshaled MatZ", "Marshaled QueriedCols",
                                 "Marshaled encrypted proof length"), sizes):
             assert f"{label}: {want}" in res.stdout, (label, want, [l for l in res.stdout.splitlines() if "Marshaled" in l])
+
+
+# (logN, rows, cols, L, ringSwitchLogN, world): the reference's own test shape (TestLigeroE2E / TestLigeroPPD, BASELINE
+# config 1) on 2, 4 and 8 ranks, with and without the ring switch, and the headline parameters (BASELINE config 4:
+# "16384x4096 LogN=14, 8 x MI355X, rows sharded") on 2 and 8 ranks
+GROUP_SHAPES = [(10, 512, 16, 6, 0, 2), (11, 2048, 64, 8, 10, 4),
+                (12, 2048, 1024, 10, 0, 2), (12, 2048, 1024, 10, 0, 4), (12, 2048, 1024, 10, 0, 8),
+                (12, 2048, 1024, 10, 10, 8),
+                (14, 16384, 4096, 12, 0, 2), (14, 16384, 4096, 12, 0, 8)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", GROUP_SHAPES)
+def test_ligero_e2e_server_group_matches_one_gpu(shape):
+    """SURVEY 8e through the C++ mirror: after the one-GPU TestLigeroE2E twin has passed (decrypt + Verify by the
+    oracle), the same witness is committed and proven by a ServerGroup of W ranks -- W contexts on this one GPU, the
+    two all-to-alls, the digest all-gather and the query gather inside the library (lumen_group_*, copy transport) --
+    and must give the same Merkle root and a byte-identical marshaled proof."""
+    args = [str(x) for x in shape]
+    res = subprocess.run([build_binary()] + args, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "PASS TestLigeroE2E" in res.stdout
+    assert f"ServerGroup: {shape[5]} ranks, transport copy" in res.stdout
+    assert f"PASS ServerGroup W={shape[5]}: same Merkle root, byte-identical proof" in res.stdout
+    assert "second Prove and re-marshal under another context format: same" in res.stdout

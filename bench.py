@@ -25,6 +25,16 @@ Nothing is replicated.  Worlds the lane path cannot serve are REFUSED unless --a
 the round-1 path (every rank holds the matrix and runs the mixing passes itself); config.parallelism names
 the path that ran.
 
+The exchange steps run INSIDE the library (include/lumenos_hip.h, lumen_group_*): --transport rccl (default) has
+every rank join an RCCL communicator of the library's own (lumen_group_create_rank; torch.distributed, backend
+gloo, only carries the 128-byte id, the barriers and the max over ranks); if that cannot be set up the run falls
+back to --transport torch (the collectives of torch.distributed on tensors that alias the library's memory) and
+says so in config.transport.  --single-process runs all N ranks from ONE process, one context per GPU behind
+lumen_group_create -- the topology of the reference's server (one Go process, cmd/server/main.go:187-266); with
+--share-gpu its N contexts sit on device 0 (copy transport: the one-GPU rehearsal).  For N > 1 the line carries
+rccl_ranks_seen, per-collective times and GB/s, per-rank stage times and roofline, and `check`: root, encoded
+columns and inner products of an N-rank run at 2048x1024 against a single-rank recompute.
+
 Rank 0 prints ONE JSON line (see the keys at the bottom of main()).  At N = 1 the default run also carries
   * marshal_s / io_inclusive_s: the proof as wire-format bytes in page-locked host memory
     (EncryptedProof.WriteTo, fhe/ligero.go:659-705) and a step that starts with the input ciphertexts in
@@ -129,7 +139,10 @@ NTT_KERNELS = ("ks_modup_ntt", "ks_moddown_ntt", "rescale_limb_ntt", "rescale_la
 class Job:
     """Device-resident inputs of one prover run + the step function."""
 
-    def __init__(self, cfg, rank, world, device, ring_switch_logn=0, allow_replicated=False):
+    def __init__(self, cfg, rank, world, device, ring_switch_logn=0, allow_replicated=False, local_devices=None):
+        """local_devices: None = this process is ONE rank (`rank`, on `device`); a list of `world` device ordinals =
+        this process owns ALL ranks (--single-process), rank i on local_devices[i] (the same ordinal repeated:
+        several ranks share that GPU as clones of one context)."""
         from lumenos_amd.hip import Context
         self.rows, self.cols, self.log_n = CONFIGS[cfg]
         self.rank, self.world = rank, world
@@ -138,8 +151,21 @@ class Job:
         self.L, self.K, self.N = len(P.q), len(P.p), P.N
         self.S = self.cols * RHO_INV
         self.queries = lp.calculate_queries(SECURITY_BITS, RHO_INV)
-        self.ctx = ctx = Context(P.log_n, P.q, P.p, P.psi, P.T, device=device)
-        ctx.field_set(np.array(lp.field_roots_forward(P.T, self.S), dtype=np.uint64))
+        self.group = None
+        self.ctx_device, self.local_devices = (local_devices[0] if local_devices else device), local_devices
+        self.local_ranks = list(range(world)) if local_devices else [rank]
+        devices = list(local_devices) if local_devices else [device]
+        # one context per device; further ranks on a device are clones (they share its tables and keys)
+        by_device, self.ctxs = {}, []
+        for d in devices:
+            if d in by_device:
+                self.ctxs.append(by_device[d].clone())
+            else:
+                by_device[d] = c = Context(P.log_n, P.q, P.p, P.psi, P.T, device=d)
+                c.field_set(np.array(lp.field_roots_forward(P.T, self.S), dtype=np.uint64))
+                self.ctxs.append(c)
+        self._key_ctxs = list(by_device.values())
+        self.ctx = ctx = self.ctxs[0]
         rng = np.random.default_rng(1)
         # lane-sharded Encode needs a power-of-two world whose lane shards keep at least one tile
         self.lane_path = world > 1 and (world & (world - 1)) == 0 and self.cols % world == 0 and (self.N // world) >= 64
@@ -151,7 +177,9 @@ class Job:
         # synthetic inputs: uniform residues (kernels are data-independent); with the lane path a
         # rank only ever holds its own block of columns
         own = self.cols // world if self.lane_path else self.cols
-        self.matrix = ctx.new_set(own, self.L).fill_random(1 + (rank if self.lane_path else 0))
+        self.matrices = [c.new_set(own, self.L).fill_random(1 + (r if self.lane_path else 0))
+                         for c, r in zip(self.ctxs, self.local_ranks)]
+        self.matrix = self.matrices[0]
 
         def rand_limbs(mods, shape_tail):
             out = np.empty((len(mods),) + shape_tail, dtype=np.uint64)
@@ -166,7 +194,8 @@ class Job:
         for g in ctx.inner_sum_galois_elements(self.rows):
             evk = np.ascontiguousarray(
                 rand_limbs(P.q + P.p, (beta, 2, self.N)).transpose(1, 2, 0, 3))  # [beta][2][L+K][N]
-            ctx.load_galois_key(g, evk)
+            for c in self._key_ctxs:
+                c.load_galois_key(g, evk)
         self.query_idx = rng.integers(0, self.S, size=self.queries).astype(np.uint32)
         self.ring_switch_logn = 0
         self._rand_limbs = rand_limbs
@@ -177,7 +206,8 @@ class Job:
         if self.lane_path:  # self.matrix IS the rank's block; its slice of the one Enc(0) for the lane Encode
             nw = self.N // world
             self.zero_lanes = np.ascontiguousarray(self.zero_ct[:, :, rank * nw:(rank + 1) * nw])
-        ctx.sync()
+        for c in self.ctxs:
+            c.sync()
 
     def enable_ring_switch(self, logn):
         """BASELINE config 5: RingSwitchNew on MatR / MatZ (ligero.go:336-342).  The key is the whole evaluation
@@ -186,19 +216,28 @@ class Job:
         P = self.P
         rns, pw2 = self.ctx.ringswitch_key_shape(13)[:2]
         key = np.ascontiguousarray(self._rand_limbs(P.q + P.p, (rns, pw2, 2, self.N)).transpose(1, 2, 3, 0, 4))
-        self.ctx.load_ringswitch_key(logn, key)
+        for c in self._key_ctxs:
+            c.load_ringswitch_key(logn, key)
+        for c in self.ctxs:
+            c._rs_logn = logn
         self.ring_switch_logn = logn
         from lumenos_amd.hip import pinned_empty
         own = self.matrix.count if self.lane_path else self.col_hi - self.col_lo
-        self.h_rs = [pinned_empty((own, 2, 1 << logn)) for _ in range(2)]  # MatR / MatZ as they leave for the proof
+        # MatR / MatZ as they leave for the proof, one pair per local rank
+        self.h_rs_all = [[pinned_empty((own, 2, 1 << logn)) for _ in range(2)] for _ in self.ctxs]
+        self.h_rs = self.h_rs_all[0]
 
     def close(self):
         for a in ("io_ctx", "up_ctx"):
             c = getattr(self, a, None)
             if c is not None:
                 c.close()
-        self.matrix.free()
-        self.ctx.close()
+        if self.group is not None:
+            self.group.close()
+        for m in self.matrices:
+            m.free()
+        for c in self.ctxs[::-1]:
+            c.close()
 
     # ---- host I/O of a prover run: the io leg of the default run
     def io_setup(self):
@@ -390,43 +429,116 @@ class Job:
             s_.free()
         return t
 
-    def step_lanes(self, dist):
-        """One step on `world` ranks with the lane-sharded Encode (module docstring)."""
+    def step_lanes(self, dist, timers=None, keep=False):
+        """One step on `world` ranks with the lane-sharded Encode (module docstring), the exchange through
+        torch.distributed on tensors aliasing the library's memory: the round-3 path, kept as --transport torch and as
+        the fallback when the library's own RCCL group cannot be set up.  timers: per-stage wall seconds of this
+        rank (every collective here ends with a device synchronisation anyway)."""
         ctx, W, rank = self.ctx, self.world, self.rank
+        pg = getattr(self, "nccl_pg", None)  # the fallback's RCCL process group (the default one is the control plane)
         Sw = self.S // W
+
+        def lap(name, t0):
+            if timers is not None:
+                ctx.sync()
+                timers[name] = timers.get(name, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+
+        t0 = time.perf_counter()
         # ---- Commit: Encode.  own columns -> lane blocks -> all-to-all -> lane shard of ALL columns
         blocks = ctx.lanes_split(self.matrix, self.logw)
         lanes = ctx.new_set_lanes(self.cols, self.L, self.logw)
-        all_to_all_sets(dist, blocks, lanes, W)
+        t0 = lap("lanes_split_s", t0)
+        all_to_all_sets(dist, blocks, lanes, W, pg)
+        t0 = lap("all_to_all_1_s", t0)
         blocks.free()
         enc = ctx.encode(lanes, self.zero_lanes, RHO_INV)  # this rank's lanes of all S encoded columns
         lanes.free()
         recv = ctx.new_set_lanes(self.S, self.L, self.logw)
-        all_to_all_sets(dist, enc, recv, W)                  # block h of every shard -> rank h
+        t0 = lap("encode_lane_shard_s", t0)
+        all_to_all_sets(dist, enc, recv, W, pg)              # block h of every shard -> rank h
+        t0 = lap("all_to_all_2_s", t0)
         enc.free()
         mine = ctx.lanes_assemble(recv)                      # whole ciphertexts of columns [rank*Sw, (rank+1)*Sw)
         recv.free()
         # ---- Commit: leaves on this rank's encoded columns, hashed under the inner products
         lvl1 = ctx.rescale(mine, 2)
-        mine.free()
+        if not keep:
+            mine.free()
         ctx.leaf_digests_begin(lvl1)
+        t0 = lap("rescale_s", t0)
         # ---- Prove: inner products on this rank's input columns
         mat_r = ctx.matrix_inner_sum(self.matrix, self.r_pt, self.rows)
+        t0 = lap("inner_product_r_s", t0)
         mat_z = ctx.matrix_inner_sum(self.matrix, self.b_pt, self.rows)
+        t0 = lap("inner_product_b_s", t0)
         if self.ring_switch_logn:
             ctx.ring_switch(mat_r, self.h_rs[0])
             ctx.ring_switch(mat_z, self.h_rs[1])
         own = self.query_idx[(self.query_idx >= rank * Sw) & (self.query_idx < (rank + 1) * Sw)] - rank * Sw
         q = ctx.gather(lvl1, own.astype(np.uint32))
+        t0 = lap("query_gather_local_s", t0)
         # ---- Commit, concluded: all-gather of the digests on device buffers, Merkle root on the device
         ptr, n = ctx.leaf_digests_end_device()
-        root = all_gather_root(dist, ctx, ptr, n, self.S, W)
+        root = all_gather_root(dist, ctx, ptr, n, self.S, W, pg)
+        t0 = lap("digest_all_gather_and_root_s", t0)
         ctx.sync()
+        if keep:
+            return [mine], [lvl1], [mat_r], [mat_z], None, root
         for s in (q, mat_r, mat_z, lvl1):
             s.free()
         return root
 
+    def step_group(self, timers=None, keep=False):
+        """One step with the exchange inside the library (lumen_group_*): this process's local ranks -- all of them
+        (--single-process) or one (a rank of torch.distributed.run) -- enqueue their stages, the group's
+        collectives order them against each other on the devices.  timers: a dict that receives per-stage wall
+        seconds, each stage drained before the next starts (the diagnostic pass; the timed steps never sync
+        between stages)."""
+        g, ctxs, W = self.group, self.ctxs, self.world
+
+        def lap(name, t0):
+            if timers is not None:
+                g.sync()
+                timers[name] = timers.get(name, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+
+        t0 = time.perf_counter()
+        # ---- Commit: Encode between the two all-to-alls (lumen_group_encode), leaves hashed on the side streams
+        enc = g.encode(self.matrices, self.zero_ct, RHO_INV)
+        t0 = lap("encode_with_both_all_to_alls_s", t0)
+        lvl1 = [c.rescale(e, 2) for c, e in zip(ctxs, enc)]
+        for c, l in zip(ctxs, lvl1):
+            c.leaf_digests_begin(l)
+        t0 = lap("rescale_s", t0)
+        # ---- Prove: inner products on every rank's own input columns
+        mat_r = [c.matrix_inner_sum(m, self.r_pt, self.rows) for c, m in zip(ctxs, self.matrices)]
+        t0 = lap("inner_product_r_s", t0)
+        mat_z = [c.matrix_inner_sum(m, self.b_pt, self.rows) for c, m in zip(ctxs, self.matrices)]
+        t0 = lap("inner_product_b_s", t0)
+        if self.ring_switch_logn:
+            for c, a, b, h in zip(ctxs, mat_r, mat_z, self.h_rs_all):
+                c.ring_switch(a, h[0])
+                c.ring_switch(b, h[1])
+            t0 = lap("ring_switch_s", t0)
+        # ---- Prove: the queried columns, collected on rank 0 in query order
+        q = g.gather(lvl1, self.query_idx)
+        t0 = lap("query_gather_to_root_s", t0)
+        # ---- Commit, concluded: ONE all-gather of the digests, Merkle root on the device
+        g.all_gather_digests()
+        root = g.merkle_root()
+        t0 = lap("digest_all_gather_and_root_s", t0)
+        g.sync()
+        if keep:
+            return enc, lvl1, mat_r, mat_z, q, root
+        for s in [q] + mat_r + mat_z + lvl1 + enc:
+            if s is not None:
+                s.free()
+        return root
+
     def step(self, dist=None, keep=False):
+        if self.group is not None:
+            return self.step_group()
         if self.lane_path and dist is not None:
             return self.step_lanes(dist)
         ctx = self.ctx
@@ -487,38 +599,38 @@ def _as_tensor(ptr, nbytes):
     return torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
 
 
-def all_to_all_sets(dist, send, recv, world):
+def all_to_all_sets(dist, send, recv, world, pg=None):
     """Block g of `send` (its g-th slice of count/world ciphertexts, contiguous: the layouts are ct-major)
     goes to rank g; block r of `recv` comes from rank r.  RCCL all-to-all on the sets' device memory; with
     gloo (one-GPU rehearsal) the same routing through the host."""
     import torch
     assert send.nbytes == recv.nbytes and send.count % world == 0
     send.ctx.sync()  # the producing kernels ran on the library's stream, the collective runs on torch's
-    if dist.get_backend() == "nccl":
-        dist.all_to_all_single(_as_tensor(recv.device_ptr, recv.nbytes), _as_tensor(send.device_ptr, send.nbytes))
+    if dist.get_backend(pg) == "nccl":
+        dist.all_to_all_single(_as_tensor(recv.device_ptr, recv.nbytes), _as_tensor(send.device_ptr, send.nbytes), group=pg)
         torch.cuda.synchronize()
         return
     host = torch.from_numpy(send.download().reshape(world, -1).view(np.int64))
     parts = [torch.empty_like(host) for _ in range(world)]
-    dist.all_gather(parts, host)  # gloo has no all-to-all: everybody sees everything, keeps its blocks
+    dist.all_gather(parts, host, group=pg)  # gloo has no all-to-all: everybody sees everything, keeps its blocks
     rank = dist.get_rank()
     out = np.stack([p[rank].numpy().view(np.uint64) for p in parts]).reshape(recv.shape)
     recv.upload(out)
 
 
-def all_gather_root(dist, ctx, dev_ptr, n, S, world):
+def all_gather_root(dist, ctx, dev_ptr, n, S, world, pg=None):
     """All-gather of the rank's n = S/world leaf digests (contiguous column blocks, so the gathered buffer
     is already in column order) and core.NewTree's root over them, all in device memory."""
     import torch
     assert n * world == S
-    if dist.get_backend() == "nccl":
+    if dist.get_backend(pg) == "nccl":
         full = torch.empty(S * 32, dtype=torch.uint8, device="cuda")
-        dist.all_gather_into_tensor(full, _as_tensor(dev_ptr, n * 32))
+        dist.all_gather_into_tensor(full, _as_tensor(dev_ptr, n * 32), group=pg)
         torch.cuda.synchronize()
         return ctx.merkle_root_device(full.data_ptr(), S)
     mine = torch.as_tensor(_DeviceBytes(dev_ptr, n * 32), device="cuda").cpu()
     parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
+    dist.all_gather(parts, mine, group=pg)
     full = torch.cat(parts).cuda()
     torch.cuda.synchronize()
     return ctx.merkle_root_device(full.data_ptr(), S)
@@ -615,18 +727,195 @@ def hashlib_sha(arr):
     return hashlib.sha256(memoryview(arr)).hexdigest()
 
 
+def attach_group(job, args, dist, new_nccl_group=None):
+    """Puts the job's local ranks behind a lumen_group (the exchange inside the library) and returns the text of
+    config.transport.  One process per GPU: rank 0 draws the communicator's id, the control-plane process group
+    carries it; every rank says whether it could join, and if any could not ALL fall back to the torch.distributed
+    path together."""
+    from lumenos_amd.hip import Group, LumenError
+    if dist is None:  # --single-process: this process owns every rank
+        want = {"rccl": "auto", "copy": "copy", "torch": None}[args.transport]
+        if want is None:
+            raise SystemExit("bench.py: --transport torch needs one process per GPU (drop --single-process)")
+        try:
+            job.group = Group(job.ctxs, transport=want)
+        except LumenError as e:
+            if want == "copy":
+                raise
+            job.group = Group(job.ctxs, transport="copy")
+            return f"lumen_group: {job.group.transport} (RCCL could not be set up: {e})"
+        return f"lumen_group: {job.group.transport}"
+    import torch
+    if args.transport == "torch" or args.share_gpu:
+        why = "--share-gpu: RCCL refuses two ranks on one device" if args.share_gpu else "--transport torch"
+        return f"torch.distributed {dist.get_backend()} on aliased device memory ({why})"
+    uid, err = np.zeros(128, dtype=np.uint8), ""
+    if job.rank == 0:
+        try:
+            uid = Group.unique_id()
+        except LumenError as e:
+            err = str(e)
+    box = [uid.tobytes(), err]
+    dist.broadcast_object_list(box, src=0)
+    ok = 0
+    if not box[1]:
+        try:
+            job.group = Group.join(job.ctx, job.rank, job.world, np.frombuffer(box[0], dtype=np.uint8))
+            ok = 1
+        except LumenError as e:
+            err = str(e)
+    flags = [None] * job.world
+    dist.all_gather_object(flags, (ok, err or box[1]))
+    if all(f[0] for f in flags):
+        return f"lumen_group: {job.group.transport} (the library's own communicator, ncclCommInitRank)"
+    if job.group is not None:
+        job.group.close()
+        job.group = None
+    reason = next(f[1] for f in flags if not f[0])
+    # fall back together: the collectives of torch.distributed (RCCL) on tensors aliasing the library's memory
+    job.nccl_pg = new_nccl_group() if new_nccl_group else dist.new_group(backend="nccl")
+    return f"torch.distributed nccl on aliased device memory (FALLBACK: the library's RCCL group failed: {reason})"
+
+
+def group_collectives(job):
+    """per-collective HIP-event time and rate since the last reset (lumen_group_stats)"""
+    out = {}
+    for name in ("all_to_all_1", "all_to_all_2", "all_gather", "gather_to_root"):
+        ms, sent, calls = job.group.stats(name)
+        if calls:
+            out[name] = {"calls": calls, "ms_per_call": round(ms / calls, 4), "MB_sent_per_rank_per_call": round(sent / calls / 1e6, 3),
+                         "GBps_per_rank": round(sent / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
+                         "GBps_all_ranks": round(sent * job.world / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
+    return out
+
+
+def check_against_single_rank(job_args, world, rank, local_devices, group_factory):
+    """An N-rank run at 2048x1024 (BASELINE config A) against a single-rank recompute on the same inputs: the Merkle
+    root, a sample of every local rank's encoded columns, and the first and last MatR ciphertext of its block.
+    Every process recomputes the whole job on its own first device (0.1 s at this size): rank r's input block is
+    fill_random(1 + r), whoever generates it."""
+    cfg = "2048x1024"
+    j = Job(cfg, rank, world, job_args["device"], 0, False, local_devices)
+    if not j.lane_path:
+        j.close()
+        return {"ok": None, "note": f"{world} ranks cannot run the lane path at {cfg}"}
+    group_factory(j)
+    res = {"config": cfg, "ranks": world, "path": "lumen_group" if j.group is not None else "torch.distributed"}
+    try:
+        if j.group is not None:
+            enc, lvl1, mat_r, mat_z, q, root = j.step_group(keep=True)
+        else:
+            enc, lvl1, mat_r, mat_z, q, root = j.step_lanes(group_factory.dist, keep=True)
+        ctx, own, Sw = j.ctx, j.cols // world, j.S // world
+        full = ctx.new_set(j.cols, j.L)
+        views = [full.slice(r * own, own).fill_random(1 + r) for r in range(world)]
+        want_enc = ctx.encode(full, j.zero_ct, RHO_INV)
+        want_l1 = ctx.rescale(want_enc, 2)
+        want_root = ctx.merkle_build(ctx.leaf_digests(want_l1))[1]
+        want_r = ctx.matrix_inner_sum(full, j.r_pt, j.rows)
+        res["root_equal"] = bool(root == want_root)
+        cols_ok, n_cols, mat_ok = True, 0, True
+        for i, r in enumerate(j.local_ranks):
+            for k in sorted({0, Sw // 3, Sw - 1}):
+                cols_ok &= bool(np.array_equal(enc[i].download(k, 1), want_enc.download(r * Sw + k, 1)))
+                n_cols += 1
+            for k in (0, own - 1):
+                mat_ok &= bool(np.array_equal(mat_r[i].download(k, 1), want_r.download(r * own + k, 1)))
+        res["encoded_columns_checked"], res["encoded_columns_equal"] = n_cols, cols_ok
+        res["mat_r_samples_equal"] = mat_ok
+        if q is not None:
+            res["queried_columns_equal"] = bool(np.array_equal(q.download(), ctx.gather(want_l1, j.query_idx).download()))
+        res["ok"] = bool(res["root_equal"] and cols_ok and mat_ok and res.get("queried_columns_equal", True))
+        for s_ in [q, want_r, want_l1, want_enc] + views + [full] + mat_r + mat_z + lvl1 + enc:
+            if s_ is not None:
+                s_.free()
+    finally:
+        j.close()
+    return res
+
+
+def multi_rank_report(job, args, dist, per_rank_prof, sec_per_step):
+    """What makes the first run on a real node self-diagnosing: ranks the RCCL communicator saw, every
+    collective's time and rate, per-rank stage times (each stage drained before the next) and per-rank roofline,
+    and the N-rank-against-one-rank check.  Collected on rank 0 (all_gather_object over the control plane)."""
+    mine = {"ranks": job.local_ranks}
+    if job.group is not None:
+        job.group.stats_reset()
+        timers = {}
+        job.step_group(timers=timers)
+        mine["stage_s"] = {k: round(v, 5) for k, v in timers.items()}
+        mine["collectives"] = group_collectives(job)
+        mine["rccl_ranks_seen"] = job.group.rccl_ranks
+    elif job.lane_path and dist is not None:
+        timers = {}
+        job.step_lanes(dist, timers=timers)
+        mine["stage_s"] = {k: round(v, 5) for k, v in timers.items()}
+        own, ct = job.cols // job.world, 2 * job.L * job.N * 8
+        sent = {"all_to_all_1": own * ct * (job.world - 1) / job.world, "all_to_all_2": 2 * own * ct * (job.world - 1) / job.world,
+                "all_gather": job.S // job.world * 32 * (job.world - 1)}
+        mine["collectives"] = {n: {"calls": 1, "ms_per_call": round(timers[k] * 1e3, 4),  # host wall: these calls end drained
+                                   "MB_sent_per_rank_per_call": round(b / 1e6, 3),
+                                   "GBps_per_rank": round(b / timers[k] / 1e9, 2), "GBps_all_ranks": round(b * job.world / timers[k] / 1e9, 2)}
+                               for n, k, b in (("all_to_all_1", "all_to_all_1_s", sent["all_to_all_1"]),
+                                               ("all_to_all_2", "all_to_all_2_s", sent["all_to_all_2"]),
+                                               ("all_gather", "digest_all_gather_and_root_s", sent["all_gather"]))}
+        pg = getattr(job, "nccl_pg", None)
+        mine["rccl_ranks_seen"] = dist.get_world_size(pg) if dist.get_backend(pg) == "nccl" else 0
+    if per_rank_prof:
+        mine["per_rank"] = [{"rank": r, "limb_ntts_executed": ex,
+                             "roofline": ({k: rl[k] for k in ("kernel", "frac", "achieved", "avg_launch_ms")} if rl else None),
+                             "limb_ntts_executed_per_s": round(ex / sec_per_step, 1) if ex else None}
+                            for r, (rl, _, ex) in zip(job.local_ranks, per_rank_prof)]
+    if not args.no_check and (job.group is not None or (job.lane_path and dist is not None)):
+        def factory(j):
+            if job.group is None:  # the torch.distributed path: the check job uses the same process groups
+                if hasattr(job, "nccl_pg"):
+                    j.nccl_pg = job.nccl_pg
+            elif dist is None:
+                from lumenos_amd.hip import Group
+                j.group = Group(j.ctxs, transport="copy" if job.group.transport.startswith("copy") else "rccl")
+            else:
+                from lumenos_amd.hip import Group
+                box = [Group.unique_id().tobytes() if job.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                j.group = Group.join(j.ctx, job.rank, job.world, np.frombuffer(box[0], dtype=np.uint8))
+        factory.dist = dist
+        try:
+            mine["check"] = check_against_single_rank({"device": job.ctx_device}, job.world, job.rank,
+                                                      job.local_devices, factory)
+        except Exception as e:  # a failed check must not cost the measurement
+            mine["check"] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+    parts = [mine]
+    if dist is not None:
+        parts = [None] * job.world
+        dist.all_gather_object(parts, mine)
+    out = {"rccl_ranks_seen": max((p.get("rccl_ranks_seen", 0) for p in parts), default=0)}
+    if any("collectives" in p for p in parts):  # a collective is as slow as its slowest rank
+        names = sorted({n for p in parts for n in p.get("collectives", {})})
+        out["collectives"] = {n: max((p["collectives"][n] for p in parts if n in p.get("collectives", {})),
+                                     key=lambda e: e["ms_per_call"]) for n in names}
+        out["per_rank_stage_s"] = {",".join(map(str, p["ranks"])): p.get("stage_s") for p in parts}
+    pr = [e for p in parts for e in p.get("per_rank", [])]
+    if pr:
+        out["per_rank"] = pr
+        out["limb_ntts_executed_all_ranks"] = sum(e["limb_ntts_executed"] or 0 for e in pr)
+    checks = [p["check"] for p in parts if "check" in p]
+    if checks:
+        out["check"] = dict(checks[0], ok=all(c.get("ok") for c in checks),
+                            failures=[c for c in checks if not c.get("ok")] or None)
+    return out
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` for N > 1: this process never initialises the GPU (no torch.cuda, no HIP) --
     it starts one rank per GPU under torch.distributed.run as a CHILD process (never an exec), relays the
     child's output (rank 0's JSON line) and returns its exit code (torch.distributed.run exits non-zero when
     any rank fails)."""
-    import socket
     import subprocess
-    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    # --standalone: the launcher picks its own free rendezvous port on the loopback interface (no window between
+    # "found a free port" and "bound it" for another process to slip into)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__), *argv]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:  # rank 0's JSON line goes to stdout; whatever a library chats there (gloo) to stderr
@@ -648,13 +937,21 @@ def timed_steps(job, dist, steps, warmup, barrier):
 
 
 def profile_kernels(job, dist, cfg):
-    """Dominant-kernel roofline: one more (untimed) step with HIP events around every launch on the context's
-    stream.  Returns (roofline, per-kernel table, limb transforms executed in the step)."""
-    job.ctx.prof_reset()
-    job.ctx.prof_enable(True)
+    """Dominant-kernel roofline: one more (untimed) step with HIP events around every launch on the contexts'
+    streams.  Returns (roofline, per-kernel table, limb transforms executed in the step) of the first local rank
+    and the same triple for every local rank."""
+    for c in job.ctxs:
+        c.prof_reset()
+        c.prof_enable(True)
     job.step(dist)
-    job.ctx.prof_enable(False)
-    tab = {k: job.ctx.prof_read(k) for k in job.ctx.prof_names()}
+    for c in job.ctxs:
+        c.prof_enable(False)
+    per_rank = [_kernel_table(job, c, cfg) for c in job.ctxs]
+    return per_rank[0] + (per_rank,)
+
+
+def _kernel_table(job, ctx, cfg):
+    tab = {k: ctx.prof_read(k) for k in ctx.prof_names()}
     pmc = pmc_table(cfg)
     stages = {}
     for k, (ms, launches, units) in sorted(tab.items()):
@@ -675,7 +972,7 @@ def profile_kernels(job, dist, cfg):
         pe = pmc_entry(pmc, dom)
         sq = (pe or {}).get("sq_per_launch") or {}
         bfly = units / launches * job.N / 2 * job.log_n  # butterflies of one launch
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
+        roofline = {"bound": "hbm", "limiter": "valu", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                     "traffic": round(pe["hbm_bytes_per_launch"]) if pe and pe.get("hbm_bytes_per_launch") else None,
                     "avg_launch_ms": round(ms / launches, 4), "limb_ntts_per_launch": units // launches,
@@ -685,8 +982,11 @@ def profile_kernels(job, dist, cfg):
                     "valu_frac": round(pe["valu_busy_frac"], 4) if pe and pe.get("valu_busy_frac") else None,
                     "valu_insts_per_butterfly": round(sq["SQ_INSTS_VALU"] * 64.0 / bfly, 2)
                     if sq.get("SQ_INSTS_VALU") else None,
-                    "note": "VALU-bound integer kernel: the >= 50 % HBM target of north_star is not reachable at "
-                            "10 multiply-adds per 64-bit Shoup product; see DESIGN.md section 6"}
+                    "note": "`bound` names the roofline `frac` is priced against (HBM, as SURVEY 8d prescribes for every "
+                            "kernel of this path); `limiter` is what actually limits the kernel: VALU issue of 64-bit "
+                            "modular butterflies.  The >= 50 % HBM target of north_star is not reachable at 10 "
+                            "multiply-adds per 64-bit Shoup product; DESIGN.md section 6 (and its pseudo-Mersenne "
+                            "experiment) has the costing"}
     return roofline, stages, executed
 
 
@@ -859,6 +1159,15 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal only)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1: ONE process drives all N ranks, one context per GPU behind lumen_group_create (the "
+                         "reference server's topology); with --share-gpu the N contexts share device 0")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "copy", "torch"],
+                    help="N > 1: rccl = the library's own RCCL communicator (default; falls back to torch if it cannot "
+                         "be set up); copy = stream-ordered peer copies (--single-process only); torch = "
+                         "torch.distributed collectives on tensors aliasing the library's memory (the round-3 path)")
+    ap.add_argument("--no-check", action="store_true",
+                    help="N > 1: skip the comparison of an N-rank run at 2048x1024 with a single-rank recompute")
     ap.add_argument("--allow-replicated", action="store_true",
                     help="N>1 worlds the lane-sharded path cannot serve: run the round-1 replicated-input path "
                          "instead of refusing (named in config.parallelism)")
@@ -874,10 +1183,14 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if "RANK" not in os.environ and args.gpus > 1:
+    if "RANK" not in os.environ and args.gpus > 1 and not args.single_process:
         sys.exit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_process:
+        if world != 1:
+            sys.exit("bench.py: --single-process is one process; do not start it under torch.distributed.run")
+        world = args.gpus
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import torch
@@ -886,21 +1199,33 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
+    dist, transport = None, None
+    if world > 1 and not args.single_process:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        # "nccl" is RCCL on ROCm; a rank that dies must not leave the others waiting in a collective for ever
-        dist.init_process_group(args.dist_backend, timeout=datetime.timedelta(minutes=10))
+        # control plane (the id of the library's communicator, barriers, max over ranks): gloo.  Data plane: the
+        # library's own RCCL communicator, or with --transport torch the process group itself ("nccl" is RCCL on
+        # ROCm).  A rank that dies must not leave the others waiting in a collective for ever.
+        use_torch = args.transport == "torch" or args.share_gpu
+        dist.init_process_group(args.dist_backend if use_torch else "gloo", timeout=datetime.timedelta(minutes=10))
 
-    job = Job(args.config, rank, world, local_rank, args.ring_switch_logn, args.allow_replicated)
+    local_devices = None
+    if args.single_process and world > 1:
+        if not args.share_gpu and torch.cuda.device_count() < world:
+            sys.exit(f"bench.py: --single-process --gpus {world} needs {world} visible devices (have "
+                     f"{torch.cuda.device_count()}); --share-gpu puts every rank on device 0")
+        local_devices = [0] * world if args.share_gpu else list(range(world))
+    job = Job(args.config, rank, world, local_rank, args.ring_switch_logn, args.allow_replicated, local_devices)
+    if world > 1 and job.lane_path:
+        transport = attach_group(job, args, dist)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        job.ctx.sync()
+        for c in job.ctxs:
+            c.sync()
 
     for _ in range(args.warmup):
         job.step(dist)
@@ -911,12 +1236,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sec_per_step = elapsed / args.steps
 
-    roofline, stages, executed = (None, None, None) if args.no_kernel_profile else profile_kernels(job, dist, args.config)
+    roofline, stages, executed, per_rank_prof = ((None, None, None, None) if args.no_kernel_profile
+                                                 else profile_kernels(job, dist, args.config))
+    multi = multi_rank_report(job, args, dist, per_rank_prof, sec_per_step) if world > 1 else None
     ntt_kernel = plain_ntt_rates(job) if world == 1 and not args.no_kernel_profile else None
     io = io_leg(job, args.config) if world == 1 and not args.no_io else None
     others = None
@@ -948,10 +1275,14 @@ def main():
                                        "input and repeats the mixing passes of Encode; columns sharded elsewhere; digest "
                                        "all-gather through the host"),
                        "lane_path": bool(job.lane_path),
+                       "transport": transport,
+                       "topology": (None if world == 1 else "single process, one context per rank (lumen_group_create)"
+                                    if args.single_process else "one process per GPU (torch.distributed.run)"),
                        "baseline_ref": "BASELINE.md: reference Go/Lattigo CPU, m7i.8xlarge 32 vCPU"},
             # limb transforms the device EXECUTES per step (sum of the NTT kernels' units: the rescale to level 1
             # runs on coefficients, 14 transforms per polynomial instead of the reference's 75) ...
-            "limb_ntts_executed_per_s": round(executed * world / sec_per_step, 1) if executed else None,
+            "limb_ntts_executed_per_s": round((multi or {}).get("limb_ntts_executed_all_ranks", executed * world)
+                                              / sec_per_step, 1) if executed else None,
             # ... and the reference's own transform count for the same step (SURVEY 8d census) over the same time
             "limb_ntts_reference_equiv_per_s": round(census / sec_per_step, 1),
             "ct_ntts_reference_equiv_per_s": round(census / sec_per_step / (2 * job.L), 1),
@@ -959,6 +1290,8 @@ def main():
             "ntt_kernel": ntt_kernel,
             "kernels": stages,
         }
+        if multi:
+            out.update(multi)
         if io:
             out.update(io)
         if others:

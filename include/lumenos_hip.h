@@ -373,7 +373,8 @@ int lumen_group_digests(lumen_group *g, uint8_t *digests, size_t cap, uint32_t *
  * on a process that does not hold rank 0, *out = NULL. */
 int lumen_group_gather(lumen_group *g, const lumen_set *const *src, const uint32_t *idx, uint32_t n,
                        lumen_set **out);
-/* HIP-event time of the collectives since the last reset: name = "all_to_all", "all_gather", "gather_to_root";
+/* HIP-event time of the collectives since the last reset: name = "all_to_all" (lumen_group_all_to_all),
+ * "all_to_all_1" / "all_to_all_2" (the two exchanges inside lumen_group_encode), "all_gather", "gather_to_root";
  * ms = sum over calls of the slowest local rank's time on its stream (it includes waiting for the peers to
  * arrive), bytes = what ONE rank sent to other ranks, summed over calls. */
 int lumen_group_stats(lumen_group *g, const char *name, double *ms, uint64_t *bytes, uint64_t *calls);

@@ -115,6 +115,7 @@ struct lumen_group {
     };
     std::vector<pending> pend;
     std::map<std::string, stat_entry> stats;
+    std::map<std::pair<std::string, uint64_t>, double> call_ms; // calls partly resolved (see stats_resolve)
     uint64_t call_seq = 0;
 };
 
@@ -150,7 +151,9 @@ int use(lumen_group *g, uint32_t i) {
 }
 
 // timing bracket of one collective on local rank i's stream
+void stats_resolve(lumen_group *g, bool only_done);
 void time_begin(lumen_group *g, const char *name, uint32_t i, uint64_t bytes) {
+    if (g->pend.size() > 512) stats_resolve(g, true); // a long run that never reads its statistics
     lumen_group::pending p;
     p.name = name, p.call = g->call_seq, p.local = i, p.bytes = bytes;
     p.a = lm_ev_get(g->ctx[i]);
@@ -167,12 +170,19 @@ void time_end(lumen_group *g, uint32_t i) {
         }
 }
 
-void stats_resolve(lumen_group *g) {
-    // per call: the slowest local rank's time; bytes as sent by one rank
+// folds finished measurements into the statistics: per call the slowest local rank's time, bytes as sent by one
+// rank.  only_done: leave what is still running on the device for later (no host block)
+void stats_resolve(lumen_group *g, bool only_done = false) {
+    std::vector<lumen_group::pending> later;
     std::map<std::pair<std::string, uint64_t>, std::pair<double, uint64_t>> per_call;
     for (auto &p : g->pend) {
         float ms = 0;
         (void)hipSetDevice(g->ctx[p.local]->device);
+        if (only_done && (!p.b || hipEventQuery(p.b) != hipSuccess)) {
+            (void)hipGetLastError();
+            later.push_back(p);
+            continue;
+        }
         if (p.b && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             auto &e = per_call[{p.name, p.call}];
             e.first = std::max(e.first, (double)ms);
@@ -183,11 +193,20 @@ void stats_resolve(lumen_group *g) {
         g->ctx[p.local]->ev_pool.push_back(p.a);
         if (p.b) g->ctx[p.local]->ev_pool.push_back(p.b);
     }
-    g->pend.clear();
+    g->pend.swap(later);
+    // a call's local ranks may resolve in different rounds: the call counts once, its time is the maximum seen
     for (auto &kv : per_call) {
         auto &s = g->stats[kv.first.first];
-        s.ms += kv.second.first, s.bytes += kv.second.second, s.calls += 1;
+        auto seen = g->call_ms.find(kv.first);
+        if (seen == g->call_ms.end()) {
+            s.ms += kv.second.first, s.bytes += kv.second.second, s.calls += 1;
+            g->call_ms[kv.first] = kv.second.first;
+        } else if (kv.second.first > seen->second) {
+            s.ms += kv.second.first - seen->second;
+            seen->second = kv.second.first;
+        }
     }
+    if (g->pend.empty()) g->call_ms.clear();
 }
 
 // "everything enqueued so far on every local rank" -> ev_ready; then dst's stream waits for all of them
@@ -375,14 +394,15 @@ extern "C" int lumen_group_sync(lumen_group *g) {
 }
 
 // ---- all-to-all on contiguous blocks.  send_ptr[i] / recv_ptr[i]: base of local rank i's W blocks of blk bytes.
-static int all_to_all_raw(lumen_group *g, const std::vector<const u64 *> &send, const std::vector<u64 *> &recv, size_t blk_words) {
+static int all_to_all_raw(lumen_group *g, const std::vector<const u64 *> &send, const std::vector<u64 *> &recv, size_t blk_words,
+                          const char *stat_name) {
     const uint32_t n = (uint32_t)g->ctx.size(), W = g->W;
     g->call_seq++;
     const uint64_t sent = (uint64_t)blk_words * 8 * (W - 1);
     if (g->transport == LUMEN_TRANSPORT_RCCL) {
         for (uint32_t i = 0; i < n; i++) {
             if (use(g, i)) return 1;
-            time_begin(g, "all_to_all", i, sent);
+            time_begin(g, stat_name, i, sent);
         }
         G_NCCL(g, g->rccl->GroupStart());
         for (uint32_t i = 0; i < n; i++) {
@@ -402,7 +422,7 @@ static int all_to_all_raw(lumen_group *g, const std::vector<const u64 *> &send, 
     // copy transport: every rank is local (n == W, local index == rank)
     for (uint32_t i = 0; i < n; i++) {
         if (use(g, i)) return 1;
-        time_begin(g, "all_to_all", i, sent);
+        time_begin(g, stat_name, i, sent);
     }
     if (ready_all(g)) return 1;
     std::vector<uint32_t> all;
@@ -423,8 +443,7 @@ static int all_to_all_raw(lumen_group *g, const std::vector<const u64 *> &send, 
     return 0;
 }
 
-extern "C" int lumen_group_all_to_all(lumen_group *g, const lumen_set *const *send, lumen_set *const *recv) {
-    LM_CHECK(nullptr, g && send && recv, "lumen_group_all_to_all: NULL argument");
+static int all_to_all_sets(lumen_group *g, const lumen_set *const *send, lumen_set *const *recv, const char *stat_name) {
     group_lock lk(g);
     const uint32_t n = (uint32_t)g->ctx.size(), W = g->W;
     std::vector<const u64 *> sp;
@@ -440,7 +459,12 @@ extern "C" int lumen_group_all_to_all(lumen_group *g, const lumen_set *const *se
         sp.push_back(send[i]->d), rp.push_back(recv[i]->d);
     }
     if (!send[0]->words) return 0;
-    return all_to_all_raw(g, sp, rp, send[0]->words / W);
+    return all_to_all_raw(g, sp, rp, send[0]->words / W, stat_name);
+}
+
+extern "C" int lumen_group_all_to_all(lumen_group *g, const lumen_set *const *send, lumen_set *const *recv) {
+    LM_CHECK(nullptr, g && send && recv, "lumen_group_all_to_all: NULL argument");
+    return all_to_all_sets(g, send, recv, "all_to_all");
 }
 
 // ---- fhe.Encode over column-sharded input (include/lumenos_hip.h)
@@ -502,7 +526,7 @@ extern "C" int lumen_group_encode(lumen_group *g, const lumen_set *const *matrix
         bin.keep(g->ctx[i], lanes);
         a[i] = blk, b[i] = lanes;
     }
-    if (lumen_group_all_to_all(g, a.data(), b.data())) return 1;
+    if (all_to_all_sets(g, a.data(), b.data(), "all_to_all_1")) return 1;
     // Encode on the lane shard, then block h of every shard -> rank h
     for (uint32_t i = 0; i < n; i++) {
         lumen_set *enc = nullptr, *recv = nullptr;
@@ -512,7 +536,7 @@ extern "C" int lumen_group_encode(lumen_group *g, const lumen_set *const *matrix
         bin.keep(g->ctx[i], recv);
         a[i] = enc, b[i] = recv;
     }
-    if (lumen_group_all_to_all(g, a.data(), b.data())) return 1;
+    if (all_to_all_sets(g, a.data(), b.data(), "all_to_all_2")) return 1;
     std::vector<lumen_set *> mine(n, nullptr);
     for (uint32_t i = 0; i < n; i++) {
         if (use(g, i) || lumen_lanes_assemble(g->ctx[i], b[i], &mine[i])) {

@@ -361,7 +361,7 @@ int main(int argc, char **argv) {
         size_t at = 0;
         while (at < wire.size() && gwire.data()[at] == wire.data()[at]) at++;
         REQUIRE(at == wire.size(), "group proof differs from the one-GPU proof at byte %zu", at);
-        for (const char *name : {"all_to_all", "all_gather", "gather_to_root"}) {
+        for (const char *name : {"all_to_all_1", "all_to_all_2", "all_gather", "gather_to_root"}) {
             double ms = 0;
             uint64_t bytes = 0, calls = 0;
             REQUIRE(!lumen_group_stats(group.Handle(), name, &ms, &bytes, &calls), "lumen_group_stats");

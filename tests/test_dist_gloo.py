@@ -171,6 +171,71 @@ def test_lane_sharded_exchange_world8():
     _run_lane_world(8)
 
 
+def _attach_worker(rank, world, port, fail_rank, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    import bench
+    import lumenos_amd.hip as hip
+
+    class FakeGroup:  # the library's group as attach_group uses it; joining fails on one rank if asked to
+        transport = "rccl"
+        closed = False
+
+        @staticmethod
+        def unique_id():
+            return np.arange(128, dtype=np.uint8)
+
+        @classmethod
+        def join(cls, ctx, r, w, uid):
+            assert np.array_equal(uid, np.arange(128, dtype=np.uint8)), "the id rank 0 drew reaches every rank"
+            if r == fail_rank:
+                raise hip.LumenError(f"ncclCommInitRank failed on rank {r}")
+            return cls()
+
+        def close(self):
+            FakeGroup.closed = True
+
+    hip.Group = FakeGroup
+
+    class J:
+        pass
+
+    job = J()
+    job.rank, job.world, job.ctx, job.group = rank, world, None, None
+    args = argparse.Namespace(transport="rccl", share_gpu=False)
+    text = bench.attach_group(job, args, dist, new_nccl_group=lambda: "nccl-subgroup")
+    out.put((rank, text, job.group is not None, getattr(job, "nccl_pg", None), FakeGroup.closed))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_ranks_agree_on_the_transport(fail_rank):
+    """bench.attach_group under gloo, world 2: the id of the library's RCCL communicator travels from rank 0 over the
+    control plane; when every rank joins, all run the in-library path; when ONE rank cannot, ALL fall back to the
+    torch.distributed path together (a rank left alone in the other path would wait in a collective for ever) and
+    config.transport says why."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_attach_worker, args=(r, world, port, fail_rank, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, text, has_group, pg, closed in res:
+        if fail_rank < 0:
+            assert text.startswith("lumen_group: rccl") and has_group and pg is None
+        else:
+            assert "FALLBACK" in text and "ncclCommInitRank failed on rank 1" in text
+            assert not has_group and pg == "nccl-subgroup"
+            assert closed == (rank != fail_rank)  # the rank that had joined gave its group back
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` as typed: the parent starts one rank per GPU under torch.distributed.run as a
     child process, relays its output and exits with its code.  Without a GPU here every rank stops at "needs a

@@ -1054,6 +1054,7 @@ def io_leg(job, cfg):
     fused = min([job.step_io_fused() for _ in range(2)], key=lambda r: r["total_s"])
     assert hashlib_sha(job.wire) == want, "the fused order produced different proof bytes"
     gb_in = job.cols * 2 * job.L * job.N * 8 / 1e9
+    stage = stage_seconds(job)
     return {"marshal_s": round(marshal_s, 4), "unmarshal_s": round(unmarshal_s, 4),
           # client side of the wire, for a client that owns a GPU: unmarshal_s above + this = "Decrypt proof"
           "decrypt_proof_s": round(decrypt_s, 4),
@@ -1062,7 +1063,8 @@ def io_leg(job, cfg):
           # what precedes the metric in the reference's server (cmd/server/main.go:188-208, "Encrypt matrix":
           # 66.84 s at 16384x4096): the raw witness columns from host memory, Encoder.Encode + EncryptNew on the device
           "encrypt_matrix_s": round(enc_s, 4),
-          "io": {"upload_s": round(best["upload_s"], 4), "marshal_tail_s": round(best["marshal_tail_s"], 4),
+          "io": {"stage_s": stage,
+                 "upload_s": round(best["upload_s"], 4), "marshal_tail_s": round(best["marshal_tail_s"], 4),
                  "upload_GB": round(gb_in, 2), "upload_GBps": round(gb_in / best["upload_s"], 1),
                  "proof_wire_GB": round(job.wire_len / 1e9, 3),
                  "marshal_GBps": round(job.wire_len / 1e9 / marshal_s, 1),
@@ -1078,6 +1080,42 @@ def io_leg(job, cfg):
                          "the order a server that owns the whole request can use -- Prove's challenges do not depend "
                          "on the Merkle root (ligero.go:198-199), so the inner products of a column slice start when "
                          "it lands and Encode runs once the last one has: the upload hides behind compute"}}
+
+
+def stage_seconds(job):
+    """SURVEY K11, measured: what the Go shim's stage() costs at this shape.  Lattigo holds one separately allocated
+    []uint64 per limb (ct.Value[k].Coeffs[i]): cols x 2 x L arrays of N words (98 304 arrays of 128 KB at 16384 x
+    4096) that cgo cannot hand over as they are.  They are gathered into the flat page-locked buffer
+    lumen_set_upload takes (lumen_host_gather: the shim pins the limbs and passes their addresses) with 1 host
+    thread -- a single goroutine's copy() loop, INTEGRATION.md's stage() -- and with 16.  NOT part of
+    io_inclusive_s / io_inclusive_fused_order_s, which start from the flat buffer: either add it, or build the
+    ciphertexts over one lumen_host_alloc block (`newAliasedCiphertexts`), which makes the
+    copy disappear."""
+    from lumenos_amd.hip import host_gather
+    n = job.cols * 2 * job.L
+    limbs = []
+    for _ in range(n):  # separately allocated, pages touched (a first-touch fault is not part of a copy)
+        a = np.empty(job.N, dtype=np.uint64)
+        a.fill(7)
+        limbs.append(a)
+    flat = job.h_matrix.reshape(-1)
+    keep = flat[:8].copy()
+    out = {"limb_arrays": n, "KB_each": job.N * 8 // 1024, "GB": round(n * job.N * 8 / 1e9, 2),
+           "included_in_io_inclusive": False}
+    for threads in (1, 16):
+        host_gather(flat, limbs, threads)  # warm
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            host_gather(flat, limbs, threads)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out[f"threads_{threads}_s"] = round(best, 4)
+        out[f"threads_{threads}_GBps"] = round(n * job.N * 8 / best / 1e9, 1)
+    assert flat[0] == 7 and keep is not None
+    del limbs
+    job.matrix.download_into(job.h_matrix)  # the staging buffer holds the synthetic matrix again
+    return out
 
 
 def plain_prover_seconds(rows, cols, device):

@@ -105,6 +105,14 @@ void *lumen_set_device_ptr(const lumen_set *set);
  * context.  Both calls return when the host buffer may be reused / holds the data. */
 void *lumen_host_alloc(size_t bytes);
 void lumen_host_free(void *p);
+/* The staging copy itself, for a host that cannot avoid it: `limbs` = n separately allocated arrays of `words`
+ * u64 each (Lattigo: ct.Value[k].Coeffs[i], pinned with runtime.Pinner and listed in a C array, in the order
+ * [ct][poly][limb]); ONE call gathers them into the flat buffer (scatter: the way back) on `threads` host
+ * threads (0: min(16, cores)) -- a single goroutine's copy() loop moves ~10 GB/s, the PCIe link ~55.
+ * INTEGRATION.md section 2 shows how to make the copy disappear instead (limb slices that alias one
+ * lumen_host_alloc block). */
+int lumen_host_gather(uint64_t *dst, const uint64_t *const *limbs, size_t n, size_t words, uint32_t threads);
+int lumen_host_scatter(const uint64_t *src, uint64_t *const *limbs, size_t n, size_t words, uint32_t threads);
 int lumen_set_upload(lumen_ctx *ctx, lumen_set *set, uint32_t first, uint32_t n,
                      const uint64_t *host);
 int lumen_set_download(lumen_ctx *ctx, const lumen_set *set, uint32_t first, uint32_t n,

@@ -470,6 +470,42 @@ extern "C" void lumen_host_free(void *p) {
     if (p) hipHostFree(p);
 }
 
+// Lattigo keeps ONE Go slice per limb (ct.Value[k].Coeffs[i]), 98 304 separately allocated 128 KB
+// arrays for the input matrix of the headline configuration.  The shim pins them (runtime.Pinner), writes their
+// addresses into a C array and makes ONE call: the gather into the flat page-locked buffer that
+// lumen_set_upload hands to the DMA engine runs on `threads` host threads (one core moves ~10 GB/s, the PCIe
+// link ~55).  _scatter is the way back for lumen_set_download's buffer.
+static int host_limbs_move(uint64_t *flat, uint64_t *const *limbs, size_t n, size_t words, uint32_t threads, bool gather) {
+    if (!n || !words) return 0;
+    const size_t bytes = words * sizeof(uint64_t);
+    size_t nthr = threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    nthr = std::min(nthr, n);
+    auto work = [=](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            if (gather) memcpy(flat + i * words, limbs[i], bytes);
+            else memcpy(limbs[i], flat + i * words, bytes);
+        }
+    };
+    if (nthr == 1) {
+        work(0, n);
+        return 0;
+    }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nthr; t++) th.emplace_back(work, n * t / nthr, n * (t + 1) / nthr);
+    for (auto &x : th) x.join();
+    return 0;
+}
+extern "C" int lumen_host_gather(uint64_t *dst, const uint64_t *const *limbs, size_t n, size_t words, uint32_t threads) {
+    LM_CHECK(nullptr, (dst && limbs) || !n, "lumen_host_gather: NULL argument");
+    for (size_t i = 0; i < n; i++) LM_CHECK(nullptr, limbs[i], "lumen_host_gather: limb %zu is NULL", i);
+    return host_limbs_move(dst, const_cast<uint64_t *const *>(limbs), n, words, threads, true);
+}
+extern "C" int lumen_host_scatter(const uint64_t *src, uint64_t *const *limbs, size_t n, size_t words, uint32_t threads) {
+    LM_CHECK(nullptr, (src && limbs) || !n, "lumen_host_scatter: NULL argument");
+    for (size_t i = 0; i < n; i++) LM_CHECK(nullptr, limbs[i], "lumen_host_scatter: limb %zu is NULL", i);
+    return host_limbs_move(const_cast<uint64_t *>(src), limbs, n, words, threads, false);
+}
+
 bool lm_host_is_pinned(const void *p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {

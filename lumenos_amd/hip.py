@@ -44,6 +44,8 @@ SYMBOLS = {
     "lumen_ctx_clone": (C.c_int, [_vp, _vpp]),
     "lumen_host_alloc": (_vp, [C.c_size_t]),
     "lumen_host_free": (None, [_vp]),
+    "lumen_host_gather": (C.c_int, [_u64p, _vpp, C.c_size_t, C.c_size_t, C.c_uint32]),
+    "lumen_host_scatter": (C.c_int, [_u64p, _vpp, C.c_size_t, C.c_size_t, C.c_uint32]),
     "lumen_last_error": (C.c_char_p, [_vp]),
     "lumen_ctx_trim": (C.c_int, [_vp]),
     "lumen_ctx_wait": (C.c_int, [_vp, _vp]),
@@ -163,6 +165,26 @@ def pinned_empty(shape):
     arr = np.frombuffer(buf, dtype=np.uint64, count=n).reshape(shape)
     _pinned_keep[arr.ctypes.data] = p
     return arr
+
+
+def host_gather(dst, limbs, threads=0):
+    """lumen_host_gather: `limbs` (a list of separately allocated uint64 arrays of equal length) -> the flat array
+    `dst`, on `threads` host threads"""
+    lib = load()
+    n, words = len(limbs), limbs[0].size
+    assert dst.dtype == np.uint64 and dst.flags["C_CONTIGUOUS"] and dst.size == n * words
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in limbs])
+    if lib.lumen_host_gather(_p64(dst.reshape(-1)), ptrs, n, words, threads):
+        raise LumenError(lib.lumen_last_error(None).decode())
+
+
+def host_scatter(src, limbs, threads=0):
+    lib = load()
+    n, words = len(limbs), limbs[0].size
+    assert src.dtype == np.uint64 and src.flags["C_CONTIGUOUS"] and src.size == n * words
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in limbs])
+    if lib.lumen_host_scatter(_p64(src.reshape(-1)), ptrs, n, words, threads):
+        raise LumenError(lib.lumen_last_error(None).decode())
 
 
 def pinned_free(arr):

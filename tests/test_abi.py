@@ -142,3 +142,26 @@ def test_environment_is_read_once_at_context_creation():
     body = body[:body.index("\n}\n")]
     assert "getenv(" in body
     assert src.count("tuning_from_env(") == 2  # the definition and the call in lumen_ctx_create
+
+
+def test_host_gather_scatter_round_trip():
+    """lumen_host_gather / _scatter (one separately allocated array per limb, as Lattigo holds them):
+    host-only entry points, any thread count, NULL limbs refused."""
+    import ctypes as C
+    import numpy as np
+    from lumenos_amd import hip
+    rng = np.random.default_rng(4)
+    limbs = [rng.integers(0, 2**63, size=257, dtype=np.uint64) for _ in range(37)]
+    want = np.concatenate(limbs)
+    for threads in (0, 1, 3, 64):
+        flat = np.zeros(37 * 257, dtype=np.uint64)
+        hip.host_gather(flat, limbs, threads)
+        assert np.array_equal(flat, want), threads
+        back = [np.zeros(257, dtype=np.uint64) for _ in range(37)]
+        hip.host_scatter(flat, back, threads)
+        assert all(np.array_equal(a, b) for a, b in zip(limbs, back)), threads
+    lib = hip.load()
+    ptrs = (C.c_void_p * 2)(limbs[0].ctypes.data, None)
+    flat = np.zeros(2 * 257, dtype=np.uint64)
+    assert lib.lumen_host_gather(flat.ctypes.data_as(C.POINTER(C.c_uint64)), ptrs, 2, 257, 1) != 0
+    assert b"limb 1 is NULL" in lib.lumen_last_error(None)

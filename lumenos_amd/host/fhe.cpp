@@ -8,6 +8,7 @@
 #include <cstring>
 #include <set>
 #include <stdexcept>
+#include <thread>
 
 #include <sys/random.h>
 
@@ -631,18 +632,54 @@ EncryptedProof LigeroProver::Prove(core::Element point, ServerBFV &backend, core
     }
     Plaintext bPt = backend.Encode(b);
 
-    // the reference runs R and Z concurrently on two evaluator copies (ligero.go:231-242); one
-    // device context serialises them on its stream
-    core::Span *spanR = core::Span::StartSpan("InnerProduct(Matrix, r)", ctx);
-    Ciphertexts matR = matrixInnerSumEval(*Matrix, rPt, rows, backend);
-    backend.check(lumen_sync(backend.Context()), "lumen_sync");
-    spanR->End();
-    delete spanR;
-    core::Span *spanZ = core::Span::StartSpan("InnerProduct(Matrix, b)", ctx);
-    Ciphertexts matZ = matrixInnerSumEval(*Matrix, bPt, rows, backend);
-    backend.check(lumen_sync(backend.Context()), "lumen_sync");
-    spanZ->End();
-    delete spanZ;
+    if (!Matrix) throw std::invalid_argument("Prove: this prover was committed on a ServerGroup; prove on that group");
+    Ciphertexts matR, matZ;
+    if (ConcurrentRZ) {
+        // ligero.go:231-242 as written: two goroutines, each on its own CopyNew (here: the server itself and one
+        // copy -- a lumen_ctx_clone with its own streams); both spans cover the overlapped evaluation
+        std::unique_ptr<ServerBFV> copy = backend.CopyNew();
+        core::Span *spanR = core::Span::StartSpan("InnerProduct(Matrix, r)", ctx);
+        core::Span *spanZ = core::Span::StartSpan("InnerProduct(Matrix, b)", ctx);
+        std::exception_ptr errZ;
+        lumen_set *zset = nullptr;
+        MetaData zmeta;
+        std::thread tz([&] {
+            try {
+                Ciphertexts z = matrixInnerSumEval(*Matrix, bPt, rows, *copy);
+                copy->check(lumen_sync(copy->Context()), "lumen_sync");
+                zmeta = z.Meta;
+                zset = z.Release(); // the set outlives the copy: from here on it is the server's to destroy
+            } catch (...) {
+                errZ = std::current_exception();
+            }
+        });
+        try {
+            matR = matrixInnerSumEval(*Matrix, rPt, rows, backend);
+            backend.check(lumen_sync(backend.Context()), "lumen_sync");
+        } catch (...) {
+            tz.join();
+            throw;
+        }
+        spanR->End();
+        delete spanR;
+        tz.join();
+        if (errZ) std::rethrow_exception(errZ);
+        matZ = Ciphertexts(backend.Context(), zset, zmeta);
+        spanZ->End();
+        delete spanZ;
+    } else {
+        // one device context runs them back to back on its stream
+        core::Span *spanR = core::Span::StartSpan("InnerProduct(Matrix, r)", ctx);
+        matR = matrixInnerSumEval(*Matrix, rPt, rows, backend);
+        backend.check(lumen_sync(backend.Context()), "lumen_sync");
+        spanR->End();
+        delete spanR;
+        core::Span *spanZ = core::Span::StartSpan("InnerProduct(Matrix, b)", ctx);
+        matZ = matrixInnerSumEval(*Matrix, bPt, rows, backend);
+        backend.check(lumen_sync(backend.Context()), "lumen_sync");
+        spanZ->End();
+        delete spanZ;
+    }
 
     transcript.AppendField("point", point);
 

@@ -81,6 +81,12 @@ class Ciphertexts {
     int Len() const;
     int Level() const;
     lumen_set *Handle() const { return set_; }
+    // gives the set up without destroying it (the caller re-wraps it, e.g. under another context of the same GPU)
+    lumen_set *Release() {
+        lumen_set *s = set_;
+        set_ = nullptr, ctx_ = nullptr;
+        return s;
+    }
     lumen_ctx *Context() const { return ctx_; }
     MetaData Meta;
     uint64_t Scale() const { return Meta.Scale; }
@@ -291,6 +297,12 @@ struct LigeroProver { // fhe/ligero.go:32-37
     // the first one touched): tests/cpp/test_ligero_host.cpp proves twice.
     ShardedCiphertexts EncodedLevel1;
     core::MerkleTree Tree;
+    // ligero.go:231-242 evaluates the R and Z inner products CONCURRENTLY, each goroutine on its own
+    // backend.CopyNew(); set this to do the same (two host threads, the server and a CopyNew of it: two streams on
+    // the one GPU) -- the spans then overlap as the reference's do.  Default: one after the other on the server's
+    // own context, which is what the span times of DESIGN.md section 6 are and, on one GPU, 4 % faster (two transform
+    // kernels side by side evict each other's L2 sets).  The proof's bytes are the same either way.
+    bool ConcurrentRZ = false;
     // ligero.go:194-291
     EncryptedProof Prove(core::Element point, ServerBFV &backend, core::Transcript &transcript, core::Span *ctx);
     // the same over the ranks of a group: inner products on every rank's own columns, the queried columns

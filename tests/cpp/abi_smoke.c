@@ -2,8 +2,8 @@
  * from explicit moduli, runs NTT -> INTT on random ciphertexts and checks the round trip, exercises
  * the error convention (non-zero status + lumen_last_error), then the proof's way out and back in as a
  * shim would drive it: a serialisation format, the wire image of a slice into page-locked memory on a
- * clone context behind lumen_ctx_wait, lumen_ct_deserialize of those bytes, a gather.  Built and run by
- * tests/test_abi.py. */
+ * clone context behind lumen_ctx_wait, lumen_ct_deserialize of those bytes, a gather; and two ranks behind a
+ * lumen_group (all-to-all, digest all-gather, device Merkle root, group gather).  Built and run by tests/test_abi.py. */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -104,6 +104,66 @@ int main(void) {
         lumen_ctx_destroy(twin);
         lumen_host_free(wire);
         lumen_leaf_format_set(ctx, NULL, 0, NULL, 0, NULL, 0);
+    }
+
+    /* several ranks behind one process, as a cgo host would drive them: two contexts on this GPU (the context and
+     * its clone), a group with the copy transport, the all-to-all on two sets per rank, the leaf digests of both ranks
+     * all-gathered and the Merkle root built on the device, the queried ciphertexts collected on rank 0 */
+    {
+        lumen_ctx *twin = NULL;
+        lumen_group *g = NULL;
+        lumen_ctx *ranks[2];
+        lumen_set *send[2] = {NULL, NULL}, *recv[2] = {NULL, NULL}, *q = NULL;
+        const lumen_set *csend[2];
+        uint8_t dig[4 * 32], dig0[2 * 32], dig1[2 * 32], root[32], nodes[16 * 32], want[32];
+        size_t n_nodes = 0;
+        uint32_t n_leaves = 0;
+        const uint32_t qidx[3] = {3, 0, 3};
+        double ms = 0;
+        uint64_t bytes = 0, calls = 0;
+        rc = lumen_ctx_clone(ctx, &twin);
+        ranks[0] = ctx, ranks[1] = twin;
+        rc = rc || lumen_group_create(ranks, 1, LUMEN_TRANSPORT_COPY, &g);
+        if (rc) return fprintf(stderr, "group: %s\n", lumen_last_error(NULL)), 17;
+        if (lumen_group_world(g) != 2 || lumen_group_local(g) != 2 || strcmp(lumen_group_transport(g), "copy") ||
+            lumen_group_rccl_ranks(g) != 0)
+            return fprintf(stderr, "group properties\n"), 18;
+        /* rank 0 sends (a[0], a[1]), rank 1 sends (a[1], a[2]): block p of a rank's set goes to rank p, so rank 0
+         * receives (a[0], a[1]) and rank 1 (a[1], a[2]) */
+        for (int r = 0; r < 2 && !rc; r++) {
+            rc = lumen_set_create(ranks[r], 2, 1, &send[r]) || lumen_set_create(ranks[r], 2, 1, &recv[r]) ||
+                 lumen_set_upload(ranks[r], send[r], 0, 2, a + (size_t)(r ? 1 : 0) * 2 * n);
+        }
+        csend[0] = send[0], csend[1] = send[1];
+        rc = rc || lumen_group_all_to_all(g, csend, recv) || lumen_group_sync(g);
+        rc = rc || lumen_set_download(ranks[0], recv[0], 0, 2, b);
+        if (rc || memcmp(b, a, (size_t)2 * n * 8) || memcmp(b + (size_t)2 * n, a + (size_t)2 * n, (size_t)2 * n * 8))
+            return fprintf(stderr, "all-to-all, rank 0: %s\n", lumen_last_error(NULL)), 19;
+        rc = lumen_set_download(ranks[1], recv[1], 0, 2, b);
+        if (rc || memcmp(b, a + (size_t)2 * n, (size_t)2 * n * 8) || memcmp(b + (size_t)2 * n, a + (size_t)4 * n, (size_t)2 * n * 8))
+            return fprintf(stderr, "all-to-all, rank 1: %s\n", lumen_last_error(NULL)), 20;
+        /* digests of both ranks' received sets, gathered in rank order; the root against the host tree */
+        rc = lumen_leaf_digests(ranks[0], recv[0], dig0) || lumen_leaf_digests(ranks[1], recv[1], dig1);
+        rc = rc || lumen_leaf_digests_begin(ranks[0], recv[0]) || lumen_leaf_digests_begin(ranks[1], recv[1]);
+        rc = rc || lumen_group_all_gather_digests(g) || lumen_group_digests(g, dig, sizeof dig, &n_leaves) ||
+             lumen_group_merkle_root(g, root);
+        if (rc || n_leaves != 4 || memcmp(dig, dig0, 64) || memcmp(dig + 64, dig1, 64))
+            return fprintf(stderr, "all-gather of the digests: %s\n", lumen_last_error(NULL)), 21;
+        rc = lumen_merkle_build(ctx, dig, 4, nodes, sizeof nodes / 32, &n_nodes, want);
+        if (rc || memcmp(root, want, 32)) return fprintf(stderr, "device root differs from the host tree\n"), 22;
+        /* the query loop over the two blocks: column 3 = rank 1's second, column 0 = rank 0's first */
+        csend[0] = recv[0], csend[1] = recv[1];
+        rc = lumen_group_gather(g, csend, qidx, 3, &q) || lumen_set_download(ctx, q, 0, 3, b);
+        if (rc || memcmp(b, a + (size_t)4 * n, (size_t)2 * n * 8) || memcmp(b + (size_t)2 * n, a, (size_t)2 * n * 8) ||
+            memcmp(b + (size_t)4 * n, a + (size_t)4 * n, (size_t)2 * n * 8))
+            return fprintf(stderr, "group gather: %s\n", lumen_last_error(NULL)), 23;
+        rc = lumen_group_stats(g, "all_to_all", &ms, &bytes, &calls);
+        if (rc || calls != 1 || bytes != (uint64_t)2 * n * 8) return fprintf(stderr, "group stats\n"), 24;
+        lumen_set_destroy(ctx, q);
+        for (int r = 0; r < 2; r++) lumen_set_destroy(ranks[r], send[r]), lumen_set_destroy(ranks[r], recv[r]);
+        lumen_group_destroy(g);
+        if (lumen_ctx_trim(twin)) return fprintf(stderr, "trim\n"), 25;
+        lumen_ctx_destroy(twin);
     }
 
     lumen_set_destroy(ctx, s);

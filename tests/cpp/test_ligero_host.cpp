@@ -173,6 +173,13 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> marshaled2 = proof2.MarshalBinary();
         core::Span::quiet = false;
         REQUIRE(marshaled2 == marshaled, "a second Prove on the same prover gives other proof bytes");
+        // ... and a third with the R and Z inner products on two host threads and two contexts, as the reference's
+        // goroutines run them (ligero.go:231-242)
+        comm.ConcurrentRZ = true;
+        core::Transcript third("test");
+        fhe::EncryptedProof proof3 = comm.Prove(z, server, third, nullptr);
+        comm.ConcurrentRZ = false;
+        REQUIRE(proof3.MarshalBinary() == marshaled, "Prove with concurrent R / Z gives other proof bytes");
         // ... and MarshalBinary frames every slice with ITS OWN MetaData and level, whatever serialisation format
         // the context was left with (here: the plain prover's empty one)
         const uint8_t none = 0;

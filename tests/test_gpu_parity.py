@@ -911,6 +911,22 @@ def test_error_paths_report_status_and_message(oracle, small):
     fails(lambda: fresh.load_ringswitch_key(P.logN + 1, key), "not supported")
     key[0, 0, 0, 0, 0] = 2**63
     fails(lambda: fresh.load_ringswitch_key(8, key), "out of range")
+    # round 4: the key's length crosses the ABI -- an older (1+K)-limb layout or a truncated block is refused
+    # before a word of it is read
+    u64p = C.POINTER(C.c_uint64)
+    short = np.zeros(key.size // 2 + 3, dtype=np.uint64)
+    fails(lambda: fresh._ck(fresh.lib.lumen_load_ringswitch_key(fresh.h, 8, 13, short.ctypes.data_as(u64p), short.size)),
+          "ring-switch key of")
+    # ... lumen_ctx_trim hands pooled storage and scratch back but not under a leaf job, and the context works on
+    gone = fresh.new_set(4, 2).fill_random(9)
+    want = fresh.leaf_digests(gone)
+    fresh.leaf_digests_begin(gone)
+    fails(fresh.trim, "in flight")
+    assert np.array_equal(fresh.leaf_digests_end(), want)
+    gone.free()
+    fresh.trim()
+    again = fresh.new_set(4, 2).fill_random(9)
+    assert np.array_equal(fresh.leaf_digests(again), want)
     fresh.wait_for(fresh)  # waiting for oneself is a no-op, not a deadlock
     fresh.close()
 

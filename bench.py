@@ -746,7 +746,7 @@ def attach_group(job, args, dist, new_nccl_group=None):
             return f"lumen_group: {job.group.transport} (RCCL could not be set up: {e})"
         return f"lumen_group: {job.group.transport}"
     import torch
-    if args.transport == "torch" or args.share_gpu:
+    if args.transport == "torch":
         why = "--share-gpu: RCCL refuses two ranks on one device" if args.share_gpu else "--transport torch"
         return f"torch.distributed {dist.get_backend()} on aliased device memory ({why})"
     uid, err = np.zeros(128, dtype=np.uint8), ""
@@ -773,8 +773,10 @@ def attach_group(job, args, dist, new_nccl_group=None):
         job.group = None
     reason = next(f[1] for f in flags if not f[0])
     # fall back together: the collectives of torch.distributed (RCCL) on tensors aliasing the library's memory
-    job.nccl_pg = new_nccl_group() if new_nccl_group else dist.new_group(backend="nccl")
-    return f"torch.distributed nccl on aliased device memory (FALLBACK: the library's RCCL group failed: {reason})"
+    # (with --share-gpu no RCCL of any kind can serve two ranks on the device: the rehearsal falls back to gloo)
+    backend = "gloo" if getattr(args, "share_gpu", False) else "nccl"
+    job.nccl_pg = new_nccl_group() if new_nccl_group else dist.new_group(backend=backend)
+    return f"torch.distributed {backend} on aliased device memory (FALLBACK: the library's RCCL group failed: {reason})"
 
 
 def group_collectives(job):
@@ -1200,10 +1202,12 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1: ONE process drives all N ranks, one context per GPU behind lumen_group_create (the "
                          "reference server's topology); with --share-gpu the N contexts share device 0")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "copy", "torch"],
+    ap.add_argument("--transport", default=None, choices=["rccl", "copy", "torch"],
                     help="N > 1: rccl = the library's own RCCL communicator (default; falls back to torch if it cannot "
                          "be set up); copy = stream-ordered peer copies (--single-process only); torch = "
-                         "torch.distributed collectives on tensors aliasing the library's memory (the round-3 path)")
+                         "torch.distributed collectives on tensors aliasing the library's memory (the round-3 path; the "
+                         "default with --share-gpu, where RCCL refuses two ranks on one device -- asking for rccl there "
+                         "rehearses the refusal and the fallback)")
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the comparison of an N-rank run at 2048x1024 with a single-rank recompute")
     ap.add_argument("--allow-replicated", action="store_true",
@@ -1219,6 +1223,8 @@ def main():
     ap.add_argument("--ring-switch-logn", type=int, default=0,
                     help="BASELINE config 5: ring-switch MatR/MatZ to this ring degree (fhe/ring_switch.go)")
     args = ap.parse_args()
+    if args.transport is None:
+        args.transport = "torch" if (args.share_gpu and not args.single_process) else "rccl"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "RANK" not in os.environ and args.gpus > 1 and not args.single_process:
@@ -1245,7 +1251,7 @@ def main():
         # control plane (the id of the library's communicator, barriers, max over ranks): gloo.  Data plane: the
         # library's own RCCL communicator, or with --transport torch the process group itself ("nccl" is RCCL on
         # ROCm).  A rank that dies must not leave the others waiting in a collective for ever.
-        use_torch = args.transport == "torch" or args.share_gpu
+        use_torch = args.transport == "torch"
         dist.init_process_group(args.dist_backend if use_torch else "gloo", timeout=datetime.timedelta(minutes=10))
 
     local_devices = None

@@ -313,7 +313,11 @@ extern "C" int lumen_group_create(lumen_ctx *const *ctxs, uint32_t log_world, ui
         std::vector<int> devs;
         for (lumen_ctx *c : g->ctx) devs.push_back(c->device);
         g->comm.assign(W, nullptr);
-        G_NCCL(g, g->rccl->CommInitAll(g->comm.data(), (int)W, devs.data()));
+        {
+            const ncclResult_t r = g->rccl->CommInitAll(g->comm.data(), (int)W, devs.data());
+            LM_CHECK(nullptr, r == ncclSuccess, "ncclCommInitAll over %u devices failed: %s (NCCL_DEBUG=WARN prints its reason)", W,
+                     g->rccl->GetErrorString(r));
+        }
         int cnt = 0;
         G_NCCL(g, g->rccl->CommCount(g->comm[0], &cnt));
         g->rccl_ranks = (uint32_t)cnt;
@@ -366,7 +370,12 @@ extern "C" int lumen_group_create_rank(lumen_ctx *ctx, uint32_t rank, uint32_t l
     memcpy(&u, id, 128);
     g->comm.assign(1, nullptr);
     if (use(g, 0)) return 1;
-    G_NCCL(g, g->rccl->CommInitRank(&g->comm[0], (int)W, u, (int)rank));
+    {
+        const ncclResult_t r = g->rccl->CommInitRank(&g->comm[0], (int)W, u, (int)rank);
+        LM_CHECK(nullptr, r == ncclSuccess,
+                 "ncclCommInitRank (rank %u of %u on device %d) failed: %s -- RCCL needs every rank on its own device; "
+                 "NCCL_DEBUG=WARN prints its reason", rank, W, ctx->device, g->rccl->GetErrorString(r));
+    }
     int cnt = 0;
     G_NCCL(g, g->rccl->CommCount(g->comm[0], &cnt));
     g->rccl_ranks = (uint32_t)cnt;

@@ -191,11 +191,15 @@ class Job:
         self.r_pt = rand_limbs(P.q, (self.N,))
         self.b_pt = rand_limbs(P.q, (self.N,))
         beta = (self.L + self.K - 1) // self.K
+        self.key_load_s, self.key_load_bytes = 0.0, 0
         for g in ctx.inner_sum_galois_elements(self.rows):
             evk = np.ascontiguousarray(
                 rand_limbs(P.q + P.p, (beta, 2, self.N)).transpose(1, 2, 0, 3))  # [beta][2][L+K][N]
             for c in self._key_ctxs:
-                c.load_galois_key(g, evk)
+                t0 = time.perf_counter()
+                c.load_galois_key(g, evk)  # (returns when the key is usable: conversion on the device)
+                self.key_load_s += time.perf_counter() - t0
+                self.key_load_bytes += evk.nbytes
         self.query_idx = rng.integers(0, self.S, size=self.queries).astype(np.uint32)
         self.ring_switch_logn = 0
         self._rand_limbs = rand_limbs
@@ -1332,6 +1336,10 @@ def main():
             "ct_ntts_reference_equiv_per_s": round(census / sec_per_step / (2 * job.L), 1),
             "roofline": roofline,
             "ntt_kernel": ntt_kernel,
+            # the evaluation keys a client posts, from pageable host memory to usable on the device
+            # (lumen_load_galois_key: upload + conversion to the gadget product's form, once per client)
+            "load_galois_keys": {"keys": job.key_load_bytes // max(1, (job.L + job.K - 1) // job.K * 2 * (job.L + job.K) * job.N * 8),
+                                 "GB": round(job.key_load_bytes / 1e9, 3), "seconds": round(job.key_load_s, 4)},
             "kernels": stages,
         }
         if multi:

@@ -273,6 +273,12 @@ int lumen_plain_inner_products(lumen_ctx *ctx, const lumen_set *columns, const u
  * evk host layout [digit(beta)][b|a][limb(L+K)][N], NTT domain, standard form
  * (the Go shim converts from Lattigo's Montgomery-form GadgetCiphertext). */
 int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint64_t *evk);
+/* The same with flags.  LUMEN_KEY_MONTGOMERY: the words are in Lattigo's Montgomery form (x * 2^64 mod q_i), i.e.
+ * GadgetCiphertext.Value[d][0][0..1] copied as it is -- no IMForm pass over 2.75 M words per key on the Go side.
+ * Either way the conversion to the form the gadget product multiplies with runs on the device (0.35 GB of keys
+ * per client at the headline size). */
+#define LUMEN_KEY_MONTGOMERY 1u
+int lumen_load_galois_key_ex(lumen_ctx *ctx, uint64_t gal_el, const uint64_t *evk, uint32_t flags);
 /* Galois elements InnerSum(ct, 1, n) needs, in the order it uses them
  * (params.GaloisElementsForInnerSum(1, rows), fhe/ligero_test.go:53) */
 uint32_t lumen_inner_sum_galois_elements(const lumen_ctx *ctx, uint32_t n, uint64_t *gal_els);

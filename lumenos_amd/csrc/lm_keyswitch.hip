@@ -976,36 +976,64 @@ extern "C" uint32_t lumen_inner_sum_galois_elements(const lumen_ctx *ctx, uint32
     return cnt;
 }
 
-extern "C" int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint64_t *evk) {
+// key words -> the form the gadget product multiplies with, on the device: dst = src * fac[limb] mod q (canonical).
+// A residue >= q is reported through `bad` (the smallest offending row [digit][b|a][limb]).
+__global__ __launch_bounds__(256) void k_key_prepare(const u64 *__restrict__ src, u64 *__restrict__ dst, uint32_t logN, uint32_t LK,
+                                                     size_t words, lm_mods mods, lm_ninv_t fac, uint32_t *__restrict__ bad) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(i >> logN), t = row % LK;
+        const u64 q = mods.m[t].q, x = src[i];
+        if (x >= q) atomicMin(bad, row);
+        dst[i] = lm_shoup_cs(x, fac.t[t], q, 0 - q);
+    }
+}
+
+int lm_h2d(lumen_ctx *ctx, void *dev, const void *host, size_t bytes);
+
+extern "C" int lumen_load_galois_key_ex(lumen_ctx *ctx, uint64_t gal_el, const uint64_t *evk, uint32_t flags) {
     LM_CHECK(nullptr, ctx && evk, "lumen_load_galois_key: NULL argument");
     LM_ENTER(ctx);
     const uint32_t N = ctx->N, L = ctx->L, K = ctx->K, LK = L + K;
     LM_CHECK(ctx, K >= 1, "parameters have no special primes: key switching unavailable");
     LM_CHECK(ctx, (gal_el & 1) && gal_el < 2ull * N, "Galois element %llu is not an odd residue mod 2N",
              (unsigned long long)gal_el);
+    LM_CHECK(ctx, !(flags & ~(uint32_t)LUMEN_KEY_MONTGOMERY), "lumen_load_galois_key_ex: unknown flags 0x%x", flags);
     const uint32_t beta = (L + K - 1) / K;
     const size_t words = (size_t)beta * 2 * LK * N;
-    // to Montgomery form on the host (one-off per key).  The Q limbs also absorb P^-1 mod q_t: the
+    // To Montgomery form (one-off per key), on the device since round 4: the host loop of 128-bit divisions cost
+    // ~70 ms per key at the headline size, 14 keys per client.  The Q limbs also absorb P^-1 mod q_t: the
     // gadget product then yields u * P^-1 directly and ModDown is u' - lift * P^-1, one multiplication
-    // on the unreduced lift (exact: (sum x*k) * P^-1 == sum x * (k * P^-1) mod q_t)
-    std::vector<u64> mont(words);
-    for (uint32_t d = 0; d < beta; d++)
-        for (uint32_t w = 0; w < 2; w++)
-            for (uint32_t t = 0; t < LK; t++) {
-                const uint64_t q = ctx->mod[t];
-                uint64_t r = (uint64_t)((((u128)1) << 64) % q);
-                if (t < L) {
-                    uint64_t P = 1;
-                    for (uint32_t a = 0; a < K; a++) P = h_mulmod(P, ctx->mod[L + a] % q, q);
-                    r = h_mulmod(r, h_invmod(P, q), q);
-                }
-                const size_t off = (((size_t)d * 2 + w) * LK + t) * N;
-                for (uint32_t k = 0; k < N; k++) {
-                    const uint64_t x = evk[off + k];
-                    if (x >= q) return lm_fail(ctx, "key residue out of range (digit %u limb %u)", d, t);
-                    mont[off + k] = h_mulmod(x, r, q);
-                }
-            }
+    // on the unreduced lift (exact: (sum x*k) * P^-1 == sum x * (k * P^-1) mod q_t).  A key that already is in
+    // Lattigo's Montgomery form (x * 2^64 mod q: what GadgetCiphertext holds) only takes the P^-1 factor.
+    lm_ninv_t fac;
+    for (uint32_t t = 0; t < LM_MAX_LIMBS; t++) fac.t[t] = h_tw(1, ctx->mod[0] ? ctx->mod[0] : 3);
+    for (uint32_t t = 0; t < LK; t++) {
+        const uint64_t q = ctx->mod[t];
+        uint64_t r = (flags & LUMEN_KEY_MONTGOMERY) ? 1 : (uint64_t)((((u128)1) << 64) % q);
+        if (t < L) {
+            uint64_t P = 1;
+            for (uint32_t a = 0; a < K; a++) P = h_mulmod(P, ctx->mod[L + a] % q, q);
+            r = h_mulmod(r, h_invmod(P, q), q);
+        }
+        fac.t[t] = h_tw(r, q);
+    }
+    u64 *raw = (u64 *)lm_scratch(ctx, "key_raw", words * 8);
+    uint32_t *bad = (uint32_t *)lm_scratch(ctx, "key_bad", 4);
+    if (!raw || !bad) return 1;
+    LM_HIP(ctx, hipMemsetAsync(bad, 0xFF, 4, ctx->stream));
+    if (int rc = lm_h2d(ctx, raw, evk, words * 8)) return rc; // returns when evk may be reused
+    u64 *d_new = nullptr;
+    LM_HIP(ctx, hipMalloc((void **)&d_new, words * 8));
+    hipLaunchKernelGGL(k_key_prepare, dim3(2048), dim3(256), 0, ctx->stream, raw, d_new, ctx->logN, LK, words, ctx->mods, fac, bad);
+    uint32_t first_bad = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&first_bad, bad, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || first_bad != 0xFFFFFFFFu) {
+        hipFree(d_new);
+        if (e != hipSuccess) return lm_fail(ctx, "key conversion failed: %s", hipGetErrorString(e));
+        return lm_fail(ctx, "key residue out of range (digit %u limb %u)", first_bad / (2 * LK), first_bad % LK);
+    }
     std::vector<uint32_t> index(N);
     const uint64_t mask = 2ull * N - 1;
     for (uint32_t i = 0; i < N; i++) { // [LATTIGO-RECALL] ring.AutomorphismNTTIndex
@@ -1015,15 +1043,22 @@ extern "C" int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint
     }
     LM_SHARED_LOCK(ctx);
     lm_galois_key &gk = ctx->gkeys[gal_el];
-    if (!gk.d_key) LM_HIP(ctx, hipMalloc((void **)&gk.d_key, words * 8));
+    if (gk.d_key) { // a key loaded again: nothing enqueued may still read the old words
+        lm_sync_all(ctx);
+        hipFree(gk.d_key);
+    }
+    gk.d_key = d_new;
     if (!gk.d_index) LM_HIP(ctx, hipMalloc((void **)&gk.d_index, (size_t)N * 4));
     if (!gk.d_inv_index) LM_HIP(ctx, hipMalloc((void **)&gk.d_inv_index, (size_t)N * 4));
     std::vector<uint32_t> inv_index(N);
     for (uint32_t i = 0; i < N; i++) inv_index[index[i]] = i;
     LM_HIP(ctx, hipMemcpy(gk.d_inv_index, inv_index.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-    LM_HIP(ctx, hipMemcpy(gk.d_key, mont.data(), words * 8, hipMemcpyHostToDevice));
     LM_HIP(ctx, hipMemcpy(gk.d_index, index.data(), (size_t)N * 4, hipMemcpyHostToDevice));
     return 0;
+}
+
+extern "C" int lumen_load_galois_key(lumen_ctx *ctx, uint64_t gal_el, const uint64_t *evk) {
+    return lumen_load_galois_key_ex(ctx, gal_el, evk, 0);
 }
 
 extern "C" int lumen_mul_plain(lumen_ctx *ctx, const lumen_set *in, const uint64_t *pt, lumen_set **out) {

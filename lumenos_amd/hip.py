@@ -89,6 +89,7 @@ SYMBOLS = {
     "lumen_leaf_digests_end": (C.c_int, [_vp, _u8p]),
     "lumen_merkle_build": (C.c_int, [_vp, _u8p, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t), _u8p]),
     "lumen_load_galois_key": (C.c_int, [_vp, C.c_uint64, _u64p]),
+    "lumen_load_galois_key_ex": (C.c_int, [_vp, C.c_uint64, _u64p, C.c_uint32]),
     "lumen_inner_sum_galois_elements": (C.c_uint32, [_vp, C.c_uint32, _u64p]),
     "lumen_matrix_inner_sum": (C.c_int, [_vp, _vp, _u64p, C.c_uint32, _vpp]),
     "lumen_mul_plain": (C.c_int, [_vp, _vp, _u64p, _vpp]),
@@ -533,9 +534,11 @@ class Context:
                                              root.ctypes.data_as(_u8p)))
         return nodes[:cnt.value].copy(), root.tobytes()
 
-    def load_galois_key(self, gal_el, evk):
+    def load_galois_key(self, gal_el, evk, montgomery=False):
+        """evk: [beta][2][L+K][N]; montgomery=True: the words are x * 2^64 mod q_i (Lattigo's own storage form)"""
         evk = np.ascontiguousarray(evk, dtype=np.uint64)
-        self._ck(self.lib.lumen_load_galois_key(self.h, gal_el, _p64(evk)))
+        assert evk.shape == ((self.L + self.K - 1) // max(self.K, 1), 2, self.L + self.K, self.N), evk.shape
+        self._ck(self.lib.lumen_load_galois_key_ex(self.h, gal_el, _p64(evk), 1 if montgomery else 0))
 
     def inner_sum_galois_elements(self, n):
         g = np.zeros(64, dtype=np.uint64)

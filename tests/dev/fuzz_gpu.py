@@ -1,6 +1,7 @@
 """Randomised differential run of the HIP path against the CPU oracle (developer tool, not collected
 by pytest): random ring degrees, limb counts, 1 or 2 special primes, random shapes; the wire image and leaf
-digests in random serialisation formats; the ring switch with 0, 1 or 2 special primes into random degrees.
+digests in random serialisation formats; the ring switch with 0, 1 or 2 special primes into random degrees; W = 2, 4, 8
+ranks behind a lumen_group (Encode between the all-to-alls, digests, root, query gather) against one rank.
 
 usage: [FUZZ_LOGN=13,14] python tests/dev/fuzz_gpu.py [cases] [seed]
 """
@@ -94,6 +95,43 @@ def one_case(o, rng, case):
     assert dig[0].tobytes() == o.sha256(P.ct_serialize(c4[0], fmt)), (tag, "leaf digest", lens)
     ctx.leaf_format_set()
     what.append(f"wire{lens}")
+    # several ranks behind one process (lumen_group, copy transport: W contexts on this one GPU): Encode between the
+    # two all-to-alls, rescale, digests + all-gather + device root, query gather -- against the oracle's one-rank run
+    if (P.N >> 1) >= 64:
+        from lumenos_amd.hip import Group
+        max_logw = min(3, log_n - 6)
+        W = 1 << int(rng.integers(1, max_logw + 1))
+        rho = int(rng.choice([1, 2, 4]))
+        cols = W * int(rng.choice([1, 2, 4]))
+        Sg = cols * rho
+        if Sg >= 2:
+            rootsg = o.field_roots(T_REF, max(Sg, 16))
+            ctx.field_set(rootsg)
+            nlg = int(rng.integers(1, num_q + 1))
+            mg = random_cts(P, cols, nlg, seed=case + 23)
+            zg = random_cts(P, 1, nlg, seed=case + 29)[0]
+            want_enc = P.ct_encode(mg, rho, zg, rootsg)
+            ctxs = [ctx] + [ctx.clone() for _ in range(W - 1)]
+            g = Group(ctxs, transport="copy")
+            own, Sw = cols // W, Sg // W
+            enc = g.encode([cx.upload(mg[r * own:(r + 1) * own]) for r, cx in enumerate(ctxs)], zg, rho)
+            for r in range(W):
+                assert np.array_equal(enc[r].download(), want_enc[r * Sw:(r + 1) * Sw]), (tag, "group encode", W, cols, rho, r)
+            tgt = min(nlg, 2)
+            l1 = [cx.rescale(e, tgt) if nlg > tgt else e for cx, e in zip(ctxs, enc)]
+            for cx, l in zip(ctxs, l1):
+                cx.leaf_digests_begin(l)
+            g.all_gather_digests()
+            one = ctx.rescale(ctx.upload(want_enc), tgt) if nlg > tgt else ctx.upload(want_enc)
+            dig1 = ctx.leaf_digests(one)
+            assert np.array_equal(g.digests(Sg), dig1), (tag, "group digests", W)
+            assert g.merkle_root() == o.merkle(dig1)[1], (tag, "group root", W)
+            qi = rng.integers(0, Sg, size=int(rng.integers(1, 9))).astype(np.uint32)
+            assert np.array_equal(g.gather(l1, qi).download(), one.download()[qi]), (tag, "group gather", W, qi)
+            g.close()
+            for cx in ctxs[1:]:
+                cx.close()
+            what.append(f"group(W={W},cols={cols},rho={rho},nl={nlg})")
     ctx.close()
     # ring switch on the gadget path the number of special primes selects (a context of its own: K = 0 too)
     kp = int(rng.choice([0, 1, 2]))

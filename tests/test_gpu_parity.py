@@ -250,6 +250,35 @@ def test_inner_sum_matches_oracle(oracle, keyed, n):
         assert np.array_equal(got[c], P.inner_sum(cts[c], n, evks)), c
 
 
+def test_galois_keys_in_lattigo_montgomery_form(oracle, keyed):
+    """lumen_load_galois_key_ex(LUMEN_KEY_MONTGOMERY): the key words as Lattigo stores them (x * 2^64 mod q_i,
+    GadgetCiphertext.Value copied as it is) give the same InnerSum as the standard-form key -- the conversion runs on
+    the device either way -- and a residue >= q_i is still refused, with its digit and limb."""
+    from lumenos_amd.hip import LumenError
+    P, ctx, sk = keyed
+    n = 16
+    gl = P.inner_sum_galois_elements(n)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    cts = random_cts(P, 2, 5, seed=1234)
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    want = ctx.inner_sum(ctx.upload(cts), n).download()
+    assert np.array_equal(want[0], P.inner_sum(cts[0], n, evks))
+    for g, e in zip(gl, evks):
+        m = np.empty_like(e)
+        for t, q in enumerate(P.moduli):
+            m[:, :, t, :] = ((e[:, :, t, :].astype(object) << 64) % int(q)).astype(np.uint64)
+        ctx.load_galois_key(g, m, montgomery=True)
+    assert np.array_equal(ctx.inner_sum(ctx.upload(cts), n).download(), want)
+    bad = evks[0].copy()
+    bad[1, 0, 2, 7] = int(P.moduli[2])
+    with pytest.raises(LumenError, match=r"key residue out of range \(digit 1 limb 2\)"):
+        ctx.load_galois_key(gl[0], bad)
+    for g, e in zip(gl, evks):  # the fixture's keys as the other tests expect them
+        ctx.load_galois_key(g, e)
+    assert np.array_equal(ctx.inner_sum(ctx.upload(cts), n).download(), want)
+
+
 @pytest.mark.parametrize("nf", [0, 1, 2])
 def test_inner_sum_fused_digit_packing(oracle, keyed, nf):
     """k_intt_pack: the (hi, lo) packing of the first nf two-limb digits is fused into the c1 inverse

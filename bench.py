@@ -778,9 +778,31 @@ def attach_group(job, args, dist, new_nccl_group=None):
     reason = next(f[1] for f in flags if not f[0])
     # fall back together: the collectives of torch.distributed (RCCL) on tensors aliasing the library's memory
     # (with --share-gpu no RCCL of any kind can serve two ranks on the device: the rehearsal falls back to gloo)
-    backend = "gloo" if getattr(args, "share_gpu", False) else "nccl"
-    job.nccl_pg = new_nccl_group() if new_nccl_group else dist.new_group(backend=backend)
-    return f"torch.distributed {backend} on aliased device memory (FALLBACK: the library's RCCL group failed: {reason})"
+    if new_nccl_group:
+        job.nccl_pg = new_nccl_group()
+        return f"torch.distributed nccl on aliased device memory (FALLBACK: the library's RCCL group failed: {reason})"
+    backend, probe = ("gloo" if getattr(args, "share_gpu", False) else "nccl"), ""
+    if backend == "nccl":
+        # whatever kept the library's communicator from forming may keep torch's from forming too (same RCCL): try one
+        # tiny collective, and if any rank cannot, ALL take the host-staged gloo path -- slow, but a number and a check
+        import datetime
+        try:
+            pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+            t = torch.ones(1, device="cuda")
+            dist.all_reduce(t, group=pg)
+            torch.cuda.synchronize()
+            good, probe = int(t.item()) == job.world, ""
+        except Exception as e:  # noqa: BLE001
+            good, probe, pg = False, f"{type(e).__name__}: {e}", None
+        verdicts = [None] * job.world
+        dist.all_gather_object(verdicts, (good, probe))
+        if all(v[0] for v in verdicts):
+            job.nccl_pg = pg
+        else:
+            backend, probe = "gloo", "; torch's nccl group failed too: " + next(v[1] for v in verdicts if not v[0])[:300]
+    if backend == "gloo":
+        job.nccl_pg = dist.new_group(backend="gloo")
+    return (f"torch.distributed {backend} on aliased device memory (FALLBACK: the library's RCCL group failed: {reason}{probe})")
 
 
 def group_collectives(job):

@@ -545,8 +545,11 @@ def test_gpu_against_fixtures(oracle, fx):
         for name in (f"innersum_{P.N // 2}.lmfx", f"innersum_{P.N}.lmfx"):
             rec = load(name)
             n, gl, evks = _inner_sum_inputs(P, rec)
+            mont = int(rec["keys_montgomery"][0])
             for g, e in zip(gl, evks):
-                ctx.load_galois_key(g, e)
+                # as the shim hands them over: Lattigo's own storage form, converted on the device
+                # (lumen_load_galois_key_ex with LUMEN_KEY_MONTGOMERY), when the fixture holds that form
+                ctx.load_galois_key(g, to_montgomery(e, P.moduli) if mont else e, montgomery=bool(mont))
             ct, pt = std_ct(rec, "in"), rec["plaintext"][0]
             inner = ctx.inner_sum(ctx.mul_plain(ctx.upload(ct[None]), pt), n).download()[0]
             assert np.array_equal(inner, std_ct(rec, "inner_sum")), name

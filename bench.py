@@ -699,7 +699,7 @@ def cpu_baseline(cfg, budget_s=20.0):
     Ps.ct_encode(m, RHO_INV, z, roots)
     t_enc = (time.time() - t0) * (2 * L * N) / (2 * 1 * Ps.N)
     # Commit leaves: rescale + serialise + SHA-256 on `cores` columns (OpenMP over columns)
-    n_c = cores
+    n_c = 4 * cores  # (about 5 s of work on 16 cores: the whole sample is 10-20 s)
     enc = rand_ct(n_c, L)
     t0 = time.time()
     P.commit_leaves(enc)
@@ -711,7 +711,7 @@ def cpu_baseline(cfg, budget_s=20.0):
         evk[:, :, t_i, :] = rng.integers(0, mod, size=(evk.shape[0], 2, N), dtype=np.uint64)
     evks = [evk] * len(gl)
     pt = np.stack([rng.integers(0, P.moduli[l], size=N, dtype=np.uint64) for l in range(L)])
-    n_i = cores
+    n_i = 2 * cores
     mat = rand_ct(n_i, L)
     t0 = time.time()
     P.matrix_inner_sum(mat, pt, rows, evks)
@@ -817,13 +817,13 @@ def group_collectives(job):
     return out
 
 
-def check_against_single_rank(job_args, world, rank, local_devices, group_factory):
+def check_against_single_rank(device, world, rank, local_devices, group_factory, dist):
     """An N-rank run at 2048x1024 (BASELINE config A) against a single-rank recompute on the same inputs: the Merkle
     root, a sample of every local rank's encoded columns, and the first and last MatR ciphertext of its block.
     Every process recomputes the whole job on its own first device (0.1 s at this size): rank r's input block is
     fill_random(1 + r), whoever generates it."""
     cfg = "2048x1024"
-    j = Job(cfg, rank, world, job_args["device"], 0, False, local_devices)
+    j = Job(cfg, rank, world, device, 0, False, local_devices)
     if not j.lane_path:
         j.close()
         return {"ok": None, "note": f"{world} ranks cannot run the lane path at {cfg}"}
@@ -833,7 +833,7 @@ def check_against_single_rank(job_args, world, rank, local_devices, group_factor
         if j.group is not None:
             enc, lvl1, mat_r, mat_z, q, root = j.step_group(keep=True)
         else:
-            enc, lvl1, mat_r, mat_z, q, root = j.step_lanes(group_factory.dist, keep=True)
+            enc, lvl1, mat_r, mat_z, q, root = j.step_lanes(dist, keep=True)
         ctx, own, Sw = j.ctx, j.cols // world, j.S // world
         full = ctx.new_set(j.cols, j.L)
         views = [full.slice(r * own, own).fill_random(1 + r) for r in range(world)]
@@ -907,10 +907,8 @@ def multi_rank_report(job, args, dist, per_rank_prof, sec_per_step):
                 box = [Group.unique_id().tobytes() if job.rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 j.group = Group.join(j.ctx, job.rank, job.world, np.frombuffer(box[0], dtype=np.uint8))
-        factory.dist = dist
         try:
-            mine["check"] = check_against_single_rank({"device": job.ctx_device}, job.world, job.rank,
-                                                      job.local_devices, factory)
+            mine["check"] = check_against_single_rank(job.ctx_device, job.world, job.rank, job.local_devices, factory, dist)
         except Exception as e:  # a failed check must not cost the measurement
             mine["check"] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     parts = [mine]

@@ -353,6 +353,7 @@ int lumen_group_create(lumen_ctx *const *ctxs, uint32_t log_world, uint32_t tran
 int lumen_group_unique_id(uint8_t id[128]);
 int lumen_group_create_rank(lumen_ctx *ctx, uint32_t rank, uint32_t log_world, const uint8_t id[128],
                             lumen_group **out);
+/* destroy a group BEFORE its contexts: it waits for their streams and returns its events to them */
 void lumen_group_destroy(lumen_group *g);
 uint32_t lumen_group_world(const lumen_group *g);
 uint32_t lumen_group_local(const lumen_group *g);

@@ -737,8 +737,11 @@ class Group:
         self._ck(self.lib.lumen_group_stats_reset(self.h))
 
     def close(self):
+        """destroy the group -- BEFORE its contexts (the C rule: lumen_group_destroy waits on their streams)"""
         if self.h:
-            self.lib.lumen_group_destroy(self.h)
+            if all(c.h for c in self.ctxs):
+                self.lib.lumen_group_destroy(self.h)
+            # a context already closed: its streams are gone, the group handle is abandoned rather than touched
             self.h = None
 
     def __del__(self):

@@ -969,9 +969,13 @@ def profile_kernels(job, dist, cfg):
     for c in job.ctxs:
         c.prof_reset()
         c.prof_enable(True)
+        # one key-switch lane for the measured step: with two (the default below N = 2^14) a kernel's event pair also
+        # spans whatever its neighbour on the other stream was doing
+        c.set_tuning("LUMEN_KS_LANES", 1)
     job.step(dist)
     for c in job.ctxs:
         c.prof_enable(False)
+        c.set_tuning("LUMEN_KS_LANES", 0)  # back to the default by ring degree
     per_rank = [_kernel_table(job, c, cfg) for c in job.ctxs]
     return per_rank[0] + (per_rank,)
 

@@ -79,7 +79,7 @@ struct lm_shared {
 // in-process way for tests and tools.
 struct lm_tuning {
     uint32_t ks_batch = 64;      // LUMEN_KS_BATCH: columns per key-switch batch
-    uint32_t ks_lanes = 1;       // LUMEN_KS_LANES: 2 = column batches alternate on two streams
+    uint32_t ks_lanes = 0;       // LUMEN_KS_LANES: 1 / 2 streams for the column batches of a key switch; 0 = by ring degree
     int32_t ks_fused_digits = -1; // LUMEN_KS_FUSED_DIGITS: digits packed inside k_intt_pack (-1: derive)
     uint32_t ct_blocks = 1;      // LUMEN_CT_BLOCKS: 0 = Encode through the op-by-op interpreter
     uint32_t debug = 0;          // LUMEN_DEBUG

@@ -170,7 +170,7 @@ static int ctx_private_init(lumen_ctx *ctx) {
 static int tuning_set(lm_tuning &t, const char *name, long v) {
     const std::string n(name ? name : "");
     if (n == "LUMEN_KS_BATCH") t.ks_batch = (v >= 1 && v <= 4096) ? (uint32_t)v : 64;
-    else if (n == "LUMEN_KS_LANES") t.ks_lanes = v == 2 ? 2 : 1;
+    else if (n == "LUMEN_KS_LANES") t.ks_lanes = (v == 1 || v == 2) ? (uint32_t)v : 0; // anything else: derived default
     else if (n == "LUMEN_KS_FUSED_DIGITS") t.ks_fused_digits = v >= 0 ? (int32_t)v : -1;
     else if (n == "LUMEN_CT_BLOCKS") t.ct_blocks = v != 0;
     else if (n == "LUMEN_DEBUG") t.debug = v != 0;

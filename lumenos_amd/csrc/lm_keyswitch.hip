@@ -734,9 +734,15 @@ int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s, int lan
 // Enqueue on the context's second stream for the lifetime of the guard.  Independent column
 // batches alternate between the two streams so that the HBM-bound steps of one batch (gadget
 // product, correction-bit pass) overlap the VALU-bound transforms of the other.
-// one lane by default: with two (LUMEN_KS_LANES=2 at context creation), independent column batches overlap
-// on two streams (about 1 % faster end to end) but per-kernel event timings then include the other lane's
-static uint32_t ks_lanes(const lumen_ctx *ctx) { return ctx->tune.ks_lanes; }
+// Two lanes up to N = 2^13, one at N = 2^14 (round 4, measured on one MI355X, seconds per prover step with 1 / 2
+// lanes: 2048x1024 0.0850 / 0.0743, 4096x2048 0.193 / 0.163, 8192x4096 0.864 / 0.799, 16384x4096 1.86 / 1.92).
+// Up to 2^13 a limb needs at most half of a CU's LDS, so workgroups of two kernels are resident side by side and
+// one batch's memory-bound steps run under the other's transforms; at 2^14 a transform workgroup owns the whole
+// LDS and two transform kernels only evict each other's L2 sets.  LUMEN_KS_LANES = 1 / 2 overrides.  (With two
+// lanes a kernel's HIP-event time includes its neighbour's: the roofline is read at N = 2^14, one lane.)
+static uint32_t ks_lanes(const lumen_ctx *ctx) {
+    return ctx->tune.ks_lanes ? ctx->tune.ks_lanes : (ctx->logN <= 13 ? 2 : 1);
+}
 // digits whose packing is fused into the c1 inverse transform (k_intt_pack): the largest count whose
 // B * nf two-transform workgroups are whole rounds of the device's workgroup slots (CUs x resident
 // workgroups per CU: 256 x 1 at N = 2^14, so 4 of 6 digits at B = 64), so that no slot waits for a

@@ -363,6 +363,12 @@ const char *lumen_group_transport(const lumen_group *g);
 uint32_t lumen_group_rccl_ranks(const lumen_group *g);
 /* waits for everything enqueued on every local context */
 int lumen_group_sync(lumen_group *g);
+/* every local rank's whole set from / to its host buffer (hosts[i]: the layout of lumen_set_upload), all transfers
+ * enqueued before any is waited for: a process that owns W GPUs moves its W blocks over W PCIe links at once
+ * (page-locked buffers; pageable ones are bounced rank by rank).  Returns when the host buffers may be reused /
+ * hold the data. */
+int lumen_group_upload(lumen_group *g, lumen_set *const *sets, const uint64_t *const *hosts);
+int lumen_group_download(lumen_group *g, const lumen_set *const *sets, uint64_t *const *hosts);
 /* block p of send[.] (its p-th run of count/W ciphertexts: every layout is ct-major, so a contiguous slice)
  * goes to rank p; block q of recv[.] comes from rank q.  send[i] and recv[i] have the same size. */
 int lumen_group_all_to_all(lumen_group *g, const lumen_set *const *send, lumen_set *const *recv);

@@ -17,8 +17,13 @@ def source_hash():
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
+        data = open(f, "rb").read()
+        # hardware counters are per KERNEL: a translation unit without device code (lm_group.hip: the host-side
+        # exchange logic) cannot change them, and editing it must not orphan a profile
+        if f.endswith(".hip") and b"__global__" not in data:
+            continue
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(data)
     flags = " ".join(os.environ.get("LUMEN_HIPCC_FLAGS", "").split())
     variant = os.environ.get("LUMEN_HIP_LIB", "")
     if variant:

@@ -723,6 +723,49 @@ extern "C" int lumen_group_gather(lumen_group *g, const lumen_set *const *src, c
     return 0;
 }
 
+// ---- host <-> ranks: every local rank's transfer is enqueued before any is waited for, so the W PCIe links of a
+// process that owns W GPUs carry their blocks at the same time (one lumen_set_upload per rank would finish the
+// first DMA before it starts the second: 12.9 GB over one link after the other)
+bool lm_host_is_pinned(const void *p);
+int lm_h2d(lumen_ctx *ctx, void *dev, const void *host, size_t bytes);
+int lm_d2h(lumen_ctx *ctx, void *host, const void *dev, size_t bytes, bool wait);
+
+static int group_io(lumen_group *g, lumen_set *const *sets, uint64_t *const *hosts, bool up, const char *what) {
+    LM_CHECK(nullptr, g && sets && hosts, "%s: NULL argument", what);
+    group_lock lk(g);
+    const uint32_t n = (uint32_t)g->ctx.size();
+    std::vector<uint32_t> later; // pageable buffers go through the contexts' bounce buffers, one rank after the other
+    for (uint32_t i = 0; i < n; i++) {
+        LM_CHECK(nullptr, sets[i] && (hosts[i] || !sets[i]->words), "%s: set or host buffer %u is NULL", what, i);
+        if (!sets[i]->words) continue;
+        if (!lm_host_is_pinned(hosts[i])) {
+            later.push_back(i);
+            continue;
+        }
+        if (use(g, i)) return 1;
+        const size_t bytes = sets[i]->words * 8;
+        if (up) G_HIP(hipMemcpyAsync(sets[i]->d, hosts[i], bytes, hipMemcpyHostToDevice, g->ctx[i]->stream));
+        else G_HIP(hipMemcpyAsync(hosts[i], sets[i]->d, bytes, hipMemcpyDeviceToHost, g->ctx[i]->stream));
+    }
+    for (uint32_t i : later) {
+        if (use(g, i)) return 1;
+        const size_t bytes = sets[i]->words * 8;
+        if (up ? lm_h2d(g->ctx[i], sets[i]->d, hosts[i], bytes) : lm_d2h(g->ctx[i], hosts[i], sets[i]->d, bytes, true)) return 1;
+    }
+    for (uint32_t i = 0; i < n; i++) { // the host buffers are the caller's: return when they may be reused / hold the data
+        if (use(g, i)) return 1;
+        G_HIP(hipStreamSynchronize(g->ctx[i]->stream));
+    }
+    return 0;
+}
+
+extern "C" int lumen_group_upload(lumen_group *g, lumen_set *const *sets, const uint64_t *const *hosts) {
+    return group_io(g, sets, const_cast<uint64_t *const *>(hosts), true, "lumen_group_upload");
+}
+extern "C" int lumen_group_download(lumen_group *g, const lumen_set *const *sets, uint64_t *const *hosts) {
+    return group_io(g, const_cast<lumen_set *const *>(sets), hosts, false, "lumen_group_download");
+}
+
 extern "C" int lumen_group_stats(lumen_group *g, const char *name, double *ms, uint64_t *bytes, uint64_t *calls) {
     LM_CHECK(nullptr, g && name, "lumen_group_stats: NULL argument");
     group_lock lk(g);

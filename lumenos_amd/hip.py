@@ -110,6 +110,8 @@ SYMBOLS = {
     "lumen_group_rccl_ranks": (C.c_uint32, [_vp]),
     "lumen_group_sync": (C.c_int, [_vp]),
     "lumen_group_all_to_all": (C.c_int, [_vp, _vpp, _vpp]),
+    "lumen_group_upload": (C.c_int, [_vp, _vpp, _vpp]),
+    "lumen_group_download": (C.c_int, [_vp, _vpp, _vpp]),
     "lumen_group_encode": (C.c_int, [_vp, _vpp, _u64p, C.c_uint32, _vpp]),
     "lumen_group_all_gather_digests": (C.c_int, [_vp]),
     "lumen_group_merkle_root": (C.c_int, [_vp, _u8p]),
@@ -692,6 +694,17 @@ class Group:
 
     def sync(self):
         self._ck(self.lib.lumen_group_sync(self.h))
+
+    def upload(self, sets, hosts):
+        """every local rank's set from its host array, all DMAs in flight together"""
+        ptrs = (C.c_void_p * len(sets))(*[h.ctypes.data for h in hosts])
+        assert all(h.dtype == np.uint64 and h.flags["C_CONTIGUOUS"] and h.nbytes == s.nbytes for h, s in zip(hosts, sets))
+        self._ck(self.lib.lumen_group_upload(self.h, self._handles(sets), ptrs))
+
+    def download(self, sets, hosts):
+        ptrs = (C.c_void_p * len(sets))(*[h.ctypes.data for h in hosts])
+        assert all(h.dtype == np.uint64 and h.flags["C_CONTIGUOUS"] and h.nbytes == s.nbytes for h, s in zip(hosts, sets))
+        self._ck(self.lib.lumen_group_download(self.h, self._handles(sets), ptrs))
 
     def all_to_all(self, send, recv):
         self._ck(self.lib.lumen_group_all_to_all(self.h, self._handles(send), self._handles(recv)))

@@ -89,6 +89,37 @@ def test_group_commit_matches_single_context(oracle, small, world):
         cx.close()
 
 
+def test_group_upload_download(small):
+    """lumen_group_upload / _download: every rank's block between host and device in one call (page-locked and
+    pageable buffers), equal to the per-context transfers."""
+    from lumenos_amd.hip import Group, pinned_empty, pinned_free
+    P, ctx = small
+    ctxs = ranks_of(ctx, 4)
+    g = Group(ctxs, transport="copy")
+    host = [random_cts(P, 5, 2, seed=700 + r) for r in range(4)]
+    pinned = []
+    for r in (0, 2):  # two ranks from page-locked memory, two from ordinary arrays
+        a = pinned_empty(host[r].shape)
+        a[:] = host[r]
+        pinned.append(a)
+        host[r] = a
+    sets = [c.new_set(5, 2) for c in ctxs]
+    g.upload(sets, host)
+    for r in range(4):
+        assert np.array_equal(sets[r].download(), host[r]), r
+    back = [np.zeros_like(np.asarray(h)) for h in host]
+    back[1] = pinned_empty(host[1].shape)
+    g.download(sets, back)
+    for r in range(4):
+        assert np.array_equal(back[r], host[r]), r
+    pinned_free(back[1])
+    for a in pinned:
+        pinned_free(a)
+    g.close()
+    for c in ctxs[1:]:
+        c.close()
+
+
 def test_group_refuses_what_it_cannot_serve(oracle, small):
     from lumenos_amd.hip import Group, LumenError
     P, ctx = small

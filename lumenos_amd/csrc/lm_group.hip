@@ -315,7 +315,9 @@ extern "C" int lumen_group_create(lumen_ctx *const *ctxs, uint32_t log_world, ui
         g->comm.assign(W, nullptr);
         {
             const ncclResult_t r = g->rccl->CommInitAll(g->comm.data(), (int)W, devs.data());
-            LM_CHECK(nullptr, r == ncclSuccess, "ncclCommInitAll over %u devices failed: %s (NCCL_DEBUG=WARN prints its reason)", W,
+            LM_CHECK(nullptr, r == ncclSuccess,
+                     "ncclCommInitAll over %u devices failed: %s (hosts whose driver only does dmabuf IPC need "
+                     "HSA_ENABLE_IPC_MODE_LEGACY=0 in the process environment; NCCL_DEBUG=WARN prints RCCL's own reason)", W,
                      g->rccl->GetErrorString(r));
         }
         int cnt = 0;
@@ -373,8 +375,10 @@ extern "C" int lumen_group_create_rank(lumen_ctx *ctx, uint32_t rank, uint32_t l
     {
         const ncclResult_t r = g->rccl->CommInitRank(&g->comm[0], (int)W, u, (int)rank);
         LM_CHECK(nullptr, r == ncclSuccess,
-                 "ncclCommInitRank (rank %u of %u on device %d) failed: %s -- RCCL needs every rank on its own device; "
-                 "NCCL_DEBUG=WARN prints its reason", rank, W, ctx->device, g->rccl->GetErrorString(r));
+                 "ncclCommInitRank (rank %u of %u on device %d) failed: %s -- RCCL needs every rank on its own device, and "
+                 "on hosts whose driver only does dmabuf IPC the process environment must carry "
+                 "HSA_ENABLE_IPC_MODE_LEGACY=0; NCCL_DEBUG=WARN prints RCCL's own reason", rank, W, ctx->device,
+                 g->rccl->GetErrorString(r));
     }
     int cnt = 0;
     G_NCCL(g, g->rccl->CommCount(g->comm[0], &cnt));

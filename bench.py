@@ -1251,6 +1251,9 @@ def main():
     ap.add_argument("--ring-switch-logn", type=int, default=0,
                     help="BASELINE config 5: ring-switch MatR/MatZ to this ring degree (fhe/ring_switch.go)")
     args = ap.parse_args()
+    # the host driver of this pool only does dmabuf IPC: RCCL (the library's own group and torch's) needs this before
+    # the HIP runtime starts in this process
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.transport is None:
         args.transport = "torch" if (args.share_gpu and not args.single_process) else "rccl"
 

@@ -731,6 +731,74 @@ def hashlib_sha(arr):
     return hashlib.sha256(memoryview(arr)).hexdigest()
 
 
+def device_identity(ctx_device):
+    """what tells two ranks that they sit on the same physical GPU: the device's UUID where torch exposes it, else
+    host + visibility masks + ordinal"""
+    import socket
+    try:
+        import torch
+        return f"{socket.gethostname()}:{torch.cuda.get_device_properties(ctx_device).uuid}"
+    except Exception:  # noqa: BLE001 -- older torch: no uuid
+        return "%s:%s:%s:%d" % (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES", ""),
+                                os.environ.get("ROCR_VISIBLE_DEVICES", ""), ctx_device)
+
+
+def join_ranks(ctx, rank, world, dist, deadline_s=None):
+    """One process per GPU: every rank joins the library's own RCCL communicator (lumen_group_create_rank) -- or none
+    does.  Returns (group or None, [(ok, reason)] of all ranks), the same on every rank.
+
+    ncclCommInitRank only returns once ALL ranks have arrived, so a rank must not find out about a problem inside
+    it while its peers are already blocked there.  Hence two steps, both agreed over the control plane (gloo):
+      1. what can be checked locally is checked BEFORE anybody joins: librccl loads and answers (ncclGetUniqueId is
+         a local call), and no two ranks sit on the same physical device (RCCL refuses that communicator);
+      2. the join itself runs under a deadline (LUMEN_BENCH_JOIN_TIMEOUT, default 180 s): a rank still inside
+         ncclCommInitRank by then -- its peers failed asymmetrically and moved on -- exits non-zero, so that
+         torch.distributed.run tears the whole job down instead of sitting in a 10-minute gloo timeout without a
+         JSON line.  (Exit, not recovery: a process that has touched the GPU is never re-executed.)"""
+    import threading
+    from lumenos_amd.hip import Group, LumenError
+    deadline_s = deadline_s or float(os.environ.get("LUMEN_BENCH_JOIN_TIMEOUT", "180"))
+    uid, err = None, ""
+    try:
+        uid = Group.unique_id()  # loads librccl in this process; only rank 0's id is used
+    except LumenError as e:
+        err = f"rank {rank}: {e}"
+    mine = (not err, err, device_identity(ctx.device), uid.tobytes() if uid is not None else b"")
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    by_dev = {}
+    for r, s_ in enumerate(seen):
+        by_dev.setdefault(s_[2], []).append(r)
+    shared = [v for v in by_dev.values() if len(v) > 1]
+    if shared or not all(s_[0] for s_ in seen):
+        why = (f"ranks {shared[0]} share one device: RCCL refuses two ranks on a device" if shared
+               else next(s_[1] for s_ in seen if not s_[0]))
+        return None, [(0, why)] * world  # nobody entered ncclCommInitRank
+    box = {}
+
+    def join():
+        try:
+            box["g"] = Group.join(ctx, rank, world, np.frombuffer(seen[0][3], dtype=np.uint8))
+        except LumenError as e:
+            box["err"] = str(e)
+
+    t = threading.Thread(target=join, daemon=True)
+    t.start()
+    t.join(deadline_s)
+    if t.is_alive():
+        sys.stderr.write(f"[bench.py] rank {rank}: still inside ncclCommInitRank after {deadline_s:.0f} s -- a peer never "
+                         f"arrived (it failed on its own and went on); exiting so that the launcher ends the job\n")
+        sys.stderr.flush()
+        os._exit(3)
+    flags = [None] * world
+    dist.all_gather_object(flags, (1 if "g" in box else 0, box.get("err", "")))
+    if all(f[0] for f in flags):
+        return box["g"], flags
+    if "g" in box:
+        box["g"].close()
+    return None, flags
+
+
 def attach_group(job, args, dist, new_nccl_group=None):
     """Puts the job's local ranks behind a lumen_group (the exchange inside the library) and returns the text of
     config.transport.  One process per GPU: rank 0 draws the communicator's id, the control-plane process group
@@ -741,40 +809,17 @@ def attach_group(job, args, dist, new_nccl_group=None):
         want = {"rccl": "auto", "copy": "copy", "torch": None}[args.transport]
         if want is None:
             raise SystemExit("bench.py: --transport torch needs one process per GPU (drop --single-process)")
-        try:
-            job.group = Group(job.ctxs, transport=want)
-        except LumenError as e:
-            if want == "copy":
-                raise
-            job.group = Group(job.ctxs, transport="copy")
-            return f"lumen_group: {job.group.transport} (RCCL could not be set up: {e})"
-        return f"lumen_group: {job.group.transport}"
+        # (LUMEN_TRANSPORT_AUTO falls back to device copies by itself when RCCL cannot be loaded or initialised)
+        job.group = Group(job.ctxs, transport=want)
+        return f"lumen_group: {job.group.transport} ({job.group.transport_note})"
     import torch
     if args.transport == "torch":
         why = "--share-gpu: RCCL refuses two ranks on one device" if args.share_gpu else "--transport torch"
         return f"torch.distributed {dist.get_backend()} on aliased device memory ({why})"
-    uid, err = np.zeros(128, dtype=np.uint8), ""
-    if job.rank == 0:
-        try:
-            uid = Group.unique_id()
-        except LumenError as e:
-            err = str(e)
-    box = [uid.tobytes(), err]
-    dist.broadcast_object_list(box, src=0)
-    ok = 0
-    if not box[1]:
-        try:
-            job.group = Group.join(job.ctx, job.rank, job.world, np.frombuffer(box[0], dtype=np.uint8))
-            ok = 1
-        except LumenError as e:
-            err = str(e)
-    flags = [None] * job.world
-    dist.all_gather_object(flags, (ok, err or box[1]))
-    if all(f[0] for f in flags):
-        return f"lumen_group: {job.group.transport} (the library's own communicator, ncclCommInitRank)"
+    group, flags = join_ranks(job.ctx, job.rank, job.world, dist)
+    job.group = group
     if job.group is not None:
-        job.group.close()
-        job.group = None
+        return f"lumen_group: {job.group.transport} (the library's own communicator, ncclCommInitRank; {job.group.transport_note})"
     reason = next(f[1] for f in flags if not f[0])
     # fall back together: the collectives of torch.distributed (RCCL) on tensors aliasing the library's memory
     # (with --share-gpu no RCCL of any kind can serve two ranks on the device: the rehearsal falls back to gloo)
@@ -903,10 +948,9 @@ def multi_rank_report(job, args, dist, per_rank_prof, sec_per_step):
                 from lumenos_amd.hip import Group
                 j.group = Group(j.ctxs, transport="copy" if job.group.transport.startswith("copy") else "rccl")
             else:
-                from lumenos_amd.hip import Group
-                box = [Group.unique_id().tobytes() if job.rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                j.group = Group.join(j.ctx, job.rank, job.world, np.frombuffer(box[0], dtype=np.uint8))
+                j.group, flags = join_ranks(j.ctx, job.rank, job.world, dist)
+                if j.group is None:  # every rank gets the same answer: all raise, none is left inside a collective
+                    raise RuntimeError("the check job's RCCL group could not be formed: " + next(f[1] for f in flags if not f[0]))
         try:
             mine["check"] = check_against_single_rank(job.ctx_device, job.world, job.rank, job.local_devices, factory, dist)
         except Exception as e:  # a failed check must not cost the measurement
@@ -1001,23 +1045,55 @@ def _kernel_table(job, ctx, cfg):
         achieved = alg_bytes_per_launch / (ms / launches * 1e-3) / 1e9
         pe = pmc_entry(pmc, dom)
         sq = (pe or {}).get("sq_per_launch") or {}
-        bfly = units / launches * job.N / 2 * job.log_n  # butterflies of one launch
         roofline = {"bound": "hbm", "limiter": "valu", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                     "traffic": round(pe["hbm_bytes_per_launch"]) if pe and pe.get("hbm_bytes_per_launch") else None,
                     "avg_launch_ms": round(ms / launches, 4), "limb_ntts_per_launch": units // launches,
-                    # what actually bounds the kernel: 64-bit modular butterflies on the VALU (no MFMA).  From
-                    # the committed SQ counters of this build (null if the profile is of another build):
-                    # fraction of SIMD cycles issuing VALU work, and wave-level VALU instructions per butterfly
-                    "valu_frac": round(pe["valu_busy_frac"], 4) if pe and pe.get("valu_busy_frac") else None,
-                    "valu_insts_per_butterfly": round(sq["SQ_INSTS_VALU"] * 64.0 / bfly, 2)
-                    if sq.get("SQ_INSTS_VALU") else None,
+                    "valu": valu_roof(job, ms, launches, units, sq),
                     "note": "`bound` names the roofline `frac` is priced against (HBM, as SURVEY 8d prescribes for every "
                             "kernel of this path); `limiter` is what actually limits the kernel: VALU issue of 64-bit "
-                            "modular butterflies.  The >= 50 % HBM target of north_star is not reachable at 10 "
-                            "multiply-adds per 64-bit Shoup product; DESIGN.md section 6 (and its pseudo-Mersenne "
-                            "experiment) has the costing"}
+                            "modular butterflies, and `valu` is that second roof, calibrated on this chip.  The >= 50 % "
+                            "HBM target of north_star is not reachable at 10 multiply-adds per 64-bit Shoup product; "
+                            "DESIGN.md section 6 (and profiles/EXPERIMENTS.md) has the costing"}
     return roofline, stages, executed
+
+
+# The VALU roof of the transform kernels, calibrated on the MI355X itself (not "4 cycles per instruction"):
+# tools/ubench_bfly.hip runs the forward butterfly stages alone -- registers only, no LDS, no global memory, the
+# product's hand-scheduled 15-instruction butterfly (10 v_mad_u64_u32 + 5) -- and needs 30.6-32.3 ns per
+# wave-butterfly per SIMD at the 4 waves per SIMD the N = 2^14 kernels run with (profiles/r02_ubench_butterfly.txt:
+# 73-78 cycles at 2.4 GHz; profiles/r04_ubench_fold.txt measures 71 / 70 / 78 at 4 / 2 / 1 waves).  The best of
+# those is the ceiling: a limb transform is N/2 * log2 N / 64 wave-butterflies, the chip has 256 CUs x 4 SIMDs.
+# Per instruction class (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt, cycles per wave-instruction per SIMD):
+# v_mad_u64_u32 5.4-5.6, other 64-bit / carry / full-rate-multiply forms 4.3-5.0, plain 32-bit ALU 2.4-2.9 -- the
+# butterfly's own mix averages 30.6 ns / 15 = 2.04 ns = 4.9 cycles, which is the price put on every VALU instruction
+# the SQ counters saw (`issue_frac`); the flat 4 cycles the counters' own "busy" figure assumes under-reads it.
+BFLY_NS_PER_WAVE_PER_SIMD = 30.6
+BFLY_INSTS = 15
+N_SIMD = 256 * 4
+
+
+def valu_roof(job, ms, launches, units, sq):
+    """roofline.valu: the butterfly-only ceiling in limb transforms per second, what the dominant kernel achieves
+    against it, and (from the committed SQ counters of this very build, else null) the fraction of the chip's VALU
+    issue time its instructions account for at the calibrated price."""
+    wave_bfly = job.N // 2 * job.log_n / 64.0                      # wave-butterflies of one limb transform
+    ceiling = N_SIMD / (wave_bfly * BFLY_NS_PER_WAVE_PER_SIMD * 1e-9)
+    got = units / (ms * 1e-3)
+    out = {"ceiling_limb_ntts_per_s": round(ceiling), "achieved_limb_ntts_per_s": round(got),
+           "frac": round(got / ceiling, 4),
+           "calibration": {"ns_per_wave_butterfly_per_simd": BFLY_NS_PER_WAVE_PER_SIMD, "insts_per_butterfly": BFLY_INSTS,
+                           "simds": N_SIMD, "source": "tools/ubench_bfly.hip, tools/ubench_valu.hip -> "
+                                                      "profiles/r02_ubench_butterfly.txt, r02_ubench_valu.txt, r04_ubench_fold.txt"},
+           "insts_per_butterfly": None, "issue_frac": None, "issue_frac_at_flat_4_cycles": None}
+    if sq.get("SQ_INSTS_VALU"):
+        insts = sq["SQ_INSTS_VALU"]                                  # wave-level VALU instructions of one launch
+        bfly_waves = units / launches * wave_bfly
+        launch_s = ms / launches * 1e-3
+        out["insts_per_butterfly"] = round(insts / bfly_waves, 2)
+        out["issue_frac"] = round(insts * (BFLY_NS_PER_WAVE_PER_SIMD / BFLY_INSTS) * 1e-9 / (launch_s * N_SIMD), 4)
+        out["issue_frac_at_flat_4_cycles"] = round(insts * 4 / 2.4e9 / (launch_s * N_SIMD), 4)
+    return out
 
 
 def plain_ntt_rates(job):

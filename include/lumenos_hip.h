@@ -76,7 +76,10 @@ int lumen_ctx_wait(lumen_ctx *ctx, lumen_ctx *other);
 /* The library's tuning switches (A/B tools; every default is the measured best; DESIGN.md "Run-time
  * switches") are read from the environment ONCE, by lumen_ctx_create; clones inherit them.  This setter is
  * the in-process form for tests and tools: name = "LUMEN_KS_BATCH", "LUMEN_KS_LANES",
- * "LUMEN_KS_FUSED_DIGITS" (value < 0: derived default), "LUMEN_CT_BLOCKS", "LUMEN_DEBUG". */
+ * "LUMEN_KS_FUSED_DIGITS" (value < 0: derived default), "LUMEN_CT_BLOCKS", "LUMEN_DEBUG"; and, for the test
+ * suite only (never read from the environment), "LUMEN_RCCL_SHARED_DEVICE": lumen_group_create then lets
+ * LUMEN_TRANSPORT_RCCL through although ranks share a device, so that the library's RCCL call sequence can be run
+ * with W > 1 on a one-GPU box against the test double tests/cpp/fake_rccl.c (real RCCL refuses such a communicator). */
 int lumen_ctx_set_tuning(lumen_ctx *ctx, const char *name, long value);
 /* Freed set storage is pooled per context and scratch buffers persist (a prover run allocates the same sizes
  * every time; mapping 25 GB per call costs 0.2 s).  lumen_ctx_trim hands all of it back to the driver -- between
@@ -337,10 +340,15 @@ int lumen_gather(lumen_ctx *ctx, const lumen_set *src, const uint32_t *idx, uint
  *                           for the two all-to-alls, ncclAllGather for the digests.  One communicator per
  *                           rank: ncclCommInitAll for a process that owns all W devices (lumen_group_create),
  *                           ncclCommInitRank for one process per GPU (lumen_group_create_rank).
- *     LUMEN_TRANSPORT_AUTO  RCCL when the W contexts sit on W distinct devices, COPY otherwise.
+ *     LUMEN_TRANSPORT_AUTO  RCCL when the W contexts sit on W distinct devices, COPY otherwise -- and COPY as well
+ *                           when RCCL cannot be loaded or refuses to initialise (a host without librccl, an IPC
+ *                           mode RCCL does not support): the W devices of one process can always exchange by
+ *                           (peer) copies.  lumen_group_transport() / _note() say what was chosen and why;
+ *                           LUMEN_TRANSPORT_RCCL asked for by name fails instead of falling back.
  * Every array argument below has lumen_group_local() entries, one per context of THIS process, in the order
  * the contexts were given (ascending global rank).  Collectives are enqueued on the contexts' own streams
- * and ordered against the work already enqueued there; nothing blocks the host unless it returns host data.
+ * and ordered against the work already enqueued there; nothing blocks the host unless it returns host data
+ * (temporaries of lumen_group_encode / _gather go back to their contexts' pools in stream order).
  * Errors: non-zero return, text through lumen_last_error(NULL) on the calling thread. */
 #define LUMEN_TRANSPORT_AUTO 0
 #define LUMEN_TRANSPORT_COPY 1
@@ -357,8 +365,13 @@ int lumen_group_create_rank(lumen_ctx *ctx, uint32_t rank, uint32_t log_world, c
 void lumen_group_destroy(lumen_group *g);
 uint32_t lumen_group_world(const lumen_group *g);
 uint32_t lumen_group_local(const lumen_group *g);
-/* "copy", "copy-peer" (several devices), "rccl" */
+/* what actually moves the blocks: "rccl"; "copy" (all ranks on one device); "copy-peer" (several devices, peer
+ * access enabled between every pair: hipMemcpyPeerAsync goes device to device over xGMI); "copy-staged" (several
+ * devices of which at least one pair has NO peer access: the runtime stages those copies through host memory --
+ * correct, but PCIe-bound; check the topology).  _note: one line on how the transport was chosen (the librccl
+ * version and init call, or why LUMEN_TRANSPORT_AUTO fell back, or the peer-access census). */
 const char *lumen_group_transport(const lumen_group *g);
+const char *lumen_group_transport_note(const lumen_group *g);
 /* ranks the RCCL communicator reports (ncclCommCount); 0 for the copy transports */
 uint32_t lumen_group_rccl_ranks(const lumen_group *g);
 /* waits for everything enqueued on every local context */
@@ -391,7 +404,14 @@ int lumen_group_digests(lumen_group *g, uint8_t *digests, size_t cap, uint32_t *
 /* the query loop of Prove (fhe/ligero.go:268-279) over column-sharded leaves: src[i] = the local rank's block
  * of S/W level-1 columns, idx = n GLOBAL column indices (duplicates allowed).  The owners gather their
  * columns and send them to rank 0, which returns them in query order as *out (a set of rank 0's context);
- * on a process that does not hold rank 0, *out = NULL. */
+ * on a process that does not hold rank 0, *out = NULL.
+ * Every rank must pass the SAME n and idx[] (each builds its half of the send / receive plan from them; the
+ * reference samples them from the one transcript, fhe/ligero.go:261-267).  With one process per GPU
+ * (lumen_group_create_rank) the call first all-gathers a fingerprint of (n, idx[]) and fails on every rank that
+ * sees a difference, instead of hanging inside RCCL -- in that form it therefore blocks the host for one tiny
+ * collective; with all ranks in one process it only enqueues.  The other collectives take their sizes from their
+ * arguments' shapes (block size, leaf count), which the ranks of a sharded Commit / Prove share by construction;
+ * passing different shapes on different processes is a caller error the library cannot see. */
 int lumen_group_gather(lumen_group *g, const lumen_set *const *src, const uint32_t *idx, uint32_t n,
                        lumen_set **out);
 /* HIP-event time of the collectives since the last reset: name = "all_to_all" (lumen_group_all_to_all),

@@ -83,6 +83,10 @@ struct lm_tuning {
     int32_t ks_fused_digits = -1; // LUMEN_KS_FUSED_DIGITS: digits packed inside k_intt_pack (-1: derive)
     uint32_t ct_blocks = 1;      // LUMEN_CT_BLOCKS: 0 = Encode through the op-by-op interpreter
     uint32_t debug = 0;          // LUMEN_DEBUG
+    // LUMEN_RCCL_SHARED_DEVICE (tests only): LUMEN_TRANSPORT_RCCL accepts ranks that share a device.  Real RCCL
+    // refuses such a communicator itself; the switch exists so that the RCCL call sequence of lm_group.hip can run
+    // with W > 1 on a one-GPU box against tests/cpp/fake_rccl.c
+    uint32_t rccl_shared_device = 0;
 };
 
 struct lumen_ctx {
@@ -129,7 +133,14 @@ struct lumen_ctx {
     std::map<std::string, std::pair<void *, size_t>> scratch;
     // freed set storage kept for reuse: a prover run allocates the same set sizes every time, and
     // mapping/unmapping tens of GB of HBM per call costs more than the kernels that fill it
-    std::multimap<size_t, void *> pool;
+    // A block may come back in STREAM ORDER (lm_set_release_async: the temporaries of a group call): `ready` is then
+    // an event behind the last work that touches it, and whoever takes the block makes the context's streams wait
+    // for it on the device -- the host never does.
+    struct pool_block {
+        void *p;
+        hipEvent_t ready;
+    };
+    std::multimap<size_t, pool_block> pool;
     size_t pool_bytes = 0;
     // kernels whose dynamic-LDS limit has already been raised on this device
     std::set<const void *> lds_attr_done;
@@ -233,6 +244,10 @@ struct lm_set_guard {
     lm_set_guard(const lm_set_guard &) = delete;
     lm_set_guard &operator=(const lm_set_guard &) = delete;
 };
+
+// gives a set back without blocking the host: its storage returns to the pool behind an event recorded on the
+// context's streams (lm_ctx.hip).  For temporaries of calls that must not wait (lumen_group_encode / _gather).
+void lm_set_release_async(lumen_ctx *ctx, lumen_set *set);
 
 // scratch buffer that persists in the context and only grows
 void *lm_scratch(lumen_ctx *ctx, const char *name, size_t bytes);

@@ -151,6 +151,16 @@ void lm_build_tw(uint64_t q, uint64_t psi, uint32_t logN, std::vector<tw_t> &fwd
     }
 }
 
+// frees the pooled storage (the caller has waited for the context's streams)
+static void pool_drain(lumen_ctx *ctx) {
+    for (auto &kv : ctx->pool) {
+        hipFree(kv.second.p);
+        if (kv.second.ready) ctx->ev_pool.push_back(kv.second.ready);
+    }
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+}
+
 // streams, events and timers: what every context owns, a clone included
 static int ctx_private_init(lumen_ctx *ctx) {
     LM_HIP(ctx, hipSetDevice(ctx->device));
@@ -174,6 +184,7 @@ static int tuning_set(lm_tuning &t, const char *name, long v) {
     else if (n == "LUMEN_KS_FUSED_DIGITS") t.ks_fused_digits = v >= 0 ? (int32_t)v : -1;
     else if (n == "LUMEN_CT_BLOCKS") t.ct_blocks = v != 0;
     else if (n == "LUMEN_DEBUG") t.debug = v != 0;
+    else if (n == "LUMEN_RCCL_SHARED_DEVICE") t.rccl_shared_device = v != 0; // tests only, never from the environment
     else return 1;
     return 0;
 }
@@ -297,7 +308,7 @@ extern "C" void lumen_ctx_destroy(lumen_ctx *ctx) {
         LM_ENTER(ctx);
         lm_sync_all(ctx);
         for (auto &kv : ctx->scratch) hipFree(kv.second.first);
-        for (auto &kv : ctx->pool) hipFree(kv.second);
+        pool_drain(ctx);
         lm_prof_resolve(ctx);
         for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
         if (ctx->tm0) hipEventDestroy(ctx->tm0);
@@ -339,9 +350,7 @@ extern "C" int lumen_ctx_trim(lumen_ctx *ctx) {
         hipFree(it->second.first);
         it = ctx->scratch.erase(it);
     }
-    for (auto &kv : ctx->pool) hipFree(kv.second);
-    ctx->pool.clear();
-    ctx->pool_bytes = 0;
+    pool_drain(ctx);
     return 0;
 }
 
@@ -380,7 +389,13 @@ extern "C" int lumen_set_create_lanes(lumen_ctx *ctx, uint32_t count, uint32_t n
         const size_t bytes = s->words * sizeof(u64);
         auto it = ctx->pool.find(bytes);
         if (it != ctx->pool.end()) { // reuse a block of exactly this size
-            s->d = (u64 *)it->second;
+            s->d = (u64 *)it->second.p;
+            if (hipEvent_t ready = it->second.ready) { // returned in stream order: whatever runs next waits on the device
+                (void)hipStreamWaitEvent(ctx->stream, ready, 0);
+                (void)hipStreamWaitEvent(ctx->stream2, ready, 0);
+                (void)hipStreamWaitEvent(ctx->stream_aux, ready, 0);
+                ctx->ev_pool.push_back(ready);
+            }
             ctx->pool.erase(it);
             ctx->pool_bytes -= bytes;
         } else {
@@ -388,9 +403,7 @@ extern "C" int lumen_set_create_lanes(lumen_ctx *ctx, uint32_t count, uint32_t n
             if (e != hipSuccess && !ctx->pool.empty()) { // give the pool back and retry once
                 (void)hipGetLastError();
                 lm_sync_all(ctx);
-                for (auto &kv : ctx->pool) hipFree(kv.second);
-                ctx->pool.clear();
-                ctx->pool_bytes = 0;
+                pool_drain(ctx);
                 e = hipMalloc((void **)&s->d, bytes);
             }
             if (e != hipSuccess) {
@@ -419,7 +432,7 @@ extern "C" void lumen_set_destroy(lumen_ctx *ctx, lumen_set *set) {
         if (set->owner && set->d) {
             const size_t bytes = set->words * sizeof(u64);
             if (ctx == set->home && ctx->pool_bytes + bytes <= ((size_t)96 << 30)) {
-                ctx->pool.emplace(bytes, set->d);
+                ctx->pool.emplace(bytes, lumen_ctx::pool_block{set->d, nullptr});
                 ctx->pool_bytes += bytes;
             } else {
                 hipFree(set->d); // never touch a context the caller did not pass
@@ -428,6 +441,32 @@ extern "C" void lumen_set_destroy(lumen_ctx *ctx, lumen_set *set) {
     } else if (set->owner && set->d) {
         hipFree(set->d); // hipFree waits for the device
     }
+    delete set;
+}
+
+// lumen_set_destroy without the host wait: the block goes back to the pool behind an event on the main stream
+// (which first waits for the second lane); lumen_set_create makes the next user's streams wait for that event.
+// Falls back to the blocking form when the block cannot be pooled or a hashing job reads it.
+void lm_set_release_async(lumen_ctx *ctx, lumen_set *set) {
+    if (!set) return;
+    LM_ENTER(ctx);
+    const size_t bytes = set->words * sizeof(u64);
+    const bool hashing = ctx->aux_digests && set->d && set->d < ctx->aux_hi && set->d + set->words > ctx->aux_lo;
+    if (!set->owner || !set->d || ctx != set->home || hashing || ctx->pool_bytes + bytes > ((size_t)96 << 30)) {
+        lumen_set_destroy(ctx, set);
+        return;
+    }
+    hipEvent_t ready = lm_ev_get(ctx);
+    bool ok = ready && hipEventRecord(ctx->ev_join, ctx->stream2) == hipSuccess &&
+              hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) == hipSuccess && hipEventRecord(ready, ctx->stream) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (ready) ctx->ev_pool.push_back(ready);
+        lumen_set_destroy(ctx, set);
+        return;
+    }
+    ctx->pool.emplace(bytes, lumen_ctx::pool_block{set->d, ready});
+    ctx->pool_bytes += bytes;
     delete set;
 }
 

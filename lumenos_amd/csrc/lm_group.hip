@@ -97,6 +97,8 @@ struct lumen_group {
     std::vector<uint32_t> rank;     // their global ranks
     int transport = LUMEN_TRANSPORT_COPY;
     bool multi_device = false;
+    bool staged = false;            // copy transport across devices of which some pair has no peer access
+    std::string note;               // how the transport was chosen (lumen_group_transport_note)
     rccl_api *rccl = nullptr;
     std::vector<ncclComm_t> comm;   // one per local context (RCCL)
     uint32_t rccl_ranks = 0;
@@ -145,6 +147,29 @@ struct group_lock {
             return lm_fail(nullptr, "%s failed: %s (%s:%d)", #call, (g)->rccl->GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
+// ncclGroupStart ... ncclGroupEnd around the sends and receives of one collective.  An early return between the two
+// (a failed ncclSend, hipSetDevice ...) must not leave the calling thread's RCCL group open: every later RCCL call of
+// that thread -- this library's or the host's own (torch's nccl in bench.py's fallback) -- would be queued behind a
+// GroupEnd that never comes.  The destructor closes what end() did not.
+struct rccl_group_scope {
+    lumen_group *g;
+    bool open = false;
+    explicit rccl_group_scope(lumen_group *grp) : g(grp) {}
+    int begin() {
+        G_NCCL(g, g->rccl->GroupStart());
+        open = true;
+        return 0;
+    }
+    int end() {
+        open = false;
+        G_NCCL(g, g->rccl->GroupEnd());
+        return 0;
+    }
+    ~rccl_group_scope() {
+        if (open) (void)g->rccl->GroupEnd();
+    }
+};
+
 int use(lumen_group *g, uint32_t i) {
     G_HIP(hipSetDevice(g->ctx[i]->device));
     return 0;
@@ -152,20 +177,30 @@ int use(lumen_group *g, uint32_t i) {
 
 // timing bracket of one collective on local rank i's stream
 void stats_resolve(lumen_group *g, bool only_done);
+// (the caller has made rank i's device current: events are created on, and recorded from, the current device)
 void time_begin(lumen_group *g, const char *name, uint32_t i, uint64_t bytes) {
     if (g->pend.size() > 512) stats_resolve(g, true); // a long run that never reads its statistics
     lumen_group::pending p;
     p.name = name, p.call = g->call_seq, p.local = i, p.bytes = bytes;
     p.a = lm_ev_get(g->ctx[i]);
     p.b = nullptr;
-    hipEventRecord(p.a, g->ctx[i]->stream);
+    if (!p.a || hipEventRecord(p.a, g->ctx[i]->stream) != hipSuccess) { // no measurement rather than a bad event in the pool
+        (void)hipGetLastError();
+        if (p.a) hipEventDestroy(p.a);
+        return;
+    }
     g->pend.push_back(p);
 }
 void time_end(lumen_group *g, uint32_t i) {
     for (auto it = g->pend.rbegin(); it != g->pend.rend(); ++it)
         if (it->local == i && it->call == g->call_seq && !it->b) {
-            it->b = lm_ev_get(g->ctx[i]);
-            hipEventRecord(it->b, g->ctx[i]->stream);
+            hipEvent_t b = lm_ev_get(g->ctx[i]);
+            if (!b || hipEventRecord(b, g->ctx[i]->stream) != hipSuccess) {
+                (void)hipGetLastError();
+                if (b) hipEventDestroy(b);
+                return; // stats_resolve drops a measurement without an end
+            }
+            it->b = b;
             return;
         }
 }
@@ -173,13 +208,25 @@ void time_end(lumen_group *g, uint32_t i) {
 // folds finished measurements into the statistics: per call the slowest local rank's time, bytes as sent by one
 // rank.  only_done: leave what is still running on the device for later (no host block)
 void stats_resolve(lumen_group *g, bool only_done = false) {
+    int dev_before = -1; // the loop below walks over the local ranks' devices: leave the caller's device current
+    (void)hipGetDevice(&dev_before);
+    struct restore {
+        int d;
+        ~restore() {
+            if (d >= 0) (void)hipSetDevice(d);
+        }
+    } restore_device{dev_before};
     std::vector<lumen_group::pending> later;
     std::map<std::pair<std::string, uint64_t>, std::pair<double, uint64_t>> per_call;
     for (auto &p : g->pend) {
         float ms = 0;
         (void)hipSetDevice(g->ctx[p.local]->device);
-        if (only_done && (!p.b || hipEventQuery(p.b) != hipSuccess)) {
+        if (only_done && p.b && hipEventQuery(p.b) != hipSuccess) {
             (void)hipGetLastError();
+            later.push_back(p);
+            continue;
+        }
+        if (only_done && !p.b && p.call == g->call_seq) { // the call that is being enqueued right now
             later.push_back(p);
             continue;
         }
@@ -282,6 +329,70 @@ extern "C" void lumen_group_destroy(lumen_group *g) {
     delete g;
 }
 
+// RCCL communicators for every rank of a one-process group; on failure `why` says what refused and nothing is left behind
+static bool rccl_init_all(lumen_group *g, std::string &why) {
+    g->rccl = rccl_load();
+    if (!g->rccl) {
+        why = g_rccl.why;
+        return false;
+    }
+    const uint32_t W = g->W;
+    std::vector<int> devs;
+    for (lumen_ctx *c : g->ctx) devs.push_back(c->device);
+    g->comm.assign(W, nullptr);
+    const ncclResult_t r = g->rccl->CommInitAll(g->comm.data(), (int)W, devs.data());
+    if (r != ncclSuccess) {
+        why = std::string("ncclCommInitAll over ") + std::to_string(W) + " devices failed: " + g->rccl->GetErrorString(r) +
+              " (hosts whose driver only does dmabuf IPC need HSA_ENABLE_IPC_MODE_LEGACY=0 in the process environment; "
+              "NCCL_DEBUG=WARN prints RCCL's own reason)";
+        g->comm.clear();
+        return false;
+    }
+    int cnt = 0;
+    const ncclResult_t rc = g->rccl->CommCount(g->comm[0], &cnt);
+    if (rc != ncclSuccess || (uint32_t)cnt != W) {
+        why = "the RCCL communicator reports " + std::to_string(cnt) + " ranks, expected " + std::to_string(W);
+        for (uint32_t i = 0; i < W; i++)
+            if (g->comm[i]) {
+                (void)hipSetDevice(g->ctx[i]->device);
+                g->rccl->CommDestroy(g->comm[i]);
+            }
+        g->comm.clear();
+        return false;
+    }
+    g->rccl_ranks = (uint32_t)cnt;
+    int ver = 0;
+    (void)g->rccl->GetVersion(&ver);
+    g->note = "rccl: librccl version " + std::to_string(ver) + ", ncclCommInitAll over " + std::to_string(W) + " devices";
+    return true;
+}
+
+// copy transport across several devices: peer access where the hardware offers it (xGMI: hipMemcpyPeerAsync then moves
+// device to device); a pair without it still works -- the runtime stages such copies through host memory -- but the
+// group says so ("copy-staged") instead of passing for a device-to-device exchange
+static int peer_setup(lumen_group *g) {
+    uint32_t pairs = 0, direct = 0;
+    for (uint32_t i = 0; i < g->ctx.size(); i++)
+        for (uint32_t j = 0; j < g->ctx.size(); j++) {
+            const int di = g->ctx[i]->device, dj = g->ctx[j]->device;
+            if (di == dj) continue;
+            pairs++;
+            int can = 0;
+            G_HIP(hipDeviceCanAccessPeer(&can, di, dj));
+            if (!can) continue;
+            G_HIP(hipSetDevice(di));
+            const hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else if (e != hipSuccess)
+                return lm_fail(nullptr, "lumen_group_create: hipDeviceEnablePeerAccess(%d -> %d) failed: %s", di, dj, hipGetErrorString(e));
+            direct++;
+        }
+    g->staged = direct < pairs;
+    if (pairs) g->note += (g->note.empty() ? "" : "; ") + std::string("peer access on ") + std::to_string(direct) + " of " +
+                          std::to_string(pairs) + " device pairs";
+    return 0;
+}
+
 extern "C" int lumen_group_create(lumen_ctx *const *ctxs, uint32_t log_world, uint32_t transport, lumen_group **out) {
     LM_CHECK(nullptr, ctxs && out, "lumen_group_create: NULL argument");
     *out = nullptr;
@@ -298,8 +409,11 @@ extern "C" int lumen_group_create(lumen_ctx *const *ctxs, uint32_t log_world, ui
     LM_CHECK(nullptr, W == 1 || (ctxs[0]->N >> log_world) >= 64,
              "lumen_group_create: a lane shard of 1/%u of N = %u is narrower than 64 coefficients", W, ctxs[0]->N);
     const bool distinct = devices.size() == W;
-    if (transport == LUMEN_TRANSPORT_AUTO) transport = (distinct && W > 1) ? LUMEN_TRANSPORT_RCCL : LUMEN_TRANSPORT_COPY;
-    LM_CHECK(nullptr, transport != LUMEN_TRANSPORT_RCCL || distinct,
+    const bool automatic = transport == LUMEN_TRANSPORT_AUTO;
+    // (the shared-device exception is a test switch: real RCCL refuses such a communicator itself)
+    const bool rccl_possible = distinct || ctxs[0]->tune.rccl_shared_device;
+    if (automatic) transport = (rccl_possible && W > 1) ? LUMEN_TRANSPORT_RCCL : LUMEN_TRANSPORT_COPY;
+    LM_CHECK(nullptr, transport != LUMEN_TRANSPORT_RCCL || rccl_possible,
              "lumen_group_create: RCCL needs every rank on its own device (%zu devices for %u ranks); use LUMEN_TRANSPORT_COPY", devices.size(), W);
     std::unique_ptr<lumen_group, void (*)(lumen_group *)> guard(new lumen_group(), lumen_group_destroy);
     lumen_group *g = guard.get();
@@ -308,34 +422,18 @@ extern "C" int lumen_group_create(lumen_ctx *const *ctxs, uint32_t log_world, ui
     group_lock lk(g);
     if (group_finish_create(g)) return 1;
     if (transport == LUMEN_TRANSPORT_RCCL) {
-        g->rccl = rccl_load();
-        LM_CHECK(nullptr, g->rccl, "lumen_group_create: RCCL transport unavailable: %s", g_rccl.why.c_str());
-        std::vector<int> devs;
-        for (lumen_ctx *c : g->ctx) devs.push_back(c->device);
-        g->comm.assign(W, nullptr);
-        {
-            const ncclResult_t r = g->rccl->CommInitAll(g->comm.data(), (int)W, devs.data());
-            LM_CHECK(nullptr, r == ncclSuccess,
-                     "ncclCommInitAll over %u devices failed: %s (hosts whose driver only does dmabuf IPC need "
-                     "HSA_ENABLE_IPC_MODE_LEGACY=0 in the process environment; NCCL_DEBUG=WARN prints RCCL's own reason)", W,
-                     g->rccl->GetErrorString(r));
+        std::string why;
+        if (!rccl_init_all(g, why)) {
+            // asked for by name: an error.  Chosen by LUMEN_TRANSPORT_AUTO: the W devices of one process can always
+            // exchange by (peer) copies -- a host without librccl, or whose RCCL refuses to initialise, still runs
+            LM_CHECK(nullptr, automatic, "lumen_group_create: RCCL transport unavailable: %s", why.c_str());
+            (void)hipGetLastError();
+            g->transport = LUMEN_TRANSPORT_COPY, g->rccl = nullptr, g->rccl_ranks = 0;
+            g->note = "auto: fell back to device copies, RCCL unavailable: " + why;
         }
-        int cnt = 0;
-        G_NCCL(g, g->rccl->CommCount(g->comm[0], &cnt));
-        g->rccl_ranks = (uint32_t)cnt;
-        LM_CHECK(nullptr, g->rccl_ranks == W, "lumen_group_create: the RCCL communicator reports %u ranks, expected %u", g->rccl_ranks, W);
-    } else if (g->multi_device) {
-        // peer access where the hardware offers it (xGMI): hipMemcpyPeerAsync then copies device to device
-        for (uint32_t i = 0; i < W; i++)
-            for (uint32_t j = 0; j < W; j++) {
-                const int di = g->ctx[i]->device, dj = g->ctx[j]->device;
-                int can = 0;
-                if (di == dj || hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess || !can) continue;
-                (void)hipSetDevice(di);
-                (void)hipDeviceEnablePeerAccess(dj, 0); // "already enabled" is fine
-                (void)hipGetLastError();
-            }
     }
+    if (g->transport == LUMEN_TRANSPORT_COPY && g->multi_device && peer_setup(g)) return 1;
+    if (g->note.empty()) g->note = g->transport == LUMEN_TRANSPORT_COPY ? "stream-ordered copies on one device" : "";
     *out = guard.release();
     return 0;
 }
@@ -384,6 +482,9 @@ extern "C" int lumen_group_create_rank(lumen_ctx *ctx, uint32_t rank, uint32_t l
     G_NCCL(g, g->rccl->CommCount(g->comm[0], &cnt));
     g->rccl_ranks = (uint32_t)cnt;
     LM_CHECK(nullptr, g->rccl_ranks == W, "lumen_group_create_rank: the RCCL communicator reports %u ranks, expected %u", g->rccl_ranks, W);
+    int ver = 0;
+    (void)g->rccl->GetVersion(&ver);
+    g->note = "rccl: librccl version " + std::to_string(ver) + ", ncclCommInitRank " + std::to_string(rank) + " of " + std::to_string(W);
     *out = guard.release();
     return 0;
 }
@@ -393,8 +494,10 @@ extern "C" uint32_t lumen_group_local(const lumen_group *g) { return g ? (uint32
 extern "C" uint32_t lumen_group_rccl_ranks(const lumen_group *g) { return g ? g->rccl_ranks : 0; }
 extern "C" const char *lumen_group_transport(const lumen_group *g) {
     if (!g) return "";
-    return g->transport == LUMEN_TRANSPORT_RCCL ? "rccl" : (g->multi_device ? "copy-peer" : "copy");
+    if (g->transport == LUMEN_TRANSPORT_RCCL) return "rccl";
+    return !g->multi_device ? "copy" : (g->staged ? "copy-staged" : "copy-peer");
 }
+extern "C" const char *lumen_group_transport_note(const lumen_group *g) { return g ? g->note.c_str() : ""; }
 
 extern "C" int lumen_group_sync(lumen_group *g) {
     LM_CHECK(nullptr, g, "lumen_group_sync: NULL group");
@@ -417,7 +520,8 @@ static int all_to_all_raw(lumen_group *g, const std::vector<const u64 *> &send, 
             if (use(g, i)) return 1;
             time_begin(g, stat_name, i, sent);
         }
-        G_NCCL(g, g->rccl->GroupStart());
+        rccl_group_scope grp(g);
+        if (grp.begin()) return 1;
         for (uint32_t i = 0; i < n; i++) {
             if (use(g, i)) return 1;
             for (uint32_t p = 0; p < W; p++) {
@@ -425,7 +529,7 @@ static int all_to_all_raw(lumen_group *g, const std::vector<const u64 *> &send, 
                 G_NCCL(g, g->rccl->Recv(recv[i] + (size_t)p * blk_words, blk_words, ncclUint64, (int)p, g->comm[i], g->ctx[i]->stream));
             }
         }
-        G_NCCL(g, g->rccl->GroupEnd());
+        if (grp.end()) return 1;
         for (uint32_t i = 0; i < n; i++) {
             if (use(g, i)) return 1;
             time_end(g, i);
@@ -482,7 +586,12 @@ extern "C" int lumen_group_all_to_all(lumen_group *g, const lumen_set *const *se
 
 // ---- fhe.Encode over column-sharded input (include/lumenos_hip.h)
 namespace {
-struct set_bin { // temporaries of a group call: destroyed (through their contexts) when the call ends
+// temporaries of a group call: handed back when the call ends, in STREAM ORDER -- their storage returns to the
+// owning context's pool behind an event on its stream (lm_set_release_async), so the call returns with its work
+// enqueued and the host goes on to enqueue the rescale and the leaf hashing of every rank (lumen_set_destroy would
+// wait for every rank's Encode here).  Other ranks' reads of a temporary are ordered before that event: the
+// copy transport makes the source's stream wait for every destination (done_all), RCCL sends from the owner's stream.
+struct set_bin {
     std::vector<std::pair<lumen_ctx *, lumen_set *>> v;
     lumen_set *keep(lumen_ctx *c, lumen_set *s) {
         v.emplace_back(c, s);
@@ -491,7 +600,7 @@ struct set_bin { // temporaries of a group call: destroyed (through their contex
     ~set_bin() {
         for (auto &p : v) {
             (void)hipSetDevice(p.first->device);
-            lumen_set_destroy(p.first, p.second);
+            lm_set_release_async(p.first, p.second);
         }
     }
 };
@@ -558,7 +667,7 @@ extern "C" int lumen_group_encode(lumen_group *g, const lumen_set *const *matrix
         }
     }
     for (uint32_t i = 0; i < n; i++) encoded[i] = mine[i];
-    return 0; // `bin` gives the temporaries back (each destroy waits for its own context's stream only)
+    return 0; // `bin` gives the temporaries back in stream order: nothing here waits for the device
 }
 
 // ---- Commit's exchange: all-gather of the leaf digests
@@ -593,12 +702,13 @@ extern "C" int lumen_group_all_gather_digests(lumen_group *g) {
     }
     g->n_per_rank = per;
     if (g->transport == LUMEN_TRANSPORT_RCCL) {
-        G_NCCL(g, g->rccl->GroupStart());
+        rccl_group_scope grp(g);
+        if (grp.begin()) return 1;
         for (uint32_t i = 0; i < n; i++) {
             if (use(g, i)) return 1;
             G_NCCL(g, g->rccl->AllGather(src[i], g->d_digests[i], part, ncclUint8, g->comm[i], g->ctx[i]->stream));
         }
-        G_NCCL(g, g->rccl->GroupEnd());
+        if (grp.end()) return 1;
     } else {
         if (ready_all(g)) return 1;
         std::vector<uint32_t> all;
@@ -670,6 +780,43 @@ extern "C" int lumen_group_gather(lumen_group *g, const lumen_set *const *src, c
             perm[k] = off[p] + seen[p]++;
         }
     }
+    // One process per GPU: every process derives the send / receive plan from the idx IT was given.  Ranks that
+    // disagree would post sends without matching receives and sit inside RCCL for good, so the processes first
+    // all-gather a fingerprint of (n, idx[]) -- a fixed-size exchange that cannot mismatch -- and compare on the host.
+    // (This makes the call block the host in that form; with all ranks in one process there is one idx.)
+    if (n < W && g->transport == LUMEN_TRANSPORT_RCCL) {
+        uint64_t fp = 1469598103934665603ull ^ nq;
+        for (uint32_t k = 0; k < nq; k++) fp = (fp ^ idx[k]) * 1099511628211ull;
+        std::vector<u64 *> dbuf(n);
+        for (uint32_t i = 0; i < n; i++) {
+            lumen_ctx *c = g->ctx[i];
+            if (use(g, i)) return 1;
+            dbuf[i] = (u64 *)lm_scratch(c, "gather_agree", 8 * (size_t)(W + 1));
+            u64 *h = (u64 *)lm_stage(c, 8);
+            if (!dbuf[i] || !h) return 1;
+            *h = fp;
+            G_HIP(hipMemcpyAsync(dbuf[i] + W, h, 8, hipMemcpyHostToDevice, c->stream));
+            G_HIP(hipEventRecord(c->ev_stage, c->stream));
+        }
+        {
+            rccl_group_scope grp(g);
+            if (grp.begin()) return 1;
+            for (uint32_t i = 0; i < n; i++) {
+                if (use(g, i)) return 1;
+                G_NCCL(g, g->rccl->AllGather(dbuf[i] + W, dbuf[i], 1, ncclUint64, g->comm[i], g->ctx[i]->stream));
+            }
+            if (grp.end()) return 1;
+        }
+        std::vector<uint64_t> seen(W);
+        for (uint32_t i = 0; i < n; i++) {
+            if (use(g, i)) return 1;
+            G_HIP(hipMemcpyAsync(seen.data(), dbuf[i], 8 * (size_t)W, hipMemcpyDeviceToHost, g->ctx[i]->stream));
+            G_HIP(hipStreamSynchronize(g->ctx[i]->stream));
+            for (uint32_t p = 0; p < W; p++)
+                LM_CHECK(nullptr, seen[p] == fp, "lumen_group_gather: rank %u was given other query indices than rank %u (every rank "
+                         "must pass the same n and idx[])", p, g->rank[i]);
+        }
+    }
     g->call_seq++;
     set_bin bin;
     std::vector<lumen_set *> q(n, nullptr);
@@ -694,7 +841,8 @@ extern "C" int lumen_group_gather(lumen_group *g, const lumen_set *const *src, c
             if (use(g, 0)) return 1;
             G_HIP(hipMemcpyAsync(stage->d, q[0]->d, q[0]->words * 8, hipMemcpyDeviceToDevice, g->ctx[0]->stream));
         }
-        G_NCCL(g, g->rccl->GroupStart());
+        rccl_group_scope grp(g);
+        if (grp.begin()) return 1;
         for (uint32_t i = 0; i < n; i++) {
             if (use(g, i)) return 1;
             if (g->rank[i] != 0 && q[i])
@@ -707,7 +855,7 @@ extern "C" int lumen_group_gather(lumen_group *g, const lumen_set *const *src, c
                     G_NCCL(g, g->rccl->Recv(stage->d + (size_t)off[p] * ctw, (size_t)(off[p + 1] - off[p]) * ctw, ncclUint64, (int)p,
                                             g->comm[0], g->ctx[0]->stream));
         }
-        G_NCCL(g, g->rccl->GroupEnd());
+        if (grp.end()) return 1;
     } else {
         if (ready_all(g)) return 1;
         if (use(g, 0) || wait_ready(g, 0)) return 1;

@@ -472,12 +472,12 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
 #pragma unroll
             for (int k = 0; k < RUN; k++)
                 if (k < count) {
-                    // u' - lift * P^-1 = u' + lift * (-P^-1) (u' = u * P^-1 comes out of the gadget product, see
-                    // lumen_load_galois_key); the multiplication takes the unreduced lift: result < 4q
-                    u64 x = lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq, uv[k]);
-                    x = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
-                    if (w == 0) x = lm_addmod(x, cv[k], qc.q);
-                    sm[LM_PAD(i0 + k)] = x; // the slots this work item just consumed
+                    // u' - lift * P^-1 = u' + lift * (-P^-1) (u' = u * P^-1 < q comes out of the gadget product, see
+                    // lumen_load_galois_key); the multiplication takes the unreduced lift and leaves [0, 3q) on top
+                    // of its addend: u' (+ c0 < 2q for w == 0).  NOTHING is reduced here -- d < 6q goes to LDS as it
+                    // is, and the one reduction of a rotation happens where the accumulator word is formed (below).
+                    const u64 add = w == 0 ? uv[k] + cv[k] : uv[k];
+                    sm[LM_PAD(i0 + k)] = lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq, add); // the slots this work item just consumed
                 }
         }
     } st{uq, ain, sm, qc, pi, w, {}, {}};
@@ -499,17 +499,42 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
 #pragma unroll
         for (uint32_t k = 0; k < IT; k++) {
             const uint32_t j = 2 * tid + k * 2 * nthreads;
+            // the accumulator is LAZY across the rotations of an InnerSum: words in [0, 2q).  acc (< 2q) + d (< 6q)
+            // < 8q comes back under 2q with two conditional subtractions -- the only ones of the kernel (the
+            // canonical form cost four per coefficient of c0 and three of c1: d to [0, q), + c0, + acc).  Its
+            // readers take [0, 2q): the inverse transform's loader (< 3q), the gadget product's own-digit operand
+            // (any u64), this kernel, and the rescale that ends matrixInnerSumEval (lm_rescale.hip).
             ulonglong2 y;
-            y.x = lm_addmod(x[k].x, sm[LM_PAD(p[k].x)], qc.q);
-            y.y = lm_addmod(x[k].y, sm[LM_PAD(p[k].y)], qc.q);
+            y.x = lm_csub(lm_csub(x[k].x + sm[LM_PAD(p[k].x)], 4 * qc.q), 2 * qc.q);
+            y.y = lm_csub(lm_csub(x[k].y + sm[LM_PAD(p[k].y)], 4 * qc.q), 2 * qc.q);
             *reinterpret_cast<ulonglong2 *>(aout + j) = y;
         }
     };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st, after);
 }
 
+// words of a lazy accumulator ([0, 2q), see k_moddown_ntt) to canonical form: for the callers that hand the
+// accumulator out as it is (lumen_inner_sum; matrixInnerSumEval when there is no limb to drop).  Elementwise,
+// [count][2][L][N], 16-byte accesses.
+__global__ __launch_bounds__(256) void k_acc_canon(u64 *__restrict__ acc, size_t pairs, uint32_t logN, uint32_t L, lm_mods mods) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < pairs; g += stride) {
+        const u64 q = mods.m[(uint32_t)((g >> (logN - 1)) % L)].q;
+        ulonglong2 v = *reinterpret_cast<ulonglong2 *>(acc + 2 * g);
+        v.x = lm_csub(v.x, q), v.y = lm_csub(v.y, q);
+        *reinterpret_cast<ulonglong2 *>(acc + 2 * g) = v;
+    }
+}
+
 // -------------------------------------------------------------------- host side
 namespace {
+
+int acc_canon(lumen_ctx *ctx, u64 *acc, size_t words, uint32_t L) {
+    if (!words) return 0;
+    hipLaunchKernelGGL(k_acc_canon, dim3(2048), dim3(256), 0, ctx->stream, acc, words / 2, ctx->logN, L, ctx->mods);
+    LM_HIP(ctx, hipGetLastError());
+    return 0;
+}
 
 struct KsTables {
     bx_t *d_bx = nullptr;    // [beta][L+K]
@@ -1047,13 +1072,28 @@ extern "C" int lumen_load_galois_key_ex(lumen_ctx *ctx, uint64_t gal_el, const u
         const uint64_t t2 = ((gal_el * t1 & mask) - 1) >> 1;
         index[i] = h_bitrev((uint32_t)t2, (int)ctx->logN);
     }
+    { // the staging copy of the host words has served (the stream is idle): do not keep a key-sized block per context
+        auto it = ctx->scratch.find("key_raw");
+        if (it != ctx->scratch.end()) {
+            hipFree(it->second.first);
+            ctx->scratch.erase(it);
+        }
+    }
     LM_SHARED_LOCK(ctx);
     lm_galois_key &gk = ctx->gkeys[gal_el];
-    if (gk.d_key) { // a key loaded again: nothing enqueued may still read the old words
+    if (gk.d_key) {
+        // a key loaded again.  The table is shared with every clone (group ranks on one GPU, CopyNew): its device
+        // pointer must stay what a clone may have read a moment ago, so the new words are copied INTO the old
+        // block (same size: it only depends on the parameters).  A clone computing at this very moment sees old or
+        // new words -- the documented "do not reconfigure under a running clone" -- but never freed memory.
         lm_sync_all(ctx);
-        hipFree(gk.d_key);
+        hipError_t ce = hipMemcpyAsync(gk.d_key, d_new, words * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+        hipFree(d_new);
+        LM_CHECK(ctx, ce == hipSuccess, "replacing Galois key %llu failed: %s", (unsigned long long)gal_el, hipGetErrorString(ce));
+    } else {
+        gk.d_key = d_new;
     }
-    gk.d_key = d_new;
     if (!gk.d_index) LM_HIP(ctx, hipMalloc((void **)&gk.d_index, (size_t)N * 4));
     if (!gk.d_inv_index) LM_HIP(ctx, hipMalloc((void **)&gk.d_inv_index, (size_t)N * 4));
     std::vector<uint32_t> inv_index(N);
@@ -1112,6 +1152,7 @@ extern "C" int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, 
         const uint32_t B = std::min(Bmax, in->count - first);
         if (int rc = inner_sum_batch(ctx, o->d + (size_t)first * ctw, B, n, tb, s)) return rc;
     }
+    if (int rc = acc_canon(ctx, o->d, o->words, in->nl)) return rc; // the rotations leave [0, 2q)
     *out = og.release();
     return 0;
 }
@@ -1168,6 +1209,7 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
         if (L > target) {
             if (int rc = lm_rescale_polys(ctx, acc, L, o->d + (size_t)g0 * octw, target, gn * 2, work, tbuf)) return rc;
         } else {
+            if (int rc = acc_canon(ctx, acc, (size_t)gn * ctw, L)) return rc; // no rescale to absorb the lazy range
             LM_HIP(ctx, hipMemcpyAsync(o->d + (size_t)g0 * octw, acc, (size_t)gn * ctw * 8, hipMemcpyDeviceToDevice,
                                        ctx->stream));
         }

@@ -107,6 +107,7 @@ SYMBOLS = {
     "lumen_group_world": (C.c_uint32, [_vp]),
     "lumen_group_local": (C.c_uint32, [_vp]),
     "lumen_group_transport": (C.c_char_p, [_vp]),
+    "lumen_group_transport_note": (C.c_char_p, [_vp]),
     "lumen_group_rccl_ranks": (C.c_uint32, [_vp]),
     "lumen_group_sync": (C.c_int, [_vp]),
     "lumen_group_all_to_all": (C.c_int, [_vp, _vpp, _vpp]),
@@ -683,6 +684,10 @@ class Group:
     @property
     def transport(self):
         return self.lib.lumen_group_transport(self.h).decode()
+
+    @property
+    def transport_note(self):
+        return self.lib.lumen_group_transport_note(self.h).decode()
 
     @property
     def rccl_ranks(self):

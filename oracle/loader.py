@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liblumen_oracle.so")
+# LUMEN_ORACLE_LIB: another build of the same sources (oracle/_san/liblumen_oracle.so from `make san`,
+# tests/test_sanitizers.py)
+_LIB = os.environ.get("LUMEN_ORACLE_LIB") or os.path.join(_HERE, "liblumen_oracle.so")
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)

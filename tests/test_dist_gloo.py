@@ -171,27 +171,38 @@ def test_lane_sharded_exchange_world8():
     _run_lane_world(8)
 
 
-def _attach_worker(rank, world, port, fail_rank, out):
+def _attach_worker(rank, world, port, mode, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import argparse
+    import time
+    import types
     import bench
     import lumenos_amd.hip as hip
 
-    class FakeGroup:  # the library's group as attach_group uses it; joining fails on one rank if asked to
+    class FakeGroup:  # the library's group as bench.join_ranks uses it; what fails, and where, is the test's `mode`
         transport = "rccl"
+        transport_note = "fake"
         closed = False
+        join_calls = 0
 
         @staticmethod
         def unique_id():
-            return np.arange(128, dtype=np.uint8)
+            if mode == "no_librccl_on_1" and rank == 1:
+                raise hip.LumenError("dlopen(librccl.so.1) failed")
+            return np.arange(128, dtype=np.uint8) + (0 if rank == 0 else 1)  # only rank 0's id may be used
 
         @classmethod
         def join(cls, ctx, r, w, uid):
+            cls.join_calls += 1
             assert np.array_equal(uid, np.arange(128, dtype=np.uint8)), "the id rank 0 drew reaches every rank"
-            if r == fail_rank:
+            if mode == "join_fails_on_1" and r == 1:
                 raise hip.LumenError(f"ncclCommInitRank failed on rank {r}")
+            if mode == "rank1_fails_rank0_blocks":  # the asymmetric case: a healthy rank waits inside ncclCommInitRank
+                if r == 1:
+                    raise hip.LumenError("ncclCommInitRank failed on rank 1")
+                time.sleep(3600)
             return cls()
 
         def close(self):
@@ -203,37 +214,68 @@ def _attach_worker(rank, world, port, fail_rank, out):
         pass
 
     job = J()
-    job.rank, job.world, job.ctx, job.group = rank, world, None, None
+    job.rank, job.world, job.group = rank, world, None
+    job.ctx = types.SimpleNamespace(device=0 if mode == "shared_device" else rank)
     args = argparse.Namespace(transport="rccl", share_gpu=False)
     text = bench.attach_group(job, args, dist, new_nccl_group=lambda: "nccl-subgroup")
-    out.put((rank, text, job.group is not None, getattr(job, "nccl_pg", None), FakeGroup.closed))
+    out.put((rank, text, job.group is not None, getattr(job, "nccl_pg", None), FakeGroup.closed, FakeGroup.join_calls))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fail_rank", [-1, 1])
-def test_ranks_agree_on_the_transport(fail_rank):
-    """bench.attach_group under gloo, world 2: the id of the library's RCCL communicator travels from rank 0 over the
-    control plane; when every rank joins, all run the in-library path; when ONE rank cannot, ALL fall back to the
-    torch.distributed path together (a rank left alone in the other path would wait in a collective for ever) and
-    config.transport says why."""
+def _run_attach(mode, env=None):
     world = 2
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_attach_worker, args=(r, world, port, fail_rank, out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(out.get(timeout=180) for _ in range(world))
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        procs = [ctx.Process(target=_attach_worker, args=(r, world, port, mode, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return procs, out
+
+
+@pytest.mark.parametrize("mode", ["all_join", "join_fails_on_1", "no_librccl_on_1", "shared_device"])
+def test_ranks_agree_on_the_transport(mode):
+    """bench.attach_group / join_ranks under gloo, world 2.  What can be checked locally is agreed BEFORE anybody
+    enters ncclCommInitRank: a rank without a usable librccl, or two ranks on one device, and NO rank joins.  Then the
+    id of rank 0 travels over the control plane; when every rank joins, all run the in-library path; when one rank's
+    join fails, ALL fall back to the torch.distributed path together (a rank left alone in the other path would wait
+    in a collective for ever) and config.transport says why."""
+    procs, out = _run_attach(mode)
+    res = sorted(out.get(timeout=180) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, text, has_group, pg, closed in res:
-        if fail_rank < 0:
-            assert text.startswith("lumen_group: rccl") and has_group and pg is None
+    for rank, text, has_group, pg, closed, join_calls in res:
+        if mode == "all_join":
+            assert text.startswith("lumen_group: rccl") and has_group and pg is None and join_calls == 1
+            continue
+        assert "FALLBACK" in text and not has_group and pg == "nccl-subgroup", text
+        if mode == "join_fails_on_1":
+            assert "ncclCommInitRank failed on rank 1" in text and join_calls == 1
+            assert closed == (rank != 1)  # the rank that had joined gave its group back
+        elif mode == "no_librccl_on_1":
+            assert "rank 1: dlopen(librccl.so.1) failed" in text and join_calls == 0
         else:
-            assert "FALLBACK" in text and "ncclCommInitRank failed on rank 1" in text
-            assert not has_group and pg == "nccl-subgroup"
-            assert closed == (rank != fail_rank)  # the rank that had joined gave its group back
+            assert "ranks [0, 1] share one device" in text and join_calls == 0
+
+
+def test_a_rank_left_alone_in_the_join_ends_the_job():
+    """The asymmetric failure: rank 1's ncclCommInitRank fails, rank 0's waits for a peer that will never come.  Rank 0
+    must not sit there until the control plane times out: after LUMEN_BENCH_JOIN_TIMEOUT it exits non-zero (exit code
+    3), which makes torch.distributed.run end the whole job."""
+    procs, _ = _run_attach("rank1_fails_rank0_blocks", env={"LUMEN_BENCH_JOIN_TIMEOUT": "3"})
+    procs[0].join(timeout=120)
+    assert procs[0].exitcode == 3
+    procs[1].join(timeout=5)  # rank 1 waits for rank 0 in the control-plane gather: the launcher would kill it
+    if procs[1].is_alive():
+        procs[1].terminate()
+        procs[1].join(timeout=30)
 
 
 def test_bench_launches_its_own_ranks():

@@ -1,7 +1,15 @@
 """The multi-GPU group API (include/lumenos_hip.h "lumen_group") on ONE GPU: W contexts on device 0
 play the W ranks of a single host process -- the reference's topology, one process that owns the request
 (cmd/server/main.go:187-266) -- and the exchange steps run inside the library (copy transport: RCCL refuses two
-ranks on one device).  Everything is held to the single-context result, itself bit-exact against the oracle."""
+ranks on one device).  Everything is held to the single-context result, itself bit-exact against the oracle.
+
+The same file runs a second time, in a child process, through the library's RCCL branch with W = 2, 4, 8
+(tests/test_group_rccl.py: LUMEN_TEST_GROUP_TRANSPORT=rccl, the test double tests/cpp/fake_rccl.cpp first on
+LD_LIBRARY_PATH, the test-only switch LUMEN_RCCL_SHARED_DEVICE): every assertion below then holds for the grouped
+ncclSend / ncclRecv, ncclAllGather and gather-to-root call sequences too."""
+import os
+import threading
+
 import numpy as np
 import pytest
 
@@ -9,13 +17,26 @@ from tests.helpers import T_REF, make_context, make_params, random_cts
 
 pytestmark = pytest.mark.gpu
 
+TRANSPORT = os.environ.get("LUMEN_TEST_GROUP_TRANSPORT", "copy")
+FAKE = TRANSPORT == "rccl"  # the child process of tests/test_group_rccl.py
+FAKE_VERSION = "99999"      # what tests/cpp/fake_rccl.cpp answers to ncclGetVersion
+
 
 @pytest.fixture(scope="module")
 def small(oracle):
     P = make_params(oracle, 10, 3)
     ctx = make_context(P)
+    if FAKE:
+        ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 1)  # clones inherit it
     yield P, ctx
     ctx.close()
+
+
+def check_transport(g, world):
+    if FAKE:
+        assert g.transport == "rccl" and g.rccl_ranks == world and FAKE_VERSION in g.transport_note, g.transport_note
+    else:
+        assert g.transport == "copy" and g.rccl_ranks == 0 and "one device" in g.transport_note
 
 
 def ranks_of(ctx, world):
@@ -28,8 +49,9 @@ def test_group_all_to_all_routes_blocks(small, world):
     from lumenos_amd.hip import Group
     P, ctx = small
     ctxs = ranks_of(ctx, world)
-    g = Group(ctxs, transport="copy")
-    assert g.transport == "copy" and g.world == world and g.rccl_ranks == 0
+    g = Group(ctxs, transport=TRANSPORT)
+    check_transport(g, world)
+    assert g.world == world
     n, nl = 3 * world, 2
     host = [random_cts(P, n, nl, seed=300 + r) for r in range(world)]
     send = [c.upload(h) for c, h in zip(ctxs, host)]
@@ -67,7 +89,8 @@ def test_group_commit_matches_single_context(oracle, small, world):
     opened = ctx.gather(lvl1, idx).download()
 
     ctxs = ranks_of(ctx, world)
-    g = Group(ctxs, transport="copy")
+    g = Group(ctxs, transport=TRANSPORT)
+    check_transport(g, world)
     own = [cx.upload(m[r * c:(r + 1) * c]) for r, cx in enumerate(ctxs)]
     enc = g.encode(own, zero, rho)
     for r in range(world):
@@ -95,7 +118,7 @@ def test_group_upload_download(small):
     from lumenos_amd.hip import Group, pinned_empty, pinned_free
     P, ctx = small
     ctxs = ranks_of(ctx, 4)
-    g = Group(ctxs, transport="copy")
+    g = Group(ctxs, transport=TRANSPORT)
     host = [random_cts(P, 5, 2, seed=700 + r) for r in range(4)]
     pinned = []
     for r in (0, 2):  # two ranks from page-locked memory, two from ordinary arrays
@@ -124,12 +147,16 @@ def test_group_refuses_what_it_cannot_serve(oracle, small):
     from lumenos_amd.hip import Group, LumenError
     P, ctx = small
     twin = ctx.clone()
+    if FAKE:
+        ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 0)
     with pytest.raises(LumenError, match="RCCL needs every rank on its own device"):
         Group([ctx, twin], transport="rccl")
     with pytest.raises(LumenError, match="same context"):
         Group([ctx, ctx], transport="copy")
     g = Group([ctx, twin], transport="auto")  # two ranks on one device: copies
-    assert g.transport == "copy"
+    assert g.transport == "copy" and g.transport_note == "stream-ordered copies on one device"
+    if FAKE:
+        ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 1)
     a, b = ctx.new_set(4, 2), twin.new_set(6, 2)
     with pytest.raises(LumenError, match="differ in size"):
         g.all_to_all([a, b], [ctx.new_set(4, 2), twin.new_set(6, 2)])
@@ -152,7 +179,8 @@ def test_group_rccl_world_of_one(small):
     from lumenos_amd.hip import Group
     P, ctx = small
     g = Group([ctx], transport="rccl")
-    assert g.transport == "rccl" and g.rccl_ranks == 1
+    assert g.transport == "rccl" and g.rccl_ranks == 1 and "librccl version" in g.transport_note
+    assert (FAKE_VERSION in g.transport_note) == FAKE, g.transport_note
     host = random_cts(P, 5, 2, seed=7)
     send, recv = ctx.upload(host), ctx.new_set(5, 2)
     g.all_to_all([send], [recv])
@@ -169,3 +197,146 @@ def test_group_rccl_world_of_one(small):
     g1.all_to_all([send], [recv])
     g1.sync()
     g1.close()
+
+
+# ---- one process per GPU (lumen_group_create_rank): W host threads play the W processes.  Needs an RCCL that
+# accepts ranks sharing the one device, i.e. the test double -- these cases run in test_group_rccl.py's child only.
+needs_fake = pytest.mark.skipif(not FAKE, reason="the per-rank form with W > 1 on one GPU needs tests/cpp/fake_rccl.cpp "
+                                                 "(run by tests/test_group_rccl.py)")
+
+
+def run_ranks(world, body):
+    """body(rank) on `world` threads (ctypes releases the GIL inside the library); re-raises the first failure"""
+    errs = [None] * world
+
+    def wrap(r):
+        try:
+            body(r)
+        except BaseException as e:  # noqa: BLE001 -- reported below, per rank
+            errs[r] = e
+
+    ts = [threading.Thread(target=wrap, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not any(t.is_alive() for t in ts), "a rank is stuck inside a collective"
+    return errs
+
+
+@needs_fake
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_per_rank_groups_commit_matches_single_context(oracle, small, world):
+    """The sequence of test_group_commit_matches_single_context with every rank in its OWN lumen_group (n = 1 local
+    context of W): ncclCommInitRank from a shared id, all-to-alls whose peers are other threads, the all-gather, the
+    fingerprint exchange in front of the query gather, sends from the owners to rank 0."""
+    from lumenos_amd.hip import Group
+    P, ctx = small
+    cols, rho, nl = 64, 2, 3
+    S, c, Sw = cols * rho, cols // world, cols * rho // world
+    roots = oracle.field_roots(T_REF, S)
+    ctx.field_set(roots)
+    m = random_cts(P, cols, nl, seed=191)
+    zero = random_cts(P, 1, nl, seed=192)[0]
+    full = ctx.encode(ctx.upload(m), zero, rho)
+    lvl1 = ctx.rescale(full, 2)
+    dig = ctx.leaf_digests(lvl1)
+    _, root = ctx.merkle_build(dig)
+    idx = np.array([5, S - 1, 0, 5, Sw % S, 77 % S, (2 * Sw - 1) % S], dtype=np.uint32)
+    opened = ctx.gather(lvl1, idx).download()
+    want_enc = full.download()
+    ctx.sync()
+
+    ctxs = ranks_of(ctx, world)
+    uid = Group.unique_id()
+    out = [None] * world
+
+    def body(r):
+        cx = ctxs[r]
+        g = Group.join(cx, r, world, uid)
+        assert g.transport == "rccl" and g.rccl_ranks == world and FAKE_VERSION in g.transport_note
+        assert "ncclCommInitRank %d of %d" % (r, world) in g.transport_note
+        enc = g.encode([cx.upload(m[r * c:(r + 1) * c])], zero, rho)[0]
+        assert np.array_equal(enc.download(), want_enc[r * Sw:(r + 1) * Sw]), r
+        l1 = cx.rescale(enc, 2)
+        cx.leaf_digests_begin(l1)
+        g.all_gather_digests()
+        assert np.array_equal(g.digests(S), dig), r  # every rank holds all W * n digests
+        if r == 0:
+            assert g.merkle_root() == root
+        q = g.gather([l1], idx)
+        if r == 0:
+            assert q.count == len(idx) and np.array_equal(q.download(), opened)
+        else:
+            assert q is None
+        assert g.stats("all_to_all_1")[2] == 1 and g.stats("all_to_all_2")[2] == 1
+        assert g.stats("all_gather")[2] == 1 and g.stats("gather_to_root")[2] == 1
+        out[r] = g
+
+    errs = run_ranks(world, body)
+    assert errs == [None] * world, errs
+    for g in out:
+        g.close()
+    for cx in ctxs[1:]:
+        cx.close()
+
+
+@needs_fake
+def test_per_rank_gather_refuses_ranks_that_disagree_on_the_queries(small):
+    """lumen_group_gather in the per-rank form: a rank that was handed other indices is told so on EVERY rank, before
+    any data send is posted (real RCCL would wait for the unmatched receive for good)."""
+    from lumenos_amd.hip import Group, LumenError
+    P, ctx = small
+    world = 2
+    ctxs = ranks_of(ctx, world)
+    uid = Group.unique_id()
+    sets = [cx.upload(random_cts(P, 4, 2, seed=40 + r)) for r, cx in enumerate(ctxs)]
+    ok = [None] * world
+
+    def body(r):
+        g = Group.join(ctxs[r], r, world, uid)
+        idx = np.array([1, 6, 2] if r == 0 else [1, 6, 3], dtype=np.uint32)
+        with pytest.raises(LumenError, match="other query indices"):
+            g.gather([sets[r]], idx)
+        good = np.array([7, 0, 7], dtype=np.uint32)  # the group is still usable afterwards
+        q = g.gather([sets[r]], good)
+        if r == 0:
+            want = np.stack([sets[i // 4].download()[i % 4] for i in good])
+            assert np.array_equal(q.download(), want)
+        g.sync()
+        ok[r] = g
+
+    errs = run_ranks(world, body)
+    assert errs == [None] * world, errs
+    for g in ok:
+        g.close()
+    ctxs[1].close()
+
+
+def test_group_temporaries_return_in_stream_order(small):
+    """lumen_group_encode hands its four temporaries per rank back to the contexts' pools behind an event, without
+    waiting for the device; the next call that takes such a block waits for the event on its stream.  Back-to-back
+    encodes (which recycle the blocks while the previous call may still be running) give the same bytes as the
+    first."""
+    from lumenos_amd.hip import Group
+    P, ctx = small
+    world, cols, rho, nl = 4, 32, 2, 3
+    ctx.field_set(np.asarray(ctx_roots(P, cols * rho)))
+    m = random_cts(P, cols, nl, seed=77)
+    zero = random_cts(P, 1, nl, seed=78)[0]
+    ctxs = ranks_of(ctx, world)
+    g = Group(ctxs, transport=TRANSPORT)
+    own = [cx.upload(m[r * (cols // world):(r + 1) * (cols // world)]) for r, cx in enumerate(ctxs)]
+    first = [e.download() for e in g.encode(own, zero, rho)]
+    for _ in range(3):
+        enc = g.encode(own, zero, rho)  # no sync in between: the pool hands out blocks with events attached
+    for r in range(world):
+        assert np.array_equal(enc[r].download(), first[r]), r
+    g.close()
+    for cx in ctxs[1:]:
+        cx.close()
+
+
+def ctx_roots(P, S):
+    from oracle.loader import Oracle
+    return Oracle().field_roots(T_REF, S)

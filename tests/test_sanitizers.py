@@ -1,0 +1,67 @@
+"""CPU sanitizer recipe (AddressSanitizer + UndefinedBehaviorSanitizer; GPU sanitizers are not available on this pool):
+
+  * `make -C oracle san` builds the C restatement into oracle/_san/liblumen_oracle.so with
+    -fsanitize=address,undefined; the oracle's known-answer and BGV suites (tests/test_oracle_kat.py,
+    tests/test_oracle_bgv.py) then run against it in ONE child interpreter (LUMEN_ORACLE_LIB points the loader at
+    that build, libasan is preloaded because the interpreter itself is not instrumented);
+  * tests/cpp/core_unit.cpp -- the CPU unit of the C++ host mirror's core.cpp (SHA-256, Merlin, PrimeField, Merkle
+    trees and paths, the ChaCha20 witness against the reference's logged P(1)) -- is built and run plain and under
+    the same sanitizers.
+
+Any report (heap overflow, use after free, signed overflow, misaligned access, shift out of range ...) aborts the
+child and fails the test.  Skipped with the reason when gcc's libasan is not installed."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _runtime(name):
+    p = subprocess.run(["gcc", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+ASAN, UBSAN = _runtime("libasan.so"), _runtime("libubsan.so")
+needs_asan = pytest.mark.skipif(not (ASAN and UBSAN), reason="gcc's libasan / libubsan are not installed")
+SAN_ENV = {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1:halt_on_error=1",  # CPython itself "leaks" by design
+           "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"}
+
+
+def test_core_unit_plain():
+    """the unit itself, without sanitizers: published vectors and reference-held answers for core.cpp"""
+    exe = os.path.join(ROOT, "tests", "cpp", "core_unit")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "tests", "cpp", "core_unit.cpp"),
+                           os.path.join(ROOT, "lumenos_amd", "host", "core.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "core_unit OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@needs_asan
+def test_core_unit_under_asan_ubsan():
+    exe = os.path.join(ROOT, "tests", "cpp", "core_unit_san")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                           os.path.join(ROOT, "tests", "cpp", "core_unit.cpp"), os.path.join(ROOT, "lumenos_amd", "host", "core.cpp"),
+                           "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, **SAN_ENV))
+    assert out.returncode == 0 and "core_unit OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
+
+
+@needs_asan
+def test_oracle_suites_under_asan_ubsan():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "san"])
+    lib = os.path.join(ROOT, "oracle", "_san", "liblumen_oracle.so")
+    assert os.path.exists(lib)
+    env = dict(os.environ, **SAN_ENV, LUMEN_ORACLE_LIB=lib, LD_PRELOAD=ASAN + ":" + UBSAN, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "-m", "not gpu",
+                        os.path.join(ROOT, "tests", "test_oracle_kat.py"), os.path.join(ROOT, "tests", "test_oracle_bgv.py")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
+    tail = r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0, tail
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, tail
+    last = r.stdout.strip().splitlines()[-1]
+    assert " passed" in last and "failed" not in last, tail

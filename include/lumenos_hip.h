@@ -76,7 +76,8 @@ int lumen_ctx_wait(lumen_ctx *ctx, lumen_ctx *other);
 /* The library's tuning switches (A/B tools; every default is the measured best; DESIGN.md "Run-time
  * switches") are read from the environment ONCE, by lumen_ctx_create; clones inherit them.  This setter is
  * the in-process form for tests and tools: name = "LUMEN_KS_BATCH", "LUMEN_KS_LANES",
- * "LUMEN_KS_FUSED_DIGITS" (value < 0: derived default), "LUMEN_CT_BLOCKS", "LUMEN_DEBUG"; and, for the test
+ * "LUMEN_KS_FUSED_DIGITS" (value < 0: derived default), "LUMEN_CT_BLOCKS", "LUMEN_DEBUG", "LUMEN_MODUP_TGROUP",
+ * "LUMEN_MODDOWN_TGROUP" (work-list order of the key switch's two transform kernels); and, for the test
  * suite only (never read from the environment), "LUMEN_RCCL_SHARED_DEVICE": lumen_group_create then lets
  * LUMEN_TRANSPORT_RCCL through although ranks share a device, so that the library's RCCL call sequence can be run
  * with W > 1 on a one-GPU box against the test double tests/cpp/fake_rccl.c (real RCCL refuses such a communicator). */

@@ -83,6 +83,9 @@ struct lm_tuning {
     int32_t ks_fused_digits = -1; // LUMEN_KS_FUSED_DIGITS: digits packed inside k_intt_pack (-1: derive)
     uint32_t ct_blocks = 1;      // LUMEN_CT_BLOCKS: 0 = Encode through the op-by-op interpreter
     uint32_t debug = 0;          // LUMEN_DEBUG
+    // LUMEN_MODUP_TGROUP / LUMEN_MODDOWN_TGROUP: target limbs one XCD walks back to back in the work lists of the
+    // two transform kernels of a key switch (lm_keyswitch.hip); 1 .. 31
+    uint32_t modup_tgroup = 4, moddown_tgroup = 4;
     // LUMEN_RCCL_SHARED_DEVICE (tests only): LUMEN_TRANSPORT_RCCL accepts ranks that share a device.  Real RCCL
     // refuses such a communicator itself; the switch exists so that the RCCL call sequence of lm_group.hip can run
     // with W > 1 on a one-GPU box against tests/cpp/fake_rccl.c

@@ -184,12 +184,15 @@ static int tuning_set(lm_tuning &t, const char *name, long v) {
     else if (n == "LUMEN_KS_FUSED_DIGITS") t.ks_fused_digits = v >= 0 ? (int32_t)v : -1;
     else if (n == "LUMEN_CT_BLOCKS") t.ct_blocks = v != 0;
     else if (n == "LUMEN_DEBUG") t.debug = v != 0;
+    else if (n == "LUMEN_MODUP_TGROUP") t.modup_tgroup = (v >= 1 && v <= 31) ? (uint32_t)v : 4;
+    else if (n == "LUMEN_MODDOWN_TGROUP") t.moddown_tgroup = (v >= 1 && v <= 31) ? (uint32_t)v : 4;
     else if (n == "LUMEN_RCCL_SHARED_DEVICE") t.rccl_shared_device = v != 0; // tests only, never from the environment
     else return 1;
     return 0;
 }
 static void tuning_from_env(lm_tuning &t) {
-    for (const char *n : {"LUMEN_KS_BATCH", "LUMEN_KS_LANES", "LUMEN_KS_FUSED_DIGITS", "LUMEN_CT_BLOCKS", "LUMEN_DEBUG"}) {
+    for (const char *n : {"LUMEN_KS_BATCH", "LUMEN_KS_LANES", "LUMEN_KS_FUSED_DIGITS", "LUMEN_CT_BLOCKS", "LUMEN_DEBUG",
+                          "LUMEN_MODUP_TGROUP", "LUMEN_MODDOWN_TGROUP"}) {
         const char *e = getenv(n);
         if (e && *e) tuning_set(t, n, atol(e)); // an empty override counts as unset
     }

@@ -421,14 +421,15 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
 // ---- steps 4+5: ModDown, add c0, automorphism, accumulate.  One workgroup per (column b,
 // poly w, Q limb t): the lift of the (coefficient-domain) P limbs into q_t is fused into the load,
 // the NTT runs in LDS, d = (u_t - lift) * P^-1 (+ c0 for w == 0) is formed in the last pass and
-// parked in LDS; after a barrier the new accumulator limb is written linearly,
-// acc_out[j] = acc_in[j] + d[index[j]], the automorphism being a gather out of LDS.  (acc is
+// parked in LDS; then every wave writes one block of the new accumulator limb linearly,
+// acc_out[j] = acc_in[j] + d[index[j]], the automorphism being a gather out of the wave's own LDS block.  (acc is
 // ping-ponged: an output needs the old accumulator at two positions, j and index[j].)
 template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 *__restrict__ u, const u64 *__restrict__ acc_in,
                                                      u64 *__restrict__ acc_out, const bx_t *__restrict__ bxp,
                                                      const tw_t *__restrict__ pinv,
                                                      const uint32_t *__restrict__ index,
+                                                     const uint32_t *__restrict__ inv_index,
                                                      const uint32_t *__restrict__ work, uint32_t B,
                                                      uint32_t L, uint32_t K, lm_mods mods,
                                                      const tw_t *__restrict__ tw_all) {
@@ -482,23 +483,32 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
         }
     } st{uq, ain, sm, qc, pi, w, {}, {}};
     // acc_out[j] = acc_in[j] + d[index[j]]: the automorphism is applied as a gather out of LDS, so the
-    // accumulator itself streams through HBM linearly in 16-byte vectors.  Every lane handles 8 pairs;
-    // their index and accumulator words are requested before the barrier, while the slower waves of the
-    // workgroup are still in their last pass.
+    // accumulator itself streams through HBM linearly in 16-byte vectors.
+    // NO workgroup barrier (round 5).  In the bit-reversed order of the NTT domain an automorphism X -> X^g permutes
+    // BLOCKS onto blocks: position i evaluates at psi^e, e = 2 bitrev(i) + 1; the low b + 1 bits of g e mod 2N only
+    // depend on the low b + 1 bits of e, i.e. on the TOP b bits of i -- so the top b bits of index[i] are a function
+    // (a bijection) of the top b bits of i, for every b.  With b = log2(waves): every output block of N / waves
+    // coefficients gathers from exactly ONE source block, the one a single wave has just left in LDS.  Wave w
+    // therefore serves output block jb = inv_index[w * BLK] / BLK as soon as ITS OWN last pass is done (a wave's LDS
+    // operations execute in order) and goes home; the waves of a workgroup finish up to 12 us apart
+    // (profiles/r02_ubench_phases.txt), and the barrier this replaces made the early ones wait for the last.
+    // Every lane handles 8 pairs; their index and accumulator words are requested before the wave's last pass.
+    constexpr uint32_t NW = lm_nthreads(LOGN) / 64, BLK = N / NW, IT = BLK / 128;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t jb = NW > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(inv_index[wave * BLK] / BLK)) : 0u;
     auto after = [&](uint32_t, uint32_t) {
-        constexpr uint32_t IT = N / (2 * lm_nthreads(LOGN));
         uint2 p[IT];
         ulonglong2 x[IT];
 #pragma unroll
         for (uint32_t k = 0; k < IT; k++) {
-            const uint32_t j = 2 * tid + k * 2 * nthreads;
+            const uint32_t j = jb * BLK + 2 * lane + k * 128;
             p[k] = *reinterpret_cast<const uint2 *>(index + j);
             x[k] = *reinterpret_cast<const ulonglong2 *>(ain + j);
         }
-        __syncthreads();
+        lm_wave_sync();
 #pragma unroll
         for (uint32_t k = 0; k < IT; k++) {
-            const uint32_t j = 2 * tid + k * 2 * nthreads;
+            const uint32_t j = jb * BLK + 2 * lane + k * 128;
             // the accumulator is LAZY across the rotations of an InnerSum: words in [0, 2q).  acc (< 2q) + d (< 6q)
             // < 8q comes back under 2q with two conditional subtractions -- the only ones of the kernel (the
             // canonical form cost four per coefficient of c0 and three of c1: d to [0, q), + c0, + acc).  Its
@@ -661,15 +671,16 @@ struct KsScratch {
 // for each group the (column, digit) pairs are walked with the group's targets innermost -- the
 // workgroups that read the same digit are adjacent on one XCD (one fabric read, the rest L2 hits)
 // while only LM_MODUP_TGROUP twiddle tables (256 KB each at N = 2^14) are live in that L2.
-#ifndef LM_MODUP_TGROUP
-#define LM_MODUP_TGROUP 4
-#endif
+// (LM_MODUP_TGROUP = ctx->tune.modup_tgroup: a run-time switch since round 5 so that an A/B can alternate orders
+// inside one process; the lists are cached per (batch size, group size).)
 static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint32_t **out) {
+    const uint32_t LM_MODUP_TGROUP = ctx->tune.modup_tgroup;
     LM_SHARED_LOCK(ctx); // the cached lists are shared with the context's clones
     // packed as column (16 bits) | digit (8) | target modulus (8): refuse what does not fit
     LM_CHECK(ctx, B >= 1 && B <= 65535 && tb->beta <= 255 && ctx->L + ctx->K <= 255,
              "key-switch batch of %u columns (beta %u) does not fit the packed work list", B, tb->beta);
-    auto it = tb->d_work.find(B);
+    const uint32_t cache_key = B | (LM_MODUP_TGROUP << 16);
+    auto it = tb->d_work.find(cache_key);
     if (it != tb->d_work.end()) {
         *out = it->second;
         return 0;
@@ -701,21 +712,20 @@ static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint3
     uint32_t *d = nullptr;
     LM_HIP(ctx, hipMalloc((void **)&d, order.size() * sizeof(uint32_t)));
     LM_HIP(ctx, hipMemcpy(d, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    tb->d_work[B] = d;
+    tb->d_work[cache_key] = d;
     *out = d;
     return 0;
 }
 
 // The same for ModDown: (polynomial pw = 2b + w, Q limb t); XCD x takes the polynomials pw == x (mod 8),
 // targets in groups of LM_MODDOWN_TGROUP, the group's targets innermost.
-#ifndef LM_MODDOWN_TGROUP
-#define LM_MODDOWN_TGROUP 4
-#endif
 static int moddown_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint32_t **out) {
+    const uint32_t LM_MODDOWN_TGROUP = ctx->tune.moddown_tgroup;
     LM_SHARED_LOCK(ctx);
     // packed as polynomial 2b + w (16 bits) | target limb (16)
     LM_CHECK(ctx, B >= 1 && 2 * (uint64_t)B <= 65535, "key-switch batch of %u columns does not fit the packed work list", B);
-    auto it = tb->d_work_down.find(B);
+    const uint32_t cache_key = B | (LM_MODDOWN_TGROUP << 17);
+    auto it = tb->d_work_down.find(cache_key);
     if (it != tb->d_work_down.end()) {
         *out = it->second;
         return 0;
@@ -741,7 +751,7 @@ static int moddown_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uin
     uint32_t *d = nullptr;
     LM_HIP(ctx, hipMalloc((void **)&d, order.size() * sizeof(uint32_t)));
     LM_HIP(ctx, hipMemcpy(d, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    tb->d_work_down[B] = d;
+    tb->d_work_down[cache_key] = d;
     *out = d;
     return 0;
 }
@@ -912,7 +922,7 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
     case n:                                                                                                   \
         LM_LDS_ATTR(ctx, k_moddown_ntt<n>, lds);               \
         hipLaunchKernelGGL(k_moddown_ntt<n>, dim3(B * 2 * L), dim3(threads), lds, ctx->stream, s.u, acc,      \
-                           acc_out, tb->d_bxp, tb->d_pinv, gk.d_index, work_down, B, L, K, ctx->mods,     \
+                           acc_out, tb->d_bxp, tb->d_pinv, gk.d_index, gk.d_inv_index, work_down, B, L, K, ctx->mods, \
                            ctx->d_tw_fwd);                                                                    \
         break;
             LM_FOR_EACH_LOGN(LM_CASE)

@@ -6,7 +6,7 @@ communicator set-ups would only ever execute with a world of one.  tests/cpp/fak
 NCCL's point-to-point semantics (matching by (source, destination) in order, stream-ordered copies, deferred
 groups, blocking ncclCommInitRank); it is built here as librccl.so.1 and put first on LD_LIBRARY_PATH of ONE child
 process -- a fresh interpreter that never imports torch, so no other RCCL holds the soname -- which runs
-tests/test_group.py again with LUMEN_TEST_GROUP_TRANSPORT=rccl.  Every assertion of that file (bytes of the copy
+tests/test_group.py again (and tests/group_per_rank_cases.py) with LUMEN_TEST_GROUP_TRANSPORT=rccl.  Every assertion of that file (bytes of the copy
 transport = bytes of one context = the oracle) then holds for the RCCL call sequences with W = 2, 4, 8, in the
 one-process form (ncclCommInitAll) and the one-process-per-GPU form (ncclCommInitRank; ranks played by threads).
 
@@ -85,7 +85,8 @@ def test_group_suite_through_the_rccl_branch():
     W = 1, 2, 4, 8, upload / download, the error paths, the per-rank form on W threads and its refusal of ranks that
     disagree on the queries."""
     build_fakes()
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_group.py"), "-m", "gpu", "-x", "-q",
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_group.py"),
+                        os.path.join(ROOT, "tests", "group_per_rank_cases.py"), "-m", "gpu", "-x", "-q",
                         "-p", "no:cacheprovider"], cwd=ROOT, env=child_env(FAKE_DIR, LUMEN_TEST_GROUP_TRANSPORT="rccl"),
                        capture_output=True, text=True, timeout=1500)
     tail = r.stdout[-3000:] + r.stderr[-2000:]

@@ -732,15 +732,12 @@ def hashlib_sha(arr):
 
 
 def device_identity(ctx_device):
-    """what tells two ranks that they sit on the same physical GPU: the device's UUID where torch exposes it, else
-    host + visibility masks + ordinal"""
+    """what tells two ranks of one launch that they sit on the same physical GPU: host, the visibility masks the
+    process runs under and the device ordinal it uses (torch.distributed.run gives every rank the same masks and its
+    own ordinal; a launcher that pins one GPU per process gives every rank ordinal 0 under its own mask)"""
     import socket
-    try:
-        import torch
-        return f"{socket.gethostname()}:{torch.cuda.get_device_properties(ctx_device).uuid}"
-    except Exception:  # noqa: BLE001 -- older torch: no uuid
-        return "%s:%s:%s:%d" % (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES", ""),
-                                os.environ.get("ROCR_VISIBLE_DEVICES", ""), ctx_device)
+    return "|".join([socket.gethostname()] + [os.environ.get(k, "") for k in
+                    ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")] + [str(ctx_device)])
 
 
 def join_ranks(ctx, rank, world, dist, deadline_s=None):
@@ -1359,7 +1356,10 @@ def main():
         # library's own RCCL communicator, or with --transport torch the process group itself ("nccl" is RCCL on
         # ROCm).  A rank that dies must not leave the others waiting in a collective for ever.
         use_torch = args.transport == "torch"
-        dist.init_process_group(args.dist_backend if use_torch else "gloo", timeout=datetime.timedelta(minutes=10))
+        # (--share-gpu: RCCL of any kind refuses two ranks on one device -- "Duplicate GPU detected" -- so the
+        # torch path of the one-GPU rehearsal is gloo whatever --dist-backend says)
+        backend = "gloo" if (not use_torch or args.share_gpu) else args.dist_backend
+        dist.init_process_group(backend, timeout=datetime.timedelta(minutes=10))
 
     local_devices = None
     if args.single_process and world > 1:

@@ -740,7 +740,7 @@ def device_identity(ctx_device):
                     ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")] + [str(ctx_device)])
 
 
-def join_ranks(ctx, rank, world, dist, deadline_s=None):
+def join_ranks(ctx, rank, world, dist, deadline_s=None, identity=None):
     """One process per GPU: every rank joins the library's own RCCL communicator (lumen_group_create_rank) -- or none
     does.  Returns (group or None, [(ok, reason)] of all ranks), the same on every rank.
 
@@ -760,7 +760,8 @@ def join_ranks(ctx, rank, world, dist, deadline_s=None):
         uid = Group.unique_id()  # loads librccl in this process; only rank 0's id is used
     except LumenError as e:
         err = f"rank {rank}: {e}"
-    mine = (not err, err, device_identity(ctx.device), uid.tobytes() if uid is not None else b"")
+    # (identity: the rehearsal in tests/dev/bench_per_rank_threads.py plays the ranks as threads on one GPU)
+    mine = (not err, err, identity or device_identity(ctx.device), uid.tobytes() if uid is not None else b"")
     seen = [None] * world
     dist.all_gather_object(seen, mine)
     by_dev = {}

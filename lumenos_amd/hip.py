@@ -294,6 +294,7 @@ class Context:
         if rc:
             raise LumenError(self.lib.lumen_last_error(None).decode())
         self.h = h
+        self.device = device  # HIP device ordinal the context lives on
         self.log_n, self.N = log_n, 1 << log_n
         self.L, self.K = len(q), len(p)
         self.q, self.p, self.T = list(q), list(p), plaintext_modulus
@@ -306,6 +307,7 @@ class Context:
         self._ck(self.lib.lumen_ctx_clone(self.h, C.byref(h)))
         c = object.__new__(Context)
         c.lib, c.h = self.lib, h
+        c.device = self.device
         c.log_n, c.N, c.L, c.K = self.log_n, self.N, self.L, self.K
         c.q, c.p, c.T = self.q, self.p, self.T
         if hasattr(self, "_rs_logn"):

@@ -48,6 +48,7 @@ def test_group_all_to_all_routes_blocks(small, world):
     from lumenos_amd.hip import Group
     P, ctx = small
     ctxs = ranks_of(ctx, world)
+    assert all(c.device == 0 for c in ctxs)  # bench.py's join_ranks tells ranks apart by it
     g = Group(ctxs, transport=TRANSPORT)
     check_transport(g, world)
     assert g.world == world

@@ -142,3 +142,25 @@ def test_auto_transport_falls_back_to_copies_when_rccl_is_unusable(case):
         assert "BYNAME" in r.stdout and "ncclCommInitAll" in r.stdout.split("BYNAME")[1]
     else:
         assert "librccl lacks:" in line and "ncclCommInitAll" in line, line
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_per_rank_path_on_thread_ranks(world):
+    """bench.py's one-process-per-GPU path -- join_ranks (real lumen_group_unique_id / lumen_group_create_rank),
+    Job.step_group with ONE local rank of W, multi_rank_report with its W-rank-against-one-rank `check` on a second
+    communicator -- is what the 8-GPU node runs and what a one-GPU box can never start as processes (RCCL refuses two
+    ranks on a device).  tests/dev/bench_per_rank_threads.py plays the ranks as threads of one child process over the
+    test double: every rank computes the same Merkle root in every step, the check is green, the communicator saw W
+    ranks."""
+    import json
+    build_fakes()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "bench_per_rank_threads.py"), "--world", str(world),
+                        "--config", "2048x1024", "--steps", "2"], cwd=ROOT, env=child_env(FAKE_DIR), capture_output=True,
+                       text=True, timeout=1500)
+    tail = r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0, tail
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ok"] and line["rccl_ranks_seen"] == world and line["transport"] == "rccl" and "99999" in line["note"], line
+    assert line["check"]["ok"] and line["check"]["path"] == "lumen_group" and line["check"]["root_equal"], line["check"]
+    assert set(line["collectives"]) == {"all_to_all_1", "all_to_all_2", "all_gather", "gather_to_root"}, line["collectives"]

@@ -49,7 +49,6 @@ typedef unsigned __int128 lo_u128;
 uint64_t lo_addmod(uint64_t a, uint64_t b, uint64_t q);
 uint64_t lo_submod(uint64_t a, uint64_t b, uint64_t q);
 uint64_t lo_mulmod(uint64_t a, uint64_t b, uint64_t q);
-uint64_t lo_mulmod_slow(uint64_t a, uint64_t b, uint64_t q); /* the plain 128-bit % form: the checker's checker */
 uint64_t lo_powmod(uint64_t a, uint64_t e, uint64_t q);
 uint64_t lo_invmod(uint64_t a, uint64_t q); /* q prime */
 int lo_is_prime(uint64_t n);

@@ -16,44 +16,12 @@ uint64_t lo_submod(uint64_t a, uint64_t b, uint64_t q) {
     return a >= b ? a - b : a + q - b;
 }
 
-/* core/field.go:56-58 BRed(x, y, q, u): x*y mod q, canonical.
- * Round 5: Barrett reduction with u = floor(2^128 / q) (Lattigo's BRedConstant is the same two words) instead of a
- * 128-bit `%` (a libgcc call of ~30 ns): the timed CPU baseline of bench.py was 3.9x slower than the reference's own
- * published figure for that reason alone.  The constant is cached per thread for the last modulus seen -- the
- * oracle's loops run over the coefficients of one limb, so q only changes once per limb.  Exact for every a, b
- * (the quotient estimate is at most 2 short: two conditional subtractions; a, b >= q are reduced first), and
- * lo_mulmod_slow() keeps the plain form: tests/test_oracle_kat.py holds one against the other. */
-uint64_t lo_mulmod_slow(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((lo_u128)a * b) % q); }
-
-static _Thread_local uint64_t bar_q, bar_hi, bar_lo; /* floor(2^128 / bar_q) = bar_hi * 2^64 + bar_lo */
-
-static inline uint64_t mulhi64(uint64_t x, uint64_t y) { return (uint64_t)(((lo_u128)x * y) >> 64); }
-
 uint64_t lo_mulmod(uint64_t a, uint64_t b, uint64_t q) {
-    if (q < 2) return 0;
-    if (q != bar_q) {
-        /* floor(2^128 / q) from two 128-by-64 divisions: 2^128 = (hi * q + r) * 2^64 with 2^64 = hi * q + r */
-        const lo_u128 one = (lo_u128)1 << 64;
-        const uint64_t hi = (uint64_t)(one / q), r = (uint64_t)(one % q);
-        bar_hi = hi;
-        bar_lo = (uint64_t)((((lo_u128)r) << 64) / q);
-        bar_q = q;
-    }
-    if (a >= q) a %= q;
-    if (b >= q) b %= q;
-    const lo_u128 p = (lo_u128)a * b; /* < q^2 < 2^128 */
-    const uint64_t ph = (uint64_t)(p >> 64), pl = (uint64_t)p;
-    /* t ~ floor(p * u / 2^128), u = bar_hi * 2^64 + bar_lo: the three partial products that reach bit 128 */
-    lo_u128 mid = (lo_u128)ph * bar_lo + (lo_u128)pl * bar_hi + mulhi64(pl, bar_lo);
-    const lo_u128 t = (lo_u128)ph * bar_hi + (mid >> 64);
-    uint64_t r = pl - (uint64_t)t * q; /* p - t*q < 3q fits 64 bits when q < 2^62; computed mod 2^64 */
-    if (q >> 62) { /* moduli that close to 2^64: keep the exact form (no path parameter gets here) */
-        return lo_mulmod_slow(a, b, q);
-    }
-    if (r >= q) r -= q;
-    if (r >= q) r -= q;
-    if (r >= q) r -= q;
-    return r;
+    /* core/field.go:56-58 BRed(x, y, q, u).  (A Barrett form with a cached floor(2^128 / q) was tried in round 5 to
+     * bring bench.py's timed CPU baseline closer to Lattigo's: on the GPU box's host cores the 128-by-64 division
+     * behind this `%` is a single fast instruction and the Barrett form was no faster -- 1908 s against 1746 s for
+     * the extrapolated baseline -- so the plain form stays.) */
+    return (uint64_t)(((lo_u128)a * b) % q);
 }
 
 uint64_t lo_powmod(uint64_t a, uint64_t e, uint64_t q) {

@@ -1454,7 +1454,15 @@ def main():
             out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    # orderly teardown: every rank is past its last collective (the report's gather above) before any communicator
+    # goes -- the group before its contexts, the library's RCCL communicator before the control plane
+    try:
+        if dist is not None:
+            dist.barrier()
+        job.close()
+    except Exception as e:  # noqa: BLE001 -- the line is out: a teardown hiccup must not turn the run into a failure
+        sys.stderr.write(f"[bench.py] teardown: {type(e).__name__}: {e}\n")
     if dist is not None:
         dist.destroy_process_group()
 

@@ -189,6 +189,7 @@ class ServerGroup {
     ServerBFV &Rank(int r) const { return *ranks_.at((size_t)r); }
     lumen_group *Handle() const { return group_; }
     std::string Transport() const { return lumen_group_transport(group_); }
+    std::string TransportNote() const { return lumen_group_transport_note(group_); } // how it was chosen (librccl version, fall-back reason ...)
     void check(int rc, const char *what) const; // throws std::runtime_error with lumen_last_error(NULL)
     void Sync() const;
     // the witness encryption loop of cmd/server/main.go:188-208 over the ranks: column j (of `count`, `rows`

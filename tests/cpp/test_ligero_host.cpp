@@ -335,6 +335,12 @@ int main(int argc, char **argv) {
         // CopyNew()s (one GPU here: they share its keys; on a node every rank is a NewBackendBFV on its own GPU).
         // The encryptor's stream is rewound so that the witness columns and the one Enc(0) of fhe.Encode come out as
         // the bits of the run above.
+        // LUMEN_TWIN_RCCL_SHARED_DEVICE=1 (tests/test_group_rccl.py, with the RCCL test double first on LD_LIBRARY_PATH):
+        // the test-only switch that lets LUMEN_TRANSPORT_AUTO pick RCCL for ranks sharing the one GPU -- set before the
+        // copies are made, they inherit it -- so that the whole sharded Commit + Prove runs through the library's RCCL
+        // call sequences and must still produce the one-GPU proof byte for byte
+        if (const char *e = getenv("LUMEN_TWIN_RCCL_SHARED_DEVICE"))
+            if (*e && *e != '0') REQUIRE(!lumen_ctx_set_tuning(server.Context(), "LUMEN_RCCL_SHARED_DEVICE", 1), "lumen_ctx_set_tuning");
         std::vector<std::unique_ptr<fhe::ServerBFV>> copies;
         std::vector<fhe::ServerBFV *> ranks{&server};
         for (int k = 1; k < world; k++) {
@@ -343,7 +349,7 @@ int main(int argc, char **argv) {
         }
         REQUIRE(!lumen_ctx_trim(server.Context()), "lumen_ctx_trim"); // several contexts share this GPU's memory
         fhe::ServerGroup group(ranks, LUMEN_TRANSPORT_AUTO);
-        printf("ServerGroup: %d ranks, transport %s\n", group.World(), group.Transport().c_str());
+        printf("ServerGroup: %d ranks, transport %s (%s)\n", group.World(), group.Transport().c_str(), group.TransportNote().c_str());
         server.RewindEncryptorForTest(0);
         span = core::Span::StartSpan("Encrypt matrix (group)", nullptr);
         fhe::ShardedCiphertexts shards = group.EncryptColumnsNew(columns, rows, cols);

@@ -164,3 +164,22 @@ def test_bench_per_rank_path_on_thread_ranks(world):
     assert line["ok"] and line["rccl_ranks_seen"] == world and line["transport"] == "rccl" and "99999" in line["note"], line
     assert line["check"]["ok"] and line["check"]["path"] == "lumen_group" and line["check"]["root_equal"], line["check"]
     assert set(line["collectives"]) == {"all_to_all_1", "all_to_all_2", "all_gather", "gather_to_root"}, line["collectives"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(12, 2048, 1024, 10, 0, 4), (12, 2048, 1024, 10, 10, 8), (14, 16384, 4096, 12, 0, 8)])
+def test_server_group_twin_through_the_rccl_branch(shape):
+    """The C++ twin of TestLigeroE2E on a ServerGroup (tests/test_host_mirror.py::test_ligero_e2e_server_group_matches_one_gpu)
+    with the exchange steps of the sharded Commit + Prove going through the library's RCCL call sequences (the test double
+    as librccl.so.1; the twin is a C++ process, no other RCCL in it): the reference's test shape on 4 ranks, with the ring
+    switch on 8, and the HEADLINE configuration -- 16384 x 4096, LogN = 14, L = 12 -- on 8 ranks.  Same Merkle root and a
+    byte-identical marshaled proof (4.46 GB at the headline size) as the one-GPU run."""
+    from tests.test_host_mirror import build_binary
+    build_fakes()
+    res = subprocess.run([build_binary()] + [str(x) for x in shape], capture_output=True, text=True, timeout=1500,
+                         env=child_env(FAKE_DIR, LUMEN_TWIN_RCCL_SHARED_DEVICE="1"))
+    tail = res.stdout[-2500:] + res.stderr[-2500:]
+    assert res.returncode == 0, tail
+    assert "PASS TestLigeroE2E" in res.stdout
+    assert f"ServerGroup: {shape[5]} ranks, transport rccl (rccl: librccl version 99999, ncclCommInitAll over {shape[5]} devices)" in res.stdout, tail
+    assert f"PASS ServerGroup W={shape[5]}: same Merkle root, byte-identical proof" in res.stdout, tail

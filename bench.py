@@ -1043,15 +1043,18 @@ def _kernel_table(job, ctx, cfg):
         achieved = alg_bytes_per_launch / (ms / launches * 1e-3) / 1e9
         pe = pmc_entry(pmc, dom)
         sq = (pe or {}).get("sq_per_launch") or {}
-        roofline = {"bound": "hbm", "limiter": "valu", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
+        roofline = {"bound": "hbm", "limiter": "valu and memory phases in series", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                     "traffic": round(pe["hbm_bytes_per_launch"]) if pe and pe.get("hbm_bytes_per_launch") else None,
                     "avg_launch_ms": round(ms / launches, 4), "limb_ntts_per_launch": units // launches,
                     "valu": valu_roof(job, ms, launches, units, sq),
                     "note": "`bound` names the roofline `frac` is priced against (HBM, as SURVEY 8d prescribes for every "
-                            "kernel of this path); `limiter` is what actually limits the kernel: VALU issue of 64-bit "
-                            "modular butterflies, and `valu` is that second roof, calibrated on this chip.  The >= 50 % "
-                            "HBM target of north_star is not reachable at 10 multiply-adds per 64-bit Shoup product; "
+                            "kernel of this path).  `limiter`: neither roof is saturated -- the butterfly-only VALU ceiling is 0.61 "
+                            "of the HBM peak (`valu`, calibrated on this chip: 10 multiply-adds per 64-bit Shoup product), the "
+                            "memory side alone (the kernels built without butterflies, profiles/r05_exp_no_butterflies_floor.txt) 0.66 "
+                            "for a plain transform and 0.52 for this kernel with its fused basis extension, and with one 144 KB "
+                            "workgroup per CU the two run in series more than they overlap: 0.35.  The >= 50 % HBM target of "
+                            "north_star is out of reach on both counts; "
                             "DESIGN.md section 6 (and profiles/EXPERIMENTS.md) has the costing"}
     return roofline, stages, executed
 

@@ -145,7 +145,7 @@ def test_auto_transport_falls_back_to_copies_when_rccl_is_unusable(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_per_rank_path_on_thread_ranks(world):
     """bench.py's one-process-per-GPU path -- join_ranks (real lumen_group_unique_id / lumen_group_create_rank),
     Job.step_group with ONE local rank of W, multi_rank_report with its W-rank-against-one-rank `check` on a second

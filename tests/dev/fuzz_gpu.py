@@ -3,7 +3,7 @@ by pytest): random ring degrees, limb counts, 1 or 2 special primes, random shap
 digests in random serialisation formats; the ring switch with 0, 1 or 2 special primes into random degrees; W = 2, 4, 8
 ranks behind a lumen_group (Encode between the all-to-alls, digests, root, query gather) against one rank.
 
-usage: [FUZZ_LOGN=13,14] python tests/dev/fuzz_gpu.py [cases] [seed]
+usage: [FUZZ_LOGN=13,14] [FUZZ_GROUP_TRANSPORT=rccl LD_LIBRARY_PATH=tests/cpp/fake_rccl:...] python tests/dev/fuzz_gpu.py [cases] [seed]
 """
 import os
 import sys
@@ -111,8 +111,14 @@ def one_case(o, rng, case):
             mg = random_cts(P, cols, nlg, seed=case + 23)
             zg = random_cts(P, 1, nlg, seed=case + 29)[0]
             want_enc = P.ct_encode(mg, rho, zg, rootsg)
+            # FUZZ_GROUP_TRANSPORT=rccl (with the RCCL test double first on LD_LIBRARY_PATH, tests/test_group_rccl.py):
+            # the group's collectives go through the library's RCCL branch
+            via_rccl = os.environ.get("FUZZ_GROUP_TRANSPORT", "copy") == "rccl"
+            if via_rccl:
+                ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 1)
             ctxs = [ctx] + [ctx.clone() for _ in range(W - 1)]
-            g = Group(ctxs, transport="copy")
+            g = Group(ctxs, transport="rccl" if via_rccl else "copy")
+            assert g.transport == ("rccl" if via_rccl else "copy")
             own, Sw = cols // W, Sg // W
             enc = g.encode([cx.upload(mg[r * own:(r + 1) * own]) for r, cx in enumerate(ctxs)], zg, rho)
             for r in range(W):

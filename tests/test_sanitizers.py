@@ -65,3 +65,25 @@ def test_oracle_suites_under_asan_ubsan():
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, tail
     last = r.stdout.strip().splitlines()[-1]
     assert " passed" in last and "failed" not in last, tail
+
+
+@needs_asan
+def test_host_mirror_fhe_cpu_parts_under_asan_ubsan():
+    """lumenos_amd/host/fhe.cpp's host-only parts (MetaDataJSON with its 128-bit hex-float Scale, go-humanize's rounding:
+    what frames every proof ciphertext) compiled WITH the mirror's sources under ASan + UBSan and run on the inputs of
+    tests/test_host_mirror.py's CPU case.  (The HIP library it links is not instrumented and is not called.)"""
+    from lumenos_amd import _build
+    lib = _build.build()
+    cd = os.path.dirname(lib)
+    exe = os.path.join(ROOT, "tests", "cpp", "metadata_len_san")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer", os.path.join(ROOT, "tests", "cpp", "metadata_len.cpp"),
+                           os.path.join(ROOT, "lumenos_amd", "host", "fhe.cpp"), os.path.join(ROOT, "lumenos_amd", "host", "core.cpp"),
+                           "-o", exe, "-L" + cd, "-llumenos_hip", f"-Wl,-rpath,{cd}"])
+    for scale, log_cols in ((1, 11), (144115188075593728, 13), (3, 12)):
+        out = subprocess.run([exe, str(scale), str(log_cols), "134550528", "134500000", "4456000000", "9", "68540000", "999"],
+                             capture_output=True, text=True, timeout=300, env=dict(os.environ, **SAN_ENV))
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
+        lines = out.stdout.split("\n")
+        assert int(lines[0]) == len(lines[1]) == 281 and lines[2:8] == ["135 MB", "134 MB", "4.5 GB", "9 B", "68 MB", "999 B"]

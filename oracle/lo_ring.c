@@ -125,12 +125,34 @@ uint64_t lo_params_psi(const lo_params *p, uint32_t i) { return p->psi[i]; }
 uint32_t lo_params_L(const lo_params *p) { return p->L; }
 uint32_t lo_params_K(const lo_params *p) { return p->K; }
 
+/* x*w mod q for a constant w with its Shoup companion wp = floor(w * 2^64 / q): exact and canonical for x < 2^64,
+ * q < 2^63 (the estimate of the quotient is at most one short).  Round 5: the transform cores divided by q for every
+ * butterfly (a 128-by-64 `%`), which made bench.py's timed CPU baseline several times slower per butterfly than the
+ * Montgomery / Shoup loops of the reference's own library; a twiddle is constant over the inner loop, so ONE division
+ * per twiddle buys division-free butterflies.  Same residues (canonical in, canonical out). */
+static inline uint64_t shoup_companion(uint64_t w, uint64_t q) { return (uint64_t)((((lo_u128)w) << 64) / q); }
+static inline uint64_t shoup_mul(uint64_t x, uint64_t w, uint64_t wp, uint64_t q) {
+    const uint64_t hi = (uint64_t)(((lo_u128)x * wp) >> 64);
+    const uint64_t r = x * w - hi * q; /* mod 2^64: the true value is in [0, 2q) */
+    return r >= q ? r - q : r;
+}
+
 void lo_ntt_core(uint64_t *a, uint32_t N, uint64_t q, const uint64_t *psi_rev) {
+    const int fast = (q >> 62) == 0;
     uint32_t t = N >> 1;
     for (uint32_t m = 1; m < N; m <<= 1, t >>= 1) {
         for (uint32_t i = 0; i < m; i++) {
             uint64_t w = psi_rev[m + i];
             uint32_t j1 = 2 * i * t;
+            if (fast && t >= 2) {
+                const uint64_t wp = shoup_companion(w, q);
+                for (uint32_t j = j1; j < j1 + t; j++) {
+                    uint64_t u = a[j], v = shoup_mul(a[j + t], w, wp, q);
+                    a[j] = lo_addmod(u, v, q);
+                    a[j + t] = lo_submod(u, v, q);
+                }
+                continue;
+            }
             for (uint32_t j = j1; j < j1 + t; j++) {
                 uint64_t u = a[j], v = lo_mulmod(a[j + t], w, q);
                 a[j] = lo_addmod(u, v, q);
@@ -142,11 +164,21 @@ void lo_ntt_core(uint64_t *a, uint32_t N, uint64_t q, const uint64_t *psi_rev) {
 
 void lo_intt_core(uint64_t *a, uint32_t N, uint64_t q, const uint64_t *psi_inv_rev,
                   uint64_t n_inv) {
+    const int fast = (q >> 62) == 0;
     uint32_t t = 1;
     for (uint32_t m = N >> 1; m >= 1; m >>= 1, t <<= 1) {
         for (uint32_t i = 0; i < m; i++) {
             uint64_t w = psi_inv_rev[m + i];
             uint32_t j1 = 2 * i * t;
+            if (fast && t >= 2) {
+                const uint64_t wp = shoup_companion(w, q);
+                for (uint32_t j = j1; j < j1 + t; j++) {
+                    uint64_t u = a[j], v = a[j + t];
+                    a[j] = lo_addmod(u, v, q);
+                    a[j + t] = shoup_mul(lo_submod(u, v, q), w, wp, q);
+                }
+                continue;
+            }
             for (uint32_t j = j1; j < j1 + t; j++) {
                 uint64_t u = a[j], v = a[j + t];
                 a[j] = lo_addmod(u, v, q);
@@ -154,7 +186,12 @@ void lo_intt_core(uint64_t *a, uint32_t N, uint64_t q, const uint64_t *psi_inv_r
             }
         }
     }
-    for (uint32_t j = 0; j < N; j++) a[j] = lo_mulmod(a[j], n_inv, q);
+    if (fast) {
+        const uint64_t np = shoup_companion(n_inv, q);
+        for (uint32_t j = 0; j < N; j++) a[j] = shoup_mul(a[j], n_inv, np, q);
+    } else {
+        for (uint32_t j = 0; j < N; j++) a[j] = lo_mulmod(a[j], n_inv, q);
+    }
 }
 
 void lo_limb_ntt(const lo_params *p, uint32_t mi, uint64_t *a) {

@@ -165,3 +165,16 @@ def test_host_gather_scatter_round_trip():
     flat = np.zeros(2 * 257, dtype=np.uint64)
     assert lib.lumen_host_gather(flat.ctypes.data_as(C.POINTER(C.c_uint64)), ptrs, 2, 257, 1) != 0
     assert b"limb 1 is NULL" in lib.lumen_last_error(None)
+
+
+def test_integration_md_only_calls_what_the_header_declares():
+    """INTEGRATION.md's Go shim is never compiled here (no Go toolchain): at least every C.lumen_* call and C.LUMEN_*
+    constant it uses must exist in include/lumenos_hip.h."""
+    hdr = open(os.path.join(ROOT, "include", "lumenos_hip.h")).read()
+    syms = set(declared_symbols()) | {"lumen_ctx", "lumen_set", "lumen_group", "lumen_params_desc"}
+    consts = set(re.findall(r"#define\s+(LUMEN_[A-Z0-9_]+)", hdr))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    used, used_c = set(re.findall(r"C\.(lumen_[a-z0-9_]+)", doc)), set(re.findall(r"C\.(LUMEN_[A-Z0-9_]+)", doc))
+    assert len(used) >= 40
+    assert not used - syms, sorted(used - syms)
+    assert not used_c - consts, sorted(used_c - consts)

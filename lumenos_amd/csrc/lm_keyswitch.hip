@@ -29,6 +29,10 @@
 
 #include "lm_ks_dev.h"
 
+#ifndef LM_MODUP_RUN_STORE
+#define LM_MODUP_RUN_STORE 0 // A/B switch of k_modup_ntt's store phase (see there)
+#endif
+
 // columns processed together (scratch ~ 172 limbs per column): 64 by default, LUMEN_KS_BATCH at context
 // creation (lm_tuning)
 static uint32_t ks_batch(const lumen_ctx *ctx) { return ctx->tune.ks_batch; }
@@ -246,8 +250,21 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
     // the extended digit is stored as it leaves the last butterfly (any value below 2^64): the gadget
     // product accumulates beta products x * k, k < q, in 128 bits (beta * 2^64 * q < 2^127: at most
     // 12 digits of moduli below 2^58.4) and its reduction takes any such sum
+#if LM_MODUP_RUN_STORE // the round-4 store phase (one 64-byte run per lane), for A/B builds: -DLM_MODUP_RUN_STORE=1
     auto st = [&](uint32_t i0, const u64 *v, int count) { lm_store_run(o, i0, v, count); };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);
+#else
+    // coalesced stores through the wave's own LDS block (lm_linear_out): -3.5 % on this kernel at N = 2^14
+    lm_lds_runs st{sm};
+    auto after = [&](uint32_t, uint32_t) {
+        lm_linear_out<LOGN>(sm, tid, [&](uint32_t j, u64 v0, u64 v1) {
+            ulonglong2 y;
+            y.x = v0, y.y = v1;
+            *reinterpret_cast<ulonglong2 *>(o + j) = y;
+        });
+    };
+    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st, after);
+#endif
 }
 
 // ---- step 3: gadget product.  u[b][w][t][i] = sum_d ext[b][d][t][i] * key[d][w][t][i]
@@ -427,6 +444,7 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
 #ifndef LM_EXP_MODDOWN_R4
 #define LM_EXP_MODDOWN_R4 0
 #endif
+
 template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 *__restrict__ u, const u64 *__restrict__ acc_in,
                                                      u64 *__restrict__ acc_out, const bx_t *__restrict__ bxp,

@@ -26,11 +26,18 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_limb_ntt(const u64 *sr
     const tw_t *tw = tw_all + (size_t)mi * N;
     if (INV) {
         const tw_t ni = ninv.t[mi];
-        auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
         auto st = [&](uint32_t i, u64 v) { o[i] = lm_shoup_cs(v, ni, c.q, c.nq); };
+#if LM_EXP_INV_LIN_LOAD
+        lm_linear_in<LOGN>(sm, tid, [&](uint32_t j) { return *reinterpret_cast<const ulonglong2 *>(p + j); });
+        lm_lds_run_loader ld{sm};
+#else
+        auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
+#endif
         lm_ntt_inverse<LOGN>(sm, tw, c, tid, nthreads, ld, st);
     } else {
         auto ld = [&](uint32_t i) { return p[i]; };
+        // (coalesced output through LDS, lm_linear_out, was measured here too: 11.5 M transforms/s either way -- the plain
+        // transform keeps its stores per run; it is the extension kernel's 604 MB of fresh output that gains)
         auto st = [&](uint32_t i0, const u64 *v, int count) {
             u64 r[8];
 #pragma unroll

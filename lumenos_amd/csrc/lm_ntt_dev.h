@@ -762,6 +762,65 @@ __device__ __forceinline__ void lm_load_run(const u64 *p, uint32_t i0, u64 *v, i
         }
     }
 }
+// ---- coalesced output of a forward transform (round 5).  The last pass finishes runs of 2^R <= 8 consecutive coefficients
+// per lane; stored from there (lm_store_run) a wave's 16-byte stores sit 64 bytes apart -- four partial writes per 128-byte
+// line, and the extension kernel's store phase is sensitive to exactly that (profiles/r05_exp_linear_store.txt: -3.5 % on
+// k_modup_ntt<14>).  Instead the runs go back to the slots their lane has just consumed (lm_lds_runs as the Storer; a wave's
+// LDS operations execute in order and every slot of a wave's block is written by that wave) and lm_linear_out hands every
+// lane PAIRS of consecutive coefficients, lanes on consecutive addresses: one contiguous kilobyte per store instruction.
+struct lm_lds_runs {
+    u64 *sm;
+    __device__ __forceinline__ void operator()(uint32_t i0, const u64 *v, int count) const {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < count) sm[LM_PAD(i0 + k)] = v[k];
+    }
+};
+// f(j, v0, v1): coefficients j, j + 1 of the limb (after the wave's own last pass; no workgroup barrier)
+template <int LOGN, class F>
+__device__ __forceinline__ void lm_linear_out(const u64 *sm, uint32_t tid, F f) {
+    constexpr uint32_t NW = lm_nthreads(LOGN) / 64, BLK = (1u << LOGN) / NW, IT = BLK / 128 ? BLK / 128 : 1;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    lm_wave_sync();
+#pragma unroll
+    for (uint32_t k = 0; k < IT; k++) {
+        const uint32_t j = wave * BLK + 2 * lane + k * 128;
+        if (BLK >= 128 || 2 * lane < BLK) f(j, sm[LM_PAD(j)], sm[LM_PAD(j + 1)]);
+    }
+}
+
+// the mirror image for an inverse transform's input (its first pass reads runs of 2^R consecutive coefficients per lane):
+// every lane fetches PAIRS of consecutive coefficients f(j) -> {c[j], c[j+1]}, lanes on consecutive addresses, into the wave's
+// own LDS block; the first pass then takes its runs from LDS (lm_lds_run_loader).  A/B: LM_EXP_INV_LIN_LOAD.
+template <int LOGN, class F>
+__device__ __forceinline__ void lm_linear_in(u64 *sm, uint32_t tid, F f) {
+    constexpr uint32_t NW = lm_nthreads(LOGN) / 64, BLK = (1u << LOGN) / NW, IT = BLK / 128 ? BLK / 128 : 1;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    ulonglong2 y[IT];
+#pragma unroll
+    for (uint32_t k = 0; k < IT; k++) {
+        const uint32_t j = wave * BLK + 2 * lane + k * 128;
+        if (BLK >= 128 || 2 * lane < BLK) y[k] = f(j);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < IT; k++) {
+        const uint32_t j = wave * BLK + 2 * lane + k * 128;
+        if (BLK >= 128 || 2 * lane < BLK) sm[LM_PAD(j)] = y[k].x, sm[LM_PAD(j + 1)] = y[k].y;
+    }
+    lm_wave_sync();
+}
+struct lm_lds_run_loader {
+    const u64 *sm;
+    __device__ __forceinline__ void operator()(uint32_t i0, u64 *v, int count) const {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < count) v[k] = sm[LM_PAD(i0 + k)];
+    }
+};
+#ifndef LM_EXP_INV_LIN_LOAD
+#define LM_EXP_INV_LIN_LOAD 0
+#endif
+
 __device__ __forceinline__ void lm_store_run(u64 *p, uint32_t i0, const u64 *v, int count) {
 #pragma unroll
     for (int k = 0; k < 8; k += 2) {

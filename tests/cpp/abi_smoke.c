@@ -126,7 +126,7 @@ int main(void) {
         rc = rc || lumen_group_create(ranks, 1, LUMEN_TRANSPORT_COPY, &g);
         if (rc) return fprintf(stderr, "group: %s\n", lumen_last_error(NULL)), 17;
         if (lumen_group_world(g) != 2 || lumen_group_local(g) != 2 || strcmp(lumen_group_transport(g), "copy") ||
-            lumen_group_rccl_ranks(g) != 0)
+            lumen_group_rccl_ranks(g) != 0 || strcmp(lumen_group_transport_note(g), "stream-ordered copies on one device"))
             return fprintf(stderr, "group properties\n"), 18;
         /* rank 0 sends (a[0], a[1]), rank 1 sends (a[1], a[2]): block p of a rank's set goes to rank p, so rank 0
          * receives (a[0], a[1]) and rank 1 (a[1], a[2]) */

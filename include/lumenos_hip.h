@@ -77,7 +77,9 @@ int lumen_ctx_wait(lumen_ctx *ctx, lumen_ctx *other);
  * switches") are read from the environment ONCE, by lumen_ctx_create; clones inherit them.  This setter is
  * the in-process form for tests and tools: name = "LUMEN_KS_BATCH", "LUMEN_KS_LANES",
  * "LUMEN_KS_FUSED_DIGITS" (value < 0: derived default), "LUMEN_CT_BLOCKS", "LUMEN_DEBUG", "LUMEN_MODUP_TGROUP",
- * "LUMEN_MODDOWN_TGROUP" (work-list order of the key switch's two transform kernels); and, for the test
+ * "LUMEN_MODDOWN_TGROUP" (work-list order of the key switch's two transform kernels), "LUMEN_KS_PLACEMENT" (candidate
+ * blocks per key-switch scratch buffer among which a context's first key switch picks by measurement, 0 = none:
+ * takes effect when the buffers are next allocated, e.g. after lumen_ctx_trim); and, for the test
  * suite only (never read from the environment), "LUMEN_RCCL_SHARED_DEVICE": lumen_group_create then lets
  * LUMEN_TRANSPORT_RCCL through although ranks share a device, so that the library's RCCL call sequence can be run
  * with W > 1 on a one-GPU box against the test double tests/cpp/fake_rccl.c (real RCCL refuses such a communicator). */
@@ -421,6 +423,18 @@ int lumen_group_gather(lumen_group *g, const lumen_set *const *src, const uint32
  * arrive), bytes = what ONE rank sent to other ranks, summed over calls. */
 int lumen_group_stats(lumen_group *g, const char *name, double *ms, uint64_t *bytes, uint64_t *calls);
 int lumen_group_stats_reset(lumen_group *g);
+
+/* ---- placement diagnostics (tools/ks_mac_placement.py; not on the product path).
+ * lumen_ctx_scratch_info: device address and size of one of the context's named scratch buffers ("ks_ext", "ks_u",
+ * "ks_coef", "ks_acc2", "ks_acc", ...); *ptr = NULL if it has not been allocated.
+ * lumen_ks_mac_probe: HIP-event time of the gadget-product kernel of a key switch (step 3 of Lattigo's hybrid
+ * key switching as InnerSum runs it, fhe/ligero.go:325) alone, on caller-chosen device blocks of at least -- ext
+ * batch * beta * (L+K) * N, acc batch * 2 * L * N, key beta * 2 * (L+K) * N, u batch * 2 * (L+K) * N words; NULL = the
+ * block the library itself uses (batch 0 = the library's batch size).  Contents are irrelevant (data-independent
+ * kernel). */
+int lumen_ctx_scratch_info(lumen_ctx *ctx, const char *name, void **ptr, size_t *bytes);
+int lumen_ks_mac_probe(lumen_ctx *ctx, uint32_t batch, const void *ext, const void *acc, const void *key, void *u,
+                       uint32_t reps, float *ms_per_launch);
 
 /* ---- timing on the context's stream (bench.py / roofline) */
 int lumen_timer_start(lumen_ctx *ctx);

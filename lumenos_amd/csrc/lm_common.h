@@ -35,7 +35,7 @@ struct lm_prof_entry {
 };
 
 struct lm_galois_key {
-    u64 *d_key = nullptr;   // [beta][2][L+K][N], Montgomery form
+    u64 *d_key = nullptr;   // [L+K][beta][2][N] (lm_keyswitch.hip, ks_key_at), Montgomery form
     uint32_t *d_index = nullptr; // automorphism gather table, N entries: out[i] = in[index[i]]
     uint32_t *d_inv_index = nullptr; // its inverse: out[inv_index[p]] = in[p]
 };
@@ -86,6 +86,9 @@ struct lm_tuning {
     // LUMEN_MODUP_TGROUP / LUMEN_MODDOWN_TGROUP: target limbs one XCD walks back to back in the work lists of the
     // two transform kernels of a key switch (lm_keyswitch.hip); 1 .. 31
     uint32_t modup_tgroup = 4, moddown_tgroup = 4;
+    // LUMEN_KS_PLACEMENT: candidate blocks per key-switch scratch buffer among which the first key switch of a context
+    // picks by measurement (lm_keyswitch.hip, select_placement); 0 or 1 = take what hipMalloc returns
+    uint32_t ks_placement = 6;
     // LUMEN_RCCL_SHARED_DEVICE (tests only): LUMEN_TRANSPORT_RCCL accepts ranks that share a device.  Real RCCL
     // refuses such a communicator itself; the switch exists so that the RCCL call sequence of lm_group.hip can run
     // with W > 1 on a one-GPU box against tests/cpp/fake_rccl.c
@@ -254,6 +257,7 @@ void lm_set_release_async(lumen_ctx *ctx, lumen_set *set);
 
 // scratch buffer that persists in the context and only grows
 void *lm_scratch(lumen_ctx *ctx, const char *name, size_t bytes);
+void lm_scratch_adopt(lumen_ctx *ctx, const char *name, void *p, size_t bytes);
 
 // profiling bracket: records HIP-event time of what is enqueued between begin/end
 struct lm_prof_scope {

@@ -42,6 +42,18 @@ void *lm_scratch(lumen_ctx *ctx, const char *name, size_t bytes) {
     return p;
 }
 
+// puts a block the caller allocated (hipMalloc) under a scratch name; whatever was there is freed after the context's
+// streams have drained.  For buffers whose PLACEMENT was chosen (lm_keyswitch.hip, select_placement).
+void lm_scratch_adopt(lumen_ctx *ctx, const char *name, void *p, size_t bytes) {
+    auto &e = ctx->scratch[name];
+    if (e.first && e.first != p) {
+        lm_sync_all(ctx);
+        hipFree(e.first);
+    }
+    e.first = p;
+    e.second = bytes;
+}
+
 lm_shared::~lm_shared() {
     hipFree(d_tw_fwd);
     hipFree(d_tw_inv);
@@ -186,13 +198,14 @@ static int tuning_set(lm_tuning &t, const char *name, long v) {
     else if (n == "LUMEN_DEBUG") t.debug = v != 0;
     else if (n == "LUMEN_MODUP_TGROUP") t.modup_tgroup = (v >= 1 && v <= 31) ? (uint32_t)v : 4;
     else if (n == "LUMEN_MODDOWN_TGROUP") t.moddown_tgroup = (v >= 1 && v <= 31) ? (uint32_t)v : 4;
+    else if (n == "LUMEN_KS_PLACEMENT") t.ks_placement = (v >= 0 && v <= 32) ? (uint32_t)v : 6;
     else if (n == "LUMEN_RCCL_SHARED_DEVICE") t.rccl_shared_device = v != 0; // tests only, never from the environment
     else return 1;
     return 0;
 }
 static void tuning_from_env(lm_tuning &t) {
     for (const char *n : {"LUMEN_KS_BATCH", "LUMEN_KS_LANES", "LUMEN_KS_FUSED_DIGITS", "LUMEN_CT_BLOCKS", "LUMEN_DEBUG",
-                          "LUMEN_MODUP_TGROUP", "LUMEN_MODDOWN_TGROUP"}) {
+                          "LUMEN_MODUP_TGROUP", "LUMEN_MODDOWN_TGROUP", "LUMEN_KS_PLACEMENT"}) {
         const char *e = getenv(n);
         if (e && *e) tuning_set(t, n, atol(e)); // an empty override counts as unset
     }
@@ -354,6 +367,17 @@ extern "C" int lumen_ctx_trim(lumen_ctx *ctx) {
         it = ctx->scratch.erase(it);
     }
     pool_drain(ctx);
+    return 0;
+}
+
+// where a named scratch buffer of the context sits (diagnostics: tools/ks_mac_placement.py); *ptr = NULL when the
+// context has not allocated it (yet)
+extern "C" int lumen_ctx_scratch_info(lumen_ctx *ctx, const char *name, void **ptr, size_t *bytes) {
+    LM_CHECK(nullptr, ctx && name && ptr, "lumen_ctx_scratch_info: NULL argument");
+    LM_ENTER(ctx);
+    auto it = ctx->scratch.find(name);
+    *ptr = it == ctx->scratch.end() ? nullptr : it->second.first;
+    if (bytes) *bytes = it == ctx->scratch.end() ? 0 : it->second.second;
     return 0;
 }
 

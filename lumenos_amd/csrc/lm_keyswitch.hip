@@ -33,6 +33,29 @@
 #define LM_MODUP_RUN_STORE 0 // A/B switch of k_modup_ntt's store phase (see there)
 #endif
 
+// Layout of the key switch's three big streams, in limbs of N words: LIMB-MAJOR (round 6).  The gadget product walks
+// ONE modulus t at a time over every (column, digit); with the modulus outermost everything one of its workgroups
+// touches -- 4 columns x beta digits of `ext`, the 2 beta key limbs, its 8 output limbs -- sits in a few MB of
+// contiguous addresses (a handful of 2 MB translations), and the chip as a whole streams one 48 MB region of `ext`
+// and one 16 MB region of `u` at a time.  Rounds 1-5 kept the column outermost ([b][d][t], [b][w][t], [d][w][t]:
+// 36 + 8 blocks 1.75 MB apart per workgroup): the gadget product took 5-8 % longer and the extension kernel, which
+// writes `ext`, 3.7 % (profiles/r06_exp_ks_layout.txt; same residues).
+// limb t of digit d of column b in the extended-digit buffer: [L+K][B][beta]
+__host__ __device__ __forceinline__ size_t ks_ext_at(uint32_t b, uint32_t d, uint32_t t, uint32_t B, uint32_t beta) {
+    return ((size_t)t * B + b) * beta + d;
+}
+// limb t of polynomial pw = 2 b + w of the gadget product's output u: the Q limbs [L][2B], behind them the limbs
+// modulo P as [2B][K] -- the K limbs of one polynomial stay adjacent (their inverse transform, the packing pass and
+// ModDown's lift read them as a pair)
+__host__ __device__ __forceinline__ size_t ks_u_at(uint32_t pw, uint32_t t, uint32_t B, uint32_t L, uint32_t K) {
+    return t < L ? (size_t)t * 2 * B + pw : (size_t)L * 2 * B + (size_t)pw * K + (t - L);
+}
+// limb t of polynomial w of digit d of a switching key as the gadget product reads it: [L+K][beta][2]
+// (lumen_load_galois_key takes the caller's [beta][2][L+K] and k_key_prepare permutes)
+__host__ __device__ __forceinline__ size_t ks_key_at(uint32_t d, uint32_t w, uint32_t t, uint32_t beta) {
+    return ((size_t)t * beta + d) * 2 + w;
+}
+
 // columns processed together (scratch ~ 172 limbs per column): 64 by default, LUMEN_KS_BATCH at context
 // creation (lm_tuning)
 static uint32_t ks_batch(const lumen_ctx *ctx) { return ctx->tune.ks_batch; }
@@ -226,7 +249,7 @@ __global__ void k_mul_plain(const u64 *__restrict__ ct, u64 *__restrict__ out, c
 }
 
 // ---- step 2: digit extension + NTT.  One workgroup per (column b, digit d, target t).
-// coef: [B][L][N] coefficient-domain c1; acc: [B][2][L][N] (c1 NTT values for own limbs); ext: [B][beta][L+K][N]
+// coef: [B][L][N] coefficient-domain c1; acc: [B][2][L][N] (c1 NTT values for own limbs); ext: [L+K][B][beta][N] (ks_ext_at)
 template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *__restrict__ coef, const u64 *__restrict__ acc,
                                                     u64 *__restrict__ ext, const bx_t *__restrict__ bx,
@@ -242,7 +265,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
     const uint32_t wk = work[blockIdx.x];
     const uint32_t b = wk & 0xFFFF, d = (wk >> 16) & 0xFF, t = wk >> 24; // t: modulus index (Q limbs then P limbs)
     const bx_t c = bx[d * LK + t];
-    u64 *o = ext + (((size_t)b * beta + d) * LK + t) * N;
+    u64 *o = ext + ks_ext_at(b, d, t, B, beta) * N;
     const lm_qc qc = lm_make_qc(mods.m[t]);
     const u64 *s0 = coef + ((size_t)b * L + d * K) * N;
     const u64 *s1 = c.ns == 2 ? s0 + N : s0; // second limb of the digit
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
 #endif
 }
 
-// ---- step 3: gadget product.  u[b][w][t][i] = sum_d ext[b][d][t][i] * key[d][w][t][i]
+// ---- step 3: gadget product.  u[b][w][t][i] = sum_d ext[b][d][t][i] * key[d][w][t][i]  (storage: ks_u_at, ks_ext_at, ks_key_at)
 // key in Montgomery form (k * 2^64 mod q): 128-bit accumulation, one Montgomery reduction.
 // COLS columns share one read of the key limb (the key is re-read B/COLS times per launch, out of
 // L2 / Infinity Cache); VEC consecutive coefficients per thread move as one VEC*8-byte access.
@@ -397,13 +420,13 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
     };
     auto fetch = [&](uint32_t d) {
         digit_t g;
-        g.k0 = vec::load(key + (((size_t)d * 2 + 0) * LK + t) * N + i);
-        g.k1 = vec::load(key + (((size_t)d * 2 + 1) * LK + t) * N + i);
+        g.k0 = vec::load(key + ks_key_at(d, 0, t, beta) * N + i);
+        g.k1 = vec::load(key + ks_key_at(d, 1, t, beta) * N + i);
 #pragma unroll
         for (int c = 0; c < LM_MAC_COLS; c++) {
             const uint32_t bc = b0 + c < B ? b0 + c : B - 1;
             g.x[c] = d == own ? vec::load(acc + ((size_t)(bc * 2 + 1) * L + t) * N + i)
-                              : vec::load_once(ext + (((size_t)bc * beta + d) * LK + t) * N + i);
+                              : vec::load_once(ext + ks_ext_at(bc, d, t, B, beta) * N + i);
         }
         return g;
     };
@@ -419,7 +442,7 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
 #pragma unroll
     for (int c = 0; c < LM_MAC_COLS; c++) {
         if (b0 + c < B) {
-            u64 *o = u + ((size_t)(b0 + c) * 2 * LK + t) * N + i;
+            u64 *o = u + ks_u_at((b0 + c) * 2, t, B, L, K) * N + i, *o1 = u + ks_u_at((b0 + c) * 2 + 1, t, B, L, K) * N + i;
             vec r0, r1;
 #pragma unroll
             for (int e = 0; e < LM_MAC_VEC; e++) {
@@ -430,7 +453,7 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
                 r1.v[e] = lm_mont_reduce_wide(lo, hi, md.q, md.qneg, md.qinv64, beta);
             }
             r0.store(o);
-            r1.store(o + (size_t)LK * N);
+            r1.store(o1);
         }
     }
 }
@@ -456,7 +479,7 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
                                                      const tw_t *__restrict__ tw_all) {
     extern __shared__ __attribute__((aligned(16))) u64 sm[];
     constexpr uint32_t N = 1u << LOGN;
-    const uint32_t tid = threadIdx.x, nthreads = blockDim.x, LK = L + K;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     // host-built, XCD-aware order (moddown_work_list): the Q limbs of one polynomial, which all lift the
     // same two P-limb words, run back to back on one XCD
     const uint32_t wk = work[blockIdx.x];
@@ -465,9 +488,9 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
     const uint32_t w = pw & 1;
     const bx_t c = bxp[t];
     const lm_qc qc = lm_make_qc(mods.m[t]);
-    const u64 *up0 = u + ((size_t)pw * LK + L) * N; // P limbs of u, coefficient domain
+    const u64 *up0 = u + ks_u_at(pw, L, B, L, K) * N; // P limbs of u, coefficient domain
     const u64 *up1 = c.ns == 2 ? up0 + N : up0;
-    const u64 *uq = u + ((size_t)pw * LK + t) * N;
+    const u64 *uq = u + ks_u_at(pw, t, B, L, K) * N;
     const u64 *ain = acc_in + ((size_t)pw * L + t) * N; // c0 (w == 0) / c1 (w == 1) limb of the accumulator
     u64 *aout = acc_out + ((size_t)pw * L + t) * N;
     // -P^-1 as a Shoup constant: (q - w, ~w') -- floor((q - w) * 2^64 / q) = 2^64 - 1 - floor(w * 2^64 / q) for
@@ -808,16 +831,6 @@ static int moddown_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uin
     return 0;
 }
 
-int get_scratch(lumen_ctx *ctx, uint32_t B, uint32_t beta, KsScratch *s, int lane = 0) {
-    const size_t N = ctx->N, L = ctx->L, LK = ctx->L + ctx->K;
-    const char *names[2][4] = {{"ks_coef", "ks_ext", "ks_u", "ks_acc2"}, {"ks_coef_b", "ks_ext_b", "ks_u_b", "ks_acc2_b"}};
-    s->coef = (u64 *)lm_scratch(ctx, names[lane][0], (size_t)B * L * N * 8);
-    s->ext = (u64 *)lm_scratch(ctx, names[lane][1], (size_t)B * beta * LK * N * 8);
-    s->u = (u64 *)lm_scratch(ctx, names[lane][2], (size_t)B * 2 * LK * N * 8);
-    s->acc2 = (u64 *)lm_scratch(ctx, names[lane][3], (size_t)B * 2 * L * N * 8);
-    return (s->coef && s->ext && s->u && s->acc2) ? 0 : 1;
-}
-
 // Enqueue on the context's second stream for the lifetime of the guard.  Independent column
 // batches alternate between the two streams so that the HBM-bound steps of one batch (gadget
 // product, correction-bit pass) overlap the VALU-bound transforms of the other.
@@ -954,13 +967,14 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
         lm_modmap mp;
         mp.period = K;
         for (uint32_t i = 0; i < LM_MAX_LIMBS; i++) mp.idx[i] = (uint8_t)(L + (i < K ? i : 0));
-        if (int rc = lm_launch_ntt_strided(ctx, s.u + (size_t)L * N, (size_t)LK * N, s.u + (size_t)L * N,
-                                           (size_t)LK * N, B * 2, mp, true, "ks_intt_p", &tb->yscale))
+        u64 *up = s.u + ks_u_at(0, L, B, L, K) * N; // the limbs modulo P: [2B][K]
+        const size_t pstride = (size_t)K * N;
+        if (int rc = lm_launch_ntt_strided(ctx, up, pstride, up, pstride, B * 2, mp, true, "ks_intt_p", &tb->yscale))
             return rc;
         if (K == 2) {
             lm_prof_scope ps(ctx, "ks_pack_v", (uint64_t)B);
-            hipLaunchKernelGGL(k_pack_v, dim3(2048), dim3(256), 0, ctx->stream, s.u + (size_t)L * N,
-                               (size_t)LK * N, B * 2, 1u, K, L, K, ctx->logN, ctx->mods);
+            hipLaunchKernelGGL(k_pack_v, dim3(2048), dim3(256), 0, ctx->stream, up, pstride, B * 2, 1u, K, L, K,
+                               ctx->logN, ctx->mods);
             LM_HIP(ctx, hipGetLastError());
         }
     }
@@ -984,6 +998,120 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
         }
         LM_HIP(ctx, hipGetLastError());
     }
+    return 0;
+}
+
+// ---- the key switch's scratch buffers, and WHERE in HBM they sit.
+// Measured in round 6 (profiles/r06_exp_ks_mac_placement.txt): the time of the gadget product is a deterministic
+// function of the physical placement of its streams -- two processes that draw the same addresses reproduce each
+// other's times to 0.2 %; exchanging only the block `u` is written to, or only the block `ext` is read from, for
+// another allocation of the same size moves the kernel by up to 16 % / 7 %; the relative offset of the two inside
+// one allocation (4 KB .. 64 MB) moves it by nothing, and one stream alone reads / writes every block at the same rate.
+// It is the pairing of a read stream's and a write stream's 2 MB pages (high physical address bits: DRAM rank /
+// bank-group assignment, invisible and uncontrollable from user space) -- which is why `ks_mac` was constant inside
+// a process and 341 .. 381 ms per step between processes.  So the first key switch of a context allocates
+// LUMEN_KS_PLACEMENT (6) candidates per buffer and keeps, buffer by buffer, the one under which two rotations of a
+// whole batch run fastest (coordinate descent in the order the sensitivities were measured: u, ext, then the
+// accumulator's twin and the coefficient buffer); the others are freed.  One-off cost at the headline size: about
+// 0.2 s and 7.5 GB of transient device memory.  Results do not depend on the choice (same kernels, same residues).
+int get_scratch(lumen_ctx *ctx, uint32_t B, KsTables *tb, KsScratch *s, int lane = 0) {
+    const size_t N = ctx->N, L = ctx->L, LK = ctx->L + ctx->K, beta = tb->beta;
+    const char *names[2][4] = {{"ks_coef", "ks_ext", "ks_u", "ks_acc2"}, {"ks_coef_b", "ks_ext_b", "ks_u_b", "ks_acc2_b"}};
+    const size_t bytes[4] = {(size_t)B * L * N * 8, (size_t)B * beta * LK * N * 8, (size_t)B * 2 * LK * N * 8, (size_t)B * 2 * L * N * 8};
+    u64 **slot[4] = {&s->coef, &s->ext, &s->u, &s->acc2};
+    bool have = true;
+    for (int c = 0; c < 4; c++) {
+        auto it = ctx->scratch.find(names[lane][c]);
+        have = have && it != ctx->scratch.end() && it->second.first && it->second.second >= bytes[c];
+    }
+    lm_galois_key gk;
+    {
+        LM_SHARED_LOCK(ctx);
+        if (!ctx->gkeys.empty()) gk = ctx->gkeys.begin()->second;
+    }
+    const uint32_t Kc = ctx->tune.ks_placement;
+    // small buffers live in the caches, and without a key no rotation can be timed: plain allocation
+    if (have || Kc < 2 || bytes[1] < ((size_t)64 << 20) || !gk.d_key) {
+        for (int c = 0; c < 4; c++) *slot[c] = (u64 *)lm_scratch(ctx, names[lane][c], bytes[c]);
+        return (s->coef && s->ext && s->u && s->acc2) ? 0 : 1;
+    }
+    std::vector<void *> cand[4];
+    void *probe_acc = nullptr;
+    auto free_all = [&] {
+        for (int c = 0; c < 4; c++)
+            for (void *p : cand[c]) hipFree(p);
+        hipFree(probe_acc);
+        (void)hipGetLastError();
+    };
+    if (hipMalloc(&probe_acc, bytes[3]) != hipSuccess) probe_acc = nullptr;
+    for (uint32_t k = 0; k < Kc && probe_acc; k++) // round-robin over the buffers: the candidates of one buffer are spread out
+        for (int c = 0; c < 4; c++) {
+            void *p = nullptr;
+            if (hipMalloc(&p, bytes[c]) == hipSuccess) cand[c].push_back(p);
+        }
+    (void)hipGetLastError();
+    if (!probe_acc || cand[0].empty() || cand[1].empty() || cand[2].empty() || cand[3].empty()) { // memory is short: no choice to make
+        free_all();
+        for (int c = 0; c < 4; c++) *slot[c] = (u64 *)lm_scratch(ctx, names[lane][c], bytes[c]);
+        return (s->coef && s->ext && s->u && s->acc2) ? 0 : 1;
+    }
+    const bool prof = ctx->prof;
+    ctx->prof = false; // the rotations below are not part of anybody's measurement
+    hipEvent_t e0 = lm_ev_get(ctx), e1 = lm_ev_get(ctx);
+    size_t pick[4] = {0, 0, 0, 0};
+    int rc = 0;
+    auto eval = [&](float *ms) -> int { // two rotations of a batch (the accumulator ping-pongs): one untimed, two timed pairs
+        KsScratch t;
+        t.coef = (u64 *)cand[0][pick[0]], t.ext = (u64 *)cand[1][pick[1]], t.u = (u64 *)cand[2][pick[2]], t.acc2 = (u64 *)cand[3][pick[3]];
+        for (int r = 0; r < 3; r++) {
+            if (r == 1) LM_HIP(ctx, hipEventRecord(e0, ctx->stream));
+            if (int e = rotate_accumulate(ctx, (u64 *)probe_acc, t.acc2, B, gk, tb, t)) return e;
+            if (int e = rotate_accumulate(ctx, t.acc2, (u64 *)probe_acc, B, gk, tb, t)) return e;
+        }
+        LM_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        LM_HIP(ctx, hipEventSynchronize(e1));
+        LM_HIP(ctx, hipEventElapsedTime(ms, e0, e1));
+        return 0;
+    };
+    float first = 0, best_all = 0;
+    static const int order[4] = {2, 1, 3, 0}; // u, ext, acc2, coef
+    for (int oi = 0; oi < 4 && !rc; oi++) {
+        const int c = order[oi];
+        float best = 0;
+        size_t arg = 0;
+        for (size_t k = 0; k < cand[c].size() && !rc; k++) {
+            if (oi > 0 && k == pick[c]) continue; // timed as the previous buffer's winner
+            const size_t keep = pick[c];
+            pick[c] = k;
+            float ms = 0;
+            rc = eval(&ms);
+            pick[c] = keep;
+            if (oi == 0 && k == 0) first = ms;
+            if (best == 0 || ms < best) best = ms, arg = k;
+        }
+        if (best == 0 || (oi > 0 && best_all > 0 && best_all <= best)) arg = pick[c]; // nothing beat the configuration already measured
+        else best_all = best;
+        pick[c] = arg;
+    }
+    ctx->ev_pool.push_back(e0);
+    ctx->ev_pool.push_back(e1);
+    ctx->prof = prof;
+    if (rc) {
+        lm_sync_all(ctx);
+        free_all();
+        return rc;
+    }
+    if (ctx->tune.debug)
+        fprintf(stderr, "[lumenos_hip] key-switch scratch placement (lane %d, %u columns): %zu candidates per buffer, 4 rotations of the "
+                        "first draw %.3f ms, of the chosen blocks %.3f ms\n", lane, B, cand[2].size(), first, best_all);
+    for (int c = 0; c < 4; c++) {
+        void *chosen = cand[c][pick[c]];
+        cand[c][pick[c]] = nullptr; // hipFree(nullptr) is a no-op
+        lm_scratch_adopt(ctx, names[lane][c], chosen, bytes[c]);
+        *slot[c] = (u64 *)chosen;
+    }
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the losers are freed: nothing may still run on them
+    free_all();
     return 0;
 }
 
@@ -1052,6 +1180,47 @@ int launch_mul_plain(lumen_ctx *ctx, const u64 *ct, u64 *out, const u64 *ptT, si
 
 } // namespace
 
+// Times the gadget product alone on caller-chosen device blocks: how its speed depends on WHERE in HBM its
+// three streams sit (tools/ks_mac_placement.py).  A NULL block = the one the product itself uses (the key
+// switch's scratch, the first Galois key loaded).  The blocks' contents are whatever they hold: the kernel's
+// control flow does not depend on data.  HIP-event time of `reps` launches on the context's stream.
+extern "C" int lumen_ks_mac_probe(lumen_ctx *ctx, uint32_t batch, const void *ext, const void *acc, const void *key,
+                                  void *u, uint32_t reps, float *ms_per_launch) {
+    LM_CHECK(nullptr, ctx && ms_per_launch, "lumen_ks_mac_probe: NULL argument");
+    LM_ENTER(ctx);
+    KsTables *tb = nullptr;
+    if (int rc = get_tables(ctx, &tb)) return rc;
+    const uint32_t N = ctx->N, L = ctx->L, K = ctx->K, LK = L + K, B = batch ? batch : ks_batch(ctx);
+    LM_CHECK(ctx, B <= 65535 && reps >= 1 && reps <= 100000, "lumen_ks_mac_probe: batch %u / reps %u out of range", B, reps);
+    KsScratch s;
+    if (int rc = get_scratch(ctx, B, tb, &s)) return rc;
+    if (!acc) acc = lm_scratch(ctx, "ks_acc", (size_t)B * 2 * L * N * 8);
+    if (!acc) return 1;
+    if (!key) {
+        LM_SHARED_LOCK(ctx);
+        LM_CHECK(ctx, !ctx->gkeys.empty(), "lumen_ks_mac_probe: no Galois key loaded");
+        key = ctx->gkeys.begin()->second.d_key;
+    }
+    const u64 *pe = ext ? (const u64 *)ext : s.ext;
+    u64 *pu = u ? (u64 *)u : s.u;
+    dim3 grid(((N / LM_MAC_VEC + 255) / 256) * LK * ((B + LM_MAC_COLS - 1) / LM_MAC_COLS));
+    auto launch = [&] {
+        hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, pe, (const u64 *)acc, (const u64 *)key, pu, B, L, K,
+                           tb->beta, ctx->logN, ctx->mods);
+    };
+    for (int i = 0; i < 3; i++) launch();
+    LM_HIP(ctx, hipGetLastError());
+    LM_HIP(ctx, hipEventRecord(ctx->tm0, ctx->stream));
+    for (uint32_t i = 0; i < reps; i++) launch();
+    LM_HIP(ctx, hipGetLastError());
+    LM_HIP(ctx, hipEventRecord(ctx->tm1, ctx->stream));
+    LM_HIP(ctx, hipEventSynchronize(ctx->tm1));
+    float ms = 0;
+    LM_HIP(ctx, hipEventElapsedTime(&ms, ctx->tm0, ctx->tm1));
+    *ms_per_launch = ms / (float)reps;
+    return 0;
+}
+
 extern "C" uint32_t lumen_inner_sum_galois_elements(const lumen_ctx *ctx, uint32_t n, uint64_t *gal_els) {
     // InnerSum(ct, 1, n), n a power of two: rotations by 2^i; when n == N the
     // column rotations span one slot row (N/2) and the rows are folded with the
@@ -1073,11 +1242,13 @@ extern "C" uint32_t lumen_inner_sum_galois_elements(const lumen_ctx *ctx, uint32
 // A residue >= q is reported through `bad` (the smallest offending row [digit][b|a][limb]).
 __global__ __launch_bounds__(256) void k_key_prepare(const u64 *__restrict__ src, u64 *__restrict__ dst, uint32_t logN, uint32_t LK,
                                                      size_t words, lm_mods mods, lm_ninv_t fac, uint32_t *__restrict__ bad) {
+    const uint32_t beta = (uint32_t)((words >> logN) / (2 * LK));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t row = (uint32_t)(i >> logN), t = row % LK;
+        const uint32_t row = (uint32_t)(i >> logN), t = row % LK; // row = (d * 2 + w) * LK + t: the caller's order
         const u64 q = mods.m[t].q, x = src[i];
         if (x >= q) atomicMin(bad, row);
-        dst[i] = lm_shoup_cs(x, fac.t[t], q, 0 - q);
+        const size_t o = (ks_key_at(row / (2 * LK), (row / LK) & 1, t, beta) << logN) + (i & (((size_t)1 << logN) - 1));
+        dst[o] = lm_shoup_cs(x, fac.t[t], q, 0 - q);
     }
 }
 
@@ -1208,7 +1379,7 @@ extern "C" int lumen_inner_sum(lumen_ctx *ctx, const lumen_set *in, uint32_t n, 
         LM_HIP(ctx, hipMemcpyAsync(o->d, in->d, in->words * 8, hipMemcpyDeviceToDevice, ctx->stream));
     const uint32_t Bmax = std::min<uint32_t>(ks_batch(ctx), std::max(in->count, 1u));
     KsScratch s;
-    if (get_scratch(ctx, Bmax, tb->beta, &s)) return 1;
+    if (int rc = get_scratch(ctx, Bmax, tb, &s)) return rc;
     const size_t ctw = (size_t)2 * in->nl * ctx->N;
     for (uint32_t first = 0; first < in->count; first += Bmax) {
         const uint32_t B = std::min(Bmax, in->count - first);
@@ -1243,7 +1414,7 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
     u64 *acc = (u64 *)lm_scratch(ctx, "ks_acc", (size_t)group * ctw * 8);
     u64 *work = (u64 *)lm_scratch(ctx, "rescale_work", (size_t)group * ctw * 8);
     u64 *tbuf = (u64 *)lm_scratch(ctx, "rescale_t", (size_t)group * 2 * N * 8);
-    if (get_scratch(ctx, Bmax, tb->beta, &s[0], 0) || (ks_lanes(ctx) > 1 && get_scratch(ctx, Bmax, tb->beta, &s[1], 1)) ||
+    if (get_scratch(ctx, Bmax, tb, &s[0], 0) || (ks_lanes(ctx) > 1 && get_scratch(ctx, Bmax, tb, &s[1], 1)) ||
         !acc || !work || !tbuf)
         return 1;
     for (uint32_t g0 = 0; g0 < matrix->count; g0 += group) {

@@ -120,6 +120,8 @@ SYMBOLS = {
     "lumen_group_gather": (C.c_int, [_vp, _vpp, _u32p, C.c_uint32, _vpp]),
     "lumen_group_stats": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "lumen_group_stats_reset": (C.c_int, [_vp]),
+    "lumen_ctx_scratch_info": (C.c_int, [_vp, C.c_char_p, _vpp, C.POINTER(C.c_size_t)]),
+    "lumen_ks_mac_probe": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_float)]),
     "lumen_timer_start": (C.c_int, [_vp]),
     "lumen_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "lumen_prof_enable": (C.c_int, [_vp, C.c_int]),
@@ -337,6 +339,20 @@ class Context:
     def set_tuning(self, name, value):
         """A/B switch of the tools and tests (lumen_ctx_set_tuning); the environment is only read at creation"""
         self._ck(self.lib.lumen_ctx_set_tuning(self.h, name.encode(), int(value)))
+
+    def scratch_info(self, name):
+        """-> (device address or None, bytes) of a named scratch buffer of the context (placement diagnostics)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.lumen_ctx_scratch_info(self.h, name.encode(), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def ks_mac_probe(self, batch=0, ext=None, acc=None, key=None, u=None, reps=100):
+        """ms per launch of the key switch's gadget product alone on the given device addresses (None = the
+        library's own blocks)"""
+        ms = C.c_float()
+        self._ck(self.lib.lumen_ks_mac_probe(self.h, batch, C.c_void_p(ext), C.c_void_p(acc), C.c_void_p(key),
+                                             C.c_void_p(u), reps, C.byref(ms)))
+        return ms.value
 
     def upload_into(self, s, host, first=0):
         """upload ciphertexts [first, first + len(host)) of a set (possibly another context's) on THIS context's

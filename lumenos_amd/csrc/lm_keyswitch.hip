@@ -300,6 +300,9 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
 #ifndef LM_MAC_VEC
 #define LM_MAC_VEC 1
 #endif
+#ifndef LM_MAC_PREFETCH
+#define LM_MAC_PREFETCH 1
+#endif
 template <int VEC>
 struct mac_vec;
 template <>
@@ -430,14 +433,25 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
         }
         return g;
     };
-    digit_t cur = fetch(0);
-    for (uint32_t d = 0; d < beta; d++) {
-        const digit_t nxt = fetch(d + 1 < beta ? d + 1 : d);
+    // software pipeline over the digits: the loads of digit d + PF are issued before the multiply-adds of digit d
+    // (the ring of PF + 1 register sets is indexed statically: the loop advances by whole turns of it)
+    constexpr int PF = LM_MAC_PREFETCH;
+    digit_t q[PF + 1];
 #pragma unroll
-        for (int c = 0; c < LM_MAC_COLS; c++)
+    for (int j = 0; j < PF; j++)
+        if ((uint32_t)j < beta) q[j] = fetch(j);
+    for (uint32_t d0 = 0; d0 < beta; d0 += PF + 1) {
 #pragma unroll
-            for (int e = 0; e < LM_MAC_VEC; e++) mac2(a0[c][e], a1[c][e], cur.x[c].v[e], cur.k0.v[e], cur.k1.v[e]);
-        cur = nxt;
+        for (int j = 0; j <= PF; j++) {
+            const uint32_t d = d0 + j;
+            if (d < beta) { // wave-uniform
+                if (d + PF < beta) q[(j + PF) % (PF + 1)] = fetch(d + PF);
+#pragma unroll
+                for (int c = 0; c < LM_MAC_COLS; c++)
+#pragma unroll
+                    for (int e = 0; e < LM_MAC_VEC; e++) mac2(a0[c][e], a1[c][e], q[j].x[c].v[e], q[j].k0.v[e], q[j].k1.v[e]);
+            }
+        }
     }
 #pragma unroll
     for (int c = 0; c < LM_MAC_COLS; c++) {

@@ -29,10 +29,6 @@
 
 #include "lm_ks_dev.h"
 
-#ifndef LM_MODUP_RUN_STORE
-#define LM_MODUP_RUN_STORE 0 // A/B switch of k_modup_ntt's store phase (see there)
-#endif
-
 // Layout of the key switch's three big streams, in limbs of N words: LIMB-MAJOR (round 6).  The gadget product walks
 // ONE modulus t at a time over every (column, digit); with the modulus outermost everything one of its workgroups
 // touches -- 4 columns x beta digits of `ext`, the 2 beta key limbs, its 8 output limbs -- sits in a few MB of
@@ -273,11 +269,8 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
     // the extended digit is stored as it leaves the last butterfly (any value below 2^64): the gadget
     // product accumulates beta products x * k, k < q, in 128 bits (beta * 2^64 * q < 2^127: at most
     // 12 digits of moduli below 2^58.4) and its reduction takes any such sum
-#if LM_MODUP_RUN_STORE // the round-4 store phase (one 64-byte run per lane), for A/B builds: -DLM_MODUP_RUN_STORE=1
-    auto st = [&](uint32_t i0, const u64 *v, int count) { lm_store_run(o, i0, v, count); };
-    lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st);
-#else
-    // coalesced stores through the wave's own LDS block (lm_linear_out): -3.5 % on this kernel at N = 2^14
+    // coalesced stores through the wave's own LDS block (lm_linear_out): -3.5 % on this kernel at N = 2^14 against one 64-byte run per
+    // lane straight from the registers (tools/exp_modup_run_store.patch, profiles/r05_exp_linear_store.txt)
     lm_lds_runs st{sm};
     auto after = [&](uint32_t, uint32_t) {
         lm_linear_out<LOGN>(sm, tid, [&](uint32_t j, u64 v0, u64 v1) {
@@ -287,7 +280,6 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_modup_ntt(const u64 *_
         });
     };
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st, after);
-#endif
 }
 
 // ---- step 3: gadget product.  u[b][w][t][i] = sum_d ext[b][d][t][i] * key[d][w][t][i]  (storage: ks_u_at, ks_ext_at, ks_key_at)

@@ -470,10 +470,6 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
 // parked in LDS; then every wave writes one block of the new accumulator limb linearly,
 // acc_out[j] = acc_in[j] + d[index[j]], the automorphism being a gather out of the wave's own LDS block.  (acc is
 // ping-ponged: an output needs the old accumulator at two positions, j and index[j].)
-#ifndef LM_EXP_MODDOWN_R4
-#define LM_EXP_MODDOWN_R4 0
-#endif
-
 template <int LOGN>
 __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 *__restrict__ u, const u64 *__restrict__ acc_in,
                                                      u64 *__restrict__ acc_out, const bx_t *__restrict__ bxp,
@@ -527,15 +523,8 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
                     // lumen_load_galois_key); the multiplication takes the unreduced lift and leaves [0, 3q) on top
                     // of its addend: u' (+ c0 < 2q for w == 0).  NOTHING is reduced here -- d < 6q goes to LDS as it
                     // is, and the one reduction of a rotation happens where the accumulator word is formed (below).
-#if LM_EXP_MODDOWN_R4 // the round-4 store phase, for A/B builds only (tools/build_variant.sh moddown_r4 -DLM_EXP_MODDOWN_R4=1)
-                    u64 x = lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq, uv[k]);
-                    x = lm_csub(lm_csub(x, 2 * qc.q), qc.q);
-                    if (w == 0) x = lm_addmod(x, cv[k], qc.q);
-                    sm[LM_PAD(i0 + k)] = x;
-#else
                     const u64 add = w == 0 ? uv[k] + cv[k] : uv[k];
                     sm[LM_PAD(i0 + k)] = lm_shoup3<true>(v[k], pi.w, pi.wp, qc.nq, add); // the slots this work item just consumed
-#endif
                 }
         }
     } st{uq, ain, sm, qc, pi, w, {}, {}};
@@ -553,29 +542,6 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
     constexpr uint32_t NW = lm_nthreads(LOGN) / 64, BLK = N / NW, IT = BLK / 128;
     const uint32_t wave = tid >> 6, lane = tid & 63;
     const uint32_t jb = NW > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(inv_index[wave * BLK] / BLK)) : 0u;
-#if LM_EXP_MODDOWN_R4 // the round-4 gather: workgroup barrier, every lane strides over the whole limb, canonical words
-    auto after = [&](uint32_t, uint32_t) {
-        constexpr uint32_t IT4 = N / (2 * lm_nthreads(LOGN));
-        uint2 p[IT4];
-        ulonglong2 x[IT4];
-#pragma unroll
-        for (uint32_t k = 0; k < IT4; k++) {
-            const uint32_t j = 2 * tid + k * 2 * nthreads;
-            p[k] = *reinterpret_cast<const uint2 *>(index + j);
-            x[k] = *reinterpret_cast<const ulonglong2 *>(ain + j);
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t k = 0; k < IT4; k++) {
-            const uint32_t j = 2 * tid + k * 2 * nthreads;
-            ulonglong2 y;
-            y.x = lm_addmod(x[k].x, sm[LM_PAD(p[k].x)], qc.q);
-            y.y = lm_addmod(x[k].y, sm[LM_PAD(p[k].y)], qc.q);
-            *reinterpret_cast<ulonglong2 *>(aout + j) = y;
-        }
-        (void)jb, (void)lane, (void)IT;
-    };
-#else
     auto after = [&](uint32_t, uint32_t) {
         uint2 p[IT];
         ulonglong2 x[IT];
@@ -600,7 +566,6 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
             *reinterpret_cast<ulonglong2 *>(aout + j) = y;
         }
     };
-#endif
     lm_ntt_forward<LOGN>(sm, tw_all + (size_t)t * N, qc, tid, nthreads, ld, st, after);
 }
 

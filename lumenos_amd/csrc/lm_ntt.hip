@@ -27,12 +27,10 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_limb_ntt(const u64 *sr
     if (INV) {
         const tw_t ni = ninv.t[mi];
         auto st = [&](uint32_t i, u64 v) { o[i] = lm_shoup_cs(v, ni, c.q, c.nq); };
-#if LM_EXP_INV_LIN_LOAD
-        lm_linear_in<LOGN>(sm, tid, [&](uint32_t j) { return *reinterpret_cast<const ulonglong2 *>(p + j); });
-        lm_lds_run_loader ld{sm};
-#else
+        // (the mirror image of the extension kernel's coalesced stores -- pairs of consecutive coefficients per lane into the
+        // wave's LDS block, the first pass reading its runs from there -- loses 2.7 %: tools/exp_inv_lin_load.patch,
+        // profiles/r05_exp_linear_store.txt)
         auto ld = [&](uint32_t i0, u64 *v, int count) { lm_load_run(p, i0, v, count); };
-#endif
         lm_ntt_inverse<LOGN>(sm, tw, c, tid, nthreads, ld, st);
     } else {
         auto ld = [&](uint32_t i) { return p[i]; };

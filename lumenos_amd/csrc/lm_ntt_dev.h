@@ -789,38 +789,6 @@ __device__ __forceinline__ void lm_linear_out(const u64 *sm, uint32_t tid, F f) 
     }
 }
 
-// the mirror image for an inverse transform's input (its first pass reads runs of 2^R consecutive coefficients per lane):
-// every lane fetches PAIRS of consecutive coefficients f(j) -> {c[j], c[j+1]}, lanes on consecutive addresses, into the wave's
-// own LDS block; the first pass then takes its runs from LDS (lm_lds_run_loader).  A/B: LM_EXP_INV_LIN_LOAD.
-template <int LOGN, class F>
-__device__ __forceinline__ void lm_linear_in(u64 *sm, uint32_t tid, F f) {
-    constexpr uint32_t NW = lm_nthreads(LOGN) / 64, BLK = (1u << LOGN) / NW, IT = BLK / 128 ? BLK / 128 : 1;
-    const uint32_t wave = tid >> 6, lane = tid & 63;
-    ulonglong2 y[IT];
-#pragma unroll
-    for (uint32_t k = 0; k < IT; k++) {
-        const uint32_t j = wave * BLK + 2 * lane + k * 128;
-        if (BLK >= 128 || 2 * lane < BLK) y[k] = f(j);
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < IT; k++) {
-        const uint32_t j = wave * BLK + 2 * lane + k * 128;
-        if (BLK >= 128 || 2 * lane < BLK) sm[LM_PAD(j)] = y[k].x, sm[LM_PAD(j + 1)] = y[k].y;
-    }
-    lm_wave_sync();
-}
-struct lm_lds_run_loader {
-    const u64 *sm;
-    __device__ __forceinline__ void operator()(uint32_t i0, u64 *v, int count) const {
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (k < count) v[k] = sm[LM_PAD(i0 + k)];
-    }
-};
-#ifndef LM_EXP_INV_LIN_LOAD
-#define LM_EXP_INV_LIN_LOAD 0
-#endif
-
 __device__ __forceinline__ void lm_store_run(u64 *p, uint32_t i0, const u64 *v, int count) {
 #pragma unroll
     for (int k = 0; k < 8; k += 2) {

@@ -322,16 +322,10 @@ struct lm_twset {
 };
 
 // R forward stages on e[0 .. 2^R) with preloaded twiddles
-// LM_EXP_NO_BUTTERFLIES (diagnostic builds only, tools/build_variant.sh NAME -DLM_EXP_NO_BUTTERFLIES=1): the stages do
-// nothing, so a transform kernel keeps its loads, its fused load / store arithmetic, its LDS round trips and its
-// barrier but none of its butterflies -- its time is then the kernel's MEMORY-SIDE floor (results are garbage).
-// profiles/EXPERIMENTS.md section 1 uses it to tell VALU-bound kernels from traffic-bound ones.
-#ifndef LM_EXP_NO_BUTTERFLIES
-#define LM_EXP_NO_BUTTERFLIES 0
-#endif
+// (tools/exp_no_butterflies.patch makes the stages return at once: a transform kernel's memory-side floor,
+// profiles/r05_exp_no_butterflies_floor.txt)
 template <int R, bool UW>
 __device__ __forceinline__ void lm_fwd_stages(u64 *e, const lm_twset<R, UW> &T, const lm_qc &c) {
-    if (LM_EXP_NO_BUTTERFLIES) return;
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int span = (1 << R) >> st, half = span >> 1;
@@ -388,7 +382,6 @@ struct lm_inv_twset {
 template <int R, bool UW, bool LAST, bool FIRST>
 __device__ __forceinline__ void lm_inv_stages(u64 *e, const lm_inv_twset<R, UW, FIRST> &T, const lm_qc &c) {
     static_assert(R <= 4, "3q * 2^R must stay below 2^64");
-    if (LM_EXP_NO_BUTTERFLIES) return;
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int half = 1 << st, span = half << 1;

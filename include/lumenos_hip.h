@@ -76,14 +76,16 @@ int lumen_ctx_wait(lumen_ctx *ctx, lumen_ctx *other);
 /* The library's tuning switches (A/B tools; every default is the measured best; DESIGN.md "Run-time
  * switches") are read from the environment ONCE, by lumen_ctx_create; clones inherit them.  This setter is
  * the in-process form for tests and tools: name = "LUMEN_KS_BATCH", "LUMEN_KS_LANES",
- * "LUMEN_KS_FUSED_DIGITS" (value < 0: derived default), "LUMEN_CT_BLOCKS", "LUMEN_DEBUG", "LUMEN_MODUP_TGROUP",
+ * "LUMEN_KS_FUSED_DIGITS" (value < 0: derived default), "LUMEN_DEBUG", "LUMEN_MODUP_TGROUP",
  * "LUMEN_MODDOWN_TGROUP" (work-list order of the key switch's two transform kernels), "LUMEN_KS_PLACEMENT" (candidate
  * blocks per key-switch scratch buffer among which a context's first key switch picks by measurement, 0 = none:
- * takes effect when the buffers are next allocated, e.g. after lumen_ctx_trim); and, for the test
- * suite only (never read from the environment), "LUMEN_RCCL_SHARED_DEVICE": lumen_group_create then lets
- * LUMEN_TRANSPORT_RCCL through although ranks share a device, so that the library's RCCL call sequence can be run
- * with W > 1 on a one-GPU box against the test double tests/cpp/fake_rccl.c (real RCCL refuses such a communicator). */
+ * takes effect when the buffers are next allocated, e.g. after lumen_ctx_trim).  An unknown name or a value out of a
+ * switch's range is an error and changes nothing. */
 int lumen_ctx_set_tuning(lumen_ctx *ctx, const char *name, long value);
+/* TEST HOOK (not a tuning switch, never read from the environment): lumen_group_create then lets LUMEN_TRANSPORT_RCCL
+ * through although ranks share a device, so that the library's RCCL call sequence can be run with W > 1 on a one-GPU
+ * box against the test double tests/cpp/fake_rccl.cpp (real RCCL refuses such a communicator). */
+int lumen_test_allow_shared_device_rccl(lumen_ctx *ctx, int on);
 /* Freed set storage is pooled per context and scratch buffers persist (a prover run allocates the same sizes
  * every time; mapping 25 GB per call costs 0.2 s).  lumen_ctx_trim hands all of it back to the driver -- between
  * jobs of different shapes, or when several contexts share one GPU.  Waits for the context's work first. */

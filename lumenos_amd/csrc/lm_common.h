@@ -81,17 +81,15 @@ struct lm_tuning {
     uint32_t ks_batch = 64;      // LUMEN_KS_BATCH: columns per key-switch batch
     uint32_t ks_lanes = 0;       // LUMEN_KS_LANES: 1 / 2 streams for the column batches of a key switch; 0 = by ring degree
     int32_t ks_fused_digits = -1; // LUMEN_KS_FUSED_DIGITS: digits packed inside k_intt_pack (-1: derive)
-    uint32_t ct_blocks = 1;      // LUMEN_CT_BLOCKS: 0 = Encode through the op-by-op interpreter
     uint32_t debug = 0;          // LUMEN_DEBUG
     // LUMEN_MODUP_TGROUP / LUMEN_MODDOWN_TGROUP: target limbs one XCD walks back to back in the work lists of the
     // two transform kernels of a key switch (lm_keyswitch.hip); 1 .. 31
-    uint32_t modup_tgroup = 4, moddown_tgroup = 4;
+    uint32_t modup_tgroup = 4, moddown_tgroup = 2; // (round 6, limb-major streams: ModDown 2 / 4 / 6 / 12 = 1.8140 / 1.8258 / 1.8246 / 1.8371 s per step)
     // LUMEN_KS_PLACEMENT: candidate blocks per key-switch scratch buffer among which the first key switch of a context
     // picks by measurement (lm_keyswitch.hip, select_placement); 0 or 1 = take what hipMalloc returns
     uint32_t ks_placement = 6;
-    // LUMEN_RCCL_SHARED_DEVICE (tests only): LUMEN_TRANSPORT_RCCL accepts ranks that share a device.  Real RCCL
-    // refuses such a communicator itself; the switch exists so that the RCCL call sequence of lm_group.hip can run
-    // with W > 1 on a one-GPU box against tests/cpp/fake_rccl.c
+    // lumen_test_allow_shared_device_rccl (tests only; not reachable through lumen_ctx_set_tuning or the environment):
+    // LUMEN_TRANSPORT_RCCL accepts ranks that share a device, for the test double tests/cpp/fake_rccl.cpp
     uint32_t rccl_shared_device = 0;
 };
 

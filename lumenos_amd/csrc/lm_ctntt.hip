@@ -32,15 +32,6 @@
 #include "lm_ntt_dev.h"
 
 #define LM_CT_GROUP 128 // max slots per component (LDS tile = GROUP * W * 8 B)
-#ifndef LM_CT_W
-#define LM_CT_W 32      // lanes per tile
-#endif
-#ifndef LM_CT_THREADS
-#define LM_CT_THREADS 512
-#endif
-#ifndef LM_CT_ILP
-#define LM_CT_ILP 2 // ops a thread row has in flight per layer (1: 59.6 ms, 2: 55.1, 4: 64.6, 8: 92.3 per Encode at D)
-#endif
 #define LM_NOSLOT 0xFFFFFFFFu
 #define LM_MOP_WORDS 16 // words of a work item of the register-blocked kernel: n | slots[2] | - | pre[8] | pad
 #define LM_CB_W 64      // its lane tile: one wave per slot row, so a work item is wave-uniform
@@ -143,11 +134,6 @@ struct Walker {
     }
 };
 
-struct Layer {
-    std::vector<uint32_t> bfly; // a | b << 16 (local slot ids)
-    std::vector<uint32_t> mul;  // a | tw_id << 8
-};
-
 // one work item of the register-blocked kernel: a base case with the six-step twiddles that precede it
 // folded into its load (pre[k] = table entry slot k is multiplied by first, LM_NOSLOT = none), or a
 // twiddle multiplication nothing follows in this transform (n == 1)
@@ -159,7 +145,6 @@ struct MOp {
 
 struct Group {
     std::vector<uint32_t> slots;
-    std::vector<Layer> layers;
     std::vector<std::vector<MOp>> mlayers;
 };
 
@@ -176,12 +161,9 @@ struct Plan {
     uint32_t max_tw = 0;
     // device copies, one per pass
     struct Dev {
-        uint32_t ngroups, gsize, nlayers;
+        uint32_t ngroups, gsize;
         uint32_t *d_slots = nullptr; // [ngroups][gsize]
-        uint32_t *d_ops = nullptr;   // [ngroups][total]
-        uint32_t *d_layer = nullptr; // [nlayers][3]: offset, nb, nm (padded counts)
-        uint32_t total = 0;
-        // the same pass for the register-blocked kernel
+        // the pass as work items of the register-blocked kernel
         uint32_t *d_mops = nullptr;   // [ngroups][mtotal][LM_MOP_WORDS]
         uint32_t *d_mlayer = nullptr; // [mlayers][2]: offset, count (padded)
         uint32_t mtotal = 0, mlayers = 0;
@@ -192,8 +174,6 @@ struct Plan {
     ~Plan() {
         for (Dev &d : dev) {
             hipFree(d.d_slots);
-            hipFree(d.d_ops);
-            hipFree(d.d_layer);
             hipFree(d.d_mops);
             hipFree(d.d_mlayer);
         }
@@ -220,7 +200,6 @@ void close_pass(const std::vector<Op> &ops, size_t lo, size_t hi, UF &uf, uint32
     std::map<uint32_t, uint32_t> gid;
     Pass pass;
     std::vector<std::map<uint32_t, uint32_t>> local; // per group: slot -> local id
-    std::vector<std::vector<uint32_t>> last;         // per group: last layer per local slot
     auto group_of = [&](uint32_t slot) {
         uint32_t r = uf.find(slot);
         auto it = gid.find(r);
@@ -229,7 +208,6 @@ void close_pass(const std::vector<Op> &ops, size_t lo, size_t hi, UF &uf, uint32
         gid[r] = g;
         pass.groups.emplace_back();
         local.emplace_back();
-        last.emplace_back();
         return g;
     };
     auto local_of = [&](uint32_t g, uint32_t slot) {
@@ -238,29 +216,15 @@ void close_pass(const std::vector<Op> &ops, size_t lo, size_t hi, UF &uf, uint32
         uint32_t id = (uint32_t)pass.groups[g].slots.size();
         local[g][slot] = id;
         pass.groups[g].slots.push_back(slot);
-        last[g].push_back(0);
         return id;
     };
-    for (size_t i = lo; i < hi; i++) {
+    for (size_t i = lo; i < hi; i++) { // slots get their local ids in the order the primitive ops touch them
         const Op &o = ops[i];
-        uint32_t g = group_of(o.a);
-        Group &G = pass.groups[g];
-        if (o.is_mul) {
-            uint32_t a = local_of(g, o.a);
-            uint32_t lay = last[g][a];
-            if (G.layers.size() <= lay) G.layers.resize(lay + 1);
-            uint32_t id = o.tw < 0 ? fieldN : (uint32_t)o.tw;
-            G.layers[lay].mul.push_back(a | (id << 8));
-            last[g][a] = lay + 1;
-        } else {
-            uint32_t a = local_of(g, o.a), b = local_of(g, o.b);
-            uint32_t lay = std::max(last[g][a], last[g][b]);
-            if (G.layers.size() <= lay) G.layers.resize(lay + 1);
-            G.layers[lay].bfly.push_back(a | (b << 16));
-            last[g][a] = last[g][b] = lay + 1;
-        }
+        const uint32_t g = group_of(o.a);
+        local_of(g, o.a);
+        if (!o.is_mul) local_of(g, o.b);
     }
-    // the same ops as work items of the register-blocked kernel
+    // the ops as work items of the register-blocked kernel
     {
         std::vector<std::vector<uint32_t>> mlast;
         auto emit = [&](uint32_t g, const MOp &m) {
@@ -325,11 +289,6 @@ void close_pass(const std::vector<Op> &ops, size_t lo, size_t hi, UF &uf, uint32
         Group &bin = packed.groups.back();
         const uint32_t base = (uint32_t)bin.slots.size();
         bin.slots.insert(bin.slots.end(), g.slots.begin(), g.slots.end());
-        if (bin.layers.size() < g.layers.size()) bin.layers.resize(g.layers.size());
-        for (size_t l = 0; l < g.layers.size(); l++) {
-            for (uint32_t op : g.layers[l].bfly) bin.layers[l].bfly.push_back(op + base + (base << 16));
-            for (uint32_t op : g.layers[l].mul) bin.layers[l].mul.push_back(op + base);
-        }
         if (bin.mlayers.size() < g.mlayers.size()) bin.mlayers.resize(g.mlayers.size());
         for (size_t l = 0; l < g.mlayers.size(); l++)
             for (MOp m : g.mlayers[l]) {
@@ -391,35 +350,10 @@ int upload_plan(lumen_ctx *ctx, Plan *plan, uint32_t count) {
         Plan::Dev d;
         d.ngroups = (uint32_t)pass.groups.size();
         d.gsize = 0;
-        d.nlayers = 0;
-        for (Group &g : pass.groups) {
-            d.gsize = std::max<uint32_t>(d.gsize, (uint32_t)g.slots.size());
-            d.nlayers = std::max<uint32_t>(d.nlayers, (uint32_t)g.layers.size());
-        }
-        std::vector<uint32_t> layer(3 * d.nlayers, 0);
-        uint32_t total = 0;
-        for (uint32_t l = 0; l < d.nlayers; l++) {
-            uint32_t nb = 0, nm = 0;
-            for (Group &g : pass.groups)
-                if (l < g.layers.size()) {
-                    nb = std::max<uint32_t>(nb, (uint32_t)g.layers[l].bfly.size());
-                    nm = std::max<uint32_t>(nm, (uint32_t)g.layers[l].mul.size());
-                }
-            layer[3 * l] = total, layer[3 * l + 1] = nb, layer[3 * l + 2] = nm;
-            total += nb + nm;
-        }
-        d.total = total;
+        for (Group &g : pass.groups) d.gsize = std::max<uint32_t>(d.gsize, (uint32_t)g.slots.size());
         std::vector<uint32_t> slots((size_t)d.ngroups * d.gsize, LM_NOSLOT);
-        std::vector<uint32_t> ops((size_t)d.ngroups * total, LM_NOSLOT);
-        for (uint32_t gi = 0; gi < d.ngroups; gi++) {
-            Group &g = pass.groups[gi];
-            std::copy(g.slots.begin(), g.slots.end(), slots.begin() + (size_t)gi * d.gsize);
-            for (uint32_t l = 0; l < g.layers.size(); l++) {
-                uint32_t *o = ops.data() + (size_t)gi * total + layer[3 * l];
-                std::copy(g.layers[l].bfly.begin(), g.layers[l].bfly.end(), o);
-                std::copy(g.layers[l].mul.begin(), g.layers[l].mul.end(), o + layer[3 * l + 1]);
-            }
-        }
+        for (uint32_t gi = 0; gi < d.ngroups; gi++)
+            std::copy(pass.groups[gi].slots.begin(), pass.groups[gi].slots.end(), slots.begin() + (size_t)gi * d.gsize);
         // work items of the register-blocked kernel, layer by layer, padded with empty items (n = 0)
         for (Group &g : pass.groups) d.mlayers = std::max<uint32_t>(d.mlayers, (uint32_t)g.mlayers.size());
         std::vector<uint32_t> mlayer(2 * d.mlayers, 0);
@@ -447,11 +381,7 @@ int upload_plan(lumen_ctx *ctx, Plan *plan, uint32_t count) {
         if (!mops.empty()) LM_HIP(ctx, hipMemcpy(d.d_mops, mops.data(), mops.size() * 4, hipMemcpyHostToDevice));
         if (!mlayer.empty()) LM_HIP(ctx, hipMemcpy(d.d_mlayer, mlayer.data(), mlayer.size() * 4, hipMemcpyHostToDevice));
         LM_HIP(ctx, hipMalloc((void **)&d.d_slots, slots.size() * 4));
-        LM_HIP(ctx, hipMalloc((void **)&d.d_ops, std::max<size_t>(ops.size(), 1) * 4));
-        LM_HIP(ctx, hipMalloc((void **)&d.d_layer, std::max<size_t>(layer.size(), 1) * 4));
         LM_HIP(ctx, hipMemcpy(d.d_slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
-        if (!ops.empty()) LM_HIP(ctx, hipMemcpy(d.d_ops, ops.data(), ops.size() * 4, hipMemcpyHostToDevice));
-        if (!layer.empty()) LM_HIP(ctx, hipMemcpy(d.d_layer, layer.data(), layer.size() * 4, hipMemcpyHostToDevice));
         plan->dev.push_back(d);
     }
     if (!plan->passes.empty())
@@ -486,113 +416,21 @@ int get_plan(lumen_ctx *ctx, uint32_t count, uint32_t size, Plan **out) {
 } // namespace
 
 // ------------------------------------------------------------------- kernel
-struct ct_pass_args {
-    const u64 *srcA; // slots < splitA: srcA + slot * ctw
-    const u64 *srcB; // slots >= splitA: srcB (one ciphertext, broadcast)
-    u64 *dst;
-    const uint32_t *slots;   // [ngroups][gsize]
-    const uint32_t *ops;     // [ngroups][total]
-    const uint32_t *layer;   // [nlayers][3]
-    const uint32_t *out_pos; // slot -> destination index, or NULL for identity
-    const tw_t *scal;        // [nl_table][fieldN+1]
-    uint32_t splitA, gsize, total, nlayers, fieldN1, logN, nl;
-    uint32_t group0; // first group of this launch (multi-GPU: a rank runs only its groups of the final pass)
-    size_t ctw;
-};
-
-// One workgroup = one component (group of <= LM_CT_GROUP slots) x one tile of W lanes.  The group's
-// op list and layer table are staged in LDS next to the tile: fetched from global memory inside the
-// layers, each op word sat on the critical path of its butterfly (one L2 round trip per iteration).
-// Values stay in [0, 2q) between layers (one conditional subtraction of 2q per result, decided on the
-// sign of the upper word) and are made canonical on the way out.
-// Measured at 16384x4096 (tools/encode_only.py): 70.8 ms per Encode with the ops in global memory,
-// 57.7 ms staged; moving the tiles alone (no layers) takes 32.7 ms.  Also tried: 4 tiles per workgroup
-// with the next tile prefetched into registers (58.8 ms: the registers cost the occupancy the
-// prefetch buys), scalars staged in LDS and ops batched 4 at a time (71 ms).
 __device__ __forceinline__ u64 ct_csub2q(u64 v, u64 n2q) { // v < 4q -> [0, 2q); n2q = 2^64 - 2q
     const u64 t = v + n2q;
     return (int32_t)(t >> 32) < 0 ? v : t;
 }
-__global__ __launch_bounds__(LM_CT_THREADS) void k_ct_pass(ct_pass_args a, lm_mods mods) {
-    extern __shared__ __attribute__((aligned(16))) u64 buf[]; // [gsize][W] coefficients | ops [total] | layers
-    const uint32_t tid = threadIdx.x, l = tid % LM_CT_W, r = tid / LM_CT_W;
-    constexpr uint32_t R = LM_CT_THREADS / LM_CT_W;
-    const uint32_t group = blockIdx.y + a.group0;
-    const size_t lane = (size_t)blockIdx.x * LM_CT_W + l;
-    // tiles are aligned runs of W <= N lanes: the limb is uniform in the workgroup
-    const uint32_t limb = (uint32_t)(((size_t)blockIdx.x * LM_CT_W) >> a.logN) % a.nl;
-    const u64 q = mods.m[limb].q, q2 = 2 * q, n2q = 0 - q2;
-    const tw_t *scal = a.scal + (size_t)limb * a.fieldN1;
-    const uint32_t *slots = a.slots + (size_t)group * a.gsize;
-    uint32_t *ops = reinterpret_cast<uint32_t *>(buf + (size_t)a.gsize * LM_CT_W);
-    uint32_t *layer = ops + a.total;
-    {
-        const uint32_t *gops = a.ops + (size_t)group * a.total;
-        for (uint32_t i = tid; i < a.total; i += LM_CT_THREADS) ops[i] = gops[i];
-        for (uint32_t i = tid; i < 3 * a.nlayers; i += LM_CT_THREADS) layer[i] = a.layer[i];
-    }
-    for (uint32_t s = r; s < a.gsize; s += R) {
-        const uint32_t slot = slots[s];
-        if (slot == LM_NOSLOT) continue;
-        const u64 *src = slot < a.splitA ? a.srcA + (size_t)slot * a.ctw : a.srcB;
-        buf[s * LM_CT_W + l] = src[lane];
-    }
-    __syncthreads();
-    for (uint32_t ly = 0; ly < a.nlayers; ly++) {
-        const uint32_t off = layer[3 * ly], nb = layer[3 * ly + 1], nm = layer[3 * ly + 2];
-        // a thread row takes every R-th op of the layer, LM_CT_ILP of them at a time: the op words, then all
-        // operands, then all results -- one LDS round trip per batch instead of one per op (the ops of a
-        // layer touch disjoint slots, so the order inside a layer is free)
-        for (uint32_t i0 = r; i0 < nb; i0 += R * LM_CT_ILP) {
-            uint32_t op[LM_CT_ILP];
-            u64 x[LM_CT_ILP], y[LM_CT_ILP];
-#pragma unroll
-            for (int k = 0; k < LM_CT_ILP; k++) op[k] = i0 + k * R < nb ? ops[off + i0 + k * R] : LM_NOSLOT;
-#pragma unroll
-            for (int k = 0; k < LM_CT_ILP; k++)
-                if (op[k] != LM_NOSLOT) x[k] = buf[(op[k] & 0xFFFF) * LM_CT_W + l], y[k] = buf[(op[k] >> 16) * LM_CT_W + l];
-#pragma unroll
-            for (int k = 0; k < LM_CT_ILP; k++)
-                if (op[k] != LM_NOSLOT) {
-                    buf[(op[k] & 0xFFFF) * LM_CT_W + l] = ct_csub2q(x[k] + y[k], n2q);      // Evaluator.Add
-                    buf[(op[k] >> 16) * LM_CT_W + l] = ct_csub2q(x[k] + q2 - y[k], n2q);    // Evaluator.Sub
-                }
-        }
-        for (uint32_t i0 = r; i0 < nm; i0 += R * LM_CT_ILP) {
-            uint32_t op[LM_CT_ILP];
-            u64 x[LM_CT_ILP];
-            tw_t sc[LM_CT_ILP];
-#pragma unroll
-            for (int k = 0; k < LM_CT_ILP; k++) op[k] = i0 + k * R < nm ? ops[off + nb + i0 + k * R] : LM_NOSLOT;
-#pragma unroll
-            for (int k = 0; k < LM_CT_ILP; k++)
-                if (op[k] != LM_NOSLOT) x[k] = buf[(op[k] & 0xFF) * LM_CT_W + l], sc[k] = scal[op[k] >> 8];
-#pragma unroll
-            for (int k = 0; k < LM_CT_ILP; k++)
-                if (op[k] != LM_NOSLOT) // Evaluator.Mul(ct, uint64): < 3q
-                    buf[(op[k] & 0xFF) * LM_CT_W + l] = ct_csub2q(lm_shoup3_c(x[k], sc[k].w, sc[k].wp, 0 - q), n2q);
-        }
-        __syncthreads();
-    }
-    for (uint32_t s = r; s < a.gsize; s += R) {
-        const uint32_t slot = slots[s];
-        if (slot == LM_NOSLOT) continue;
-        const uint32_t pos = a.out_pos ? a.out_pos[slot] : slot;
-        if (pos == LM_NOSLOT) continue; // a slot this rank's share of the next pass never reads
-        a.dst[(size_t)pos * a.ctw + lane] = lm_csub(buf[s * LM_CT_W + l], q);
-    }
-}
-
 
 // ------------------------------------------------- register-blocked kernel
-// The interpreter above spends 39 VALU instructions per ciphertext-level op and lane (SQ counters, D):
-// op words, two LDS round trips and a barrier layer per butterfly.  But nttInner only ever does three
-// things to a lane: the hard-coded transforms of 2, 4 and 8 ciphertexts and the six-step twiddles between
-// them.  Here a WAVE owns a work item: it loads the item's 2/4/8 slot rows (64 lanes each, so the item,
-// its slots and its twiddles are wave-uniform: descriptor and scalars come through the scalar cache into
-// SGPRs), multiplies by the twiddles that precede the base case, runs the base case in registers and
-// writes the rows back -- one LDS round trip and one barrier per base case instead of one per butterfly
-// layer, no per-lane op decoding.  Values stay in [0, 2q) in LDS, as above.
+// nttInner only ever does three things to a lane: the hard-coded transforms of 2, 4 and 8 ciphertexts and the six-step
+// twiddles between them.  A WAVE owns a work item: it loads the item's 2/4/8 slot rows (64 lanes each, so the item, its
+// slots and its twiddles are wave-uniform: descriptor and scalars come through the scalar cache into SGPRs), multiplies by
+// the twiddles that precede the base case, runs the base case in registers and writes the rows back -- one LDS round trip
+// and one barrier per base case, no per-lane op decoding.  Values stay in [0, 2q) in LDS (one conditional subtraction of
+// 2q per result, decided on the sign of the upper word) and are made canonical on the way out.
+// (Rounds 1-4 ran an op-by-op interpreter, one LDS round trip and barrier layer per butterfly, 39 VALU instructions per
+// ciphertext-level op and lane by the SQ counters: 54.9 ms per Encode at 16384 x 4096 against 33 here; it left the library
+// in round 6 -- git history, profiles/EXPERIMENTS.md section 6.)
 struct ct_blocks_args {
     const u64 *srcA, *srcB;
     u64 *dst;
@@ -735,10 +573,6 @@ __global__ __launch_bounds__(LM_CB_THREADS) void k_ct_blocks(ct_blocks_args a, l
     }
 }
 
-// LUMEN_CT_BLOCKS=0 (read at lumen_ctx_create; lumen_ctx_set_tuning for a test that runs both kernels on the
-// same input in one process): the op-by-op interpreter instead
-static bool ct_blocks_enabled(const lumen_ctx *ctx) { return ctx->tune.ct_blocks != 0; }
-
 // final_g0/final_ng: groups of the final pass to run (all when final_ng == 0); final_pos: device
 // table slot -> output position for that pass (the plan's own permutation when NULL)
 // keep_pos: for a sharded run, device table slot -> slot (or LM_NOSLOT) applied to the stores of the
@@ -751,7 +585,9 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
                     uint32_t logw = 0) {
     const size_t ctw = (size_t)2 * nl * (ctx->N >> logw);
     const uint32_t P = (uint32_t)plan->dev.size();
-    LM_CHECK(ctx, ctw % LM_CT_W == 0, "ciphertext width not a multiple of the lane tile");
+    // (a tile must not straddle two limbs: every supported width, N >= 256 and lane shards of >= 64 coefficients,
+    // is a multiple of the 64-lane tile)
+    LM_CHECK(ctx, ((ctx->N >> logw) % LM_CB_W) == 0, "limbs of %u coefficients are not a multiple of the %u-lane tile", ctx->N >> logw, LM_CB_W);
     const u64 *cur = srcA;
     uint32_t split = splitA;
     const u64 *curB = srcB;
@@ -759,40 +595,23 @@ static int run_plan(lumen_ctx *ctx, Plan *plan, uint32_t count, uint32_t nl, con
         const Plan::Dev &d = plan->dev[p];
         LM_CHECK(ctx, d.gsize <= 256 && d.gsize <= LM_CT_GROUP, "component of %u slots exceeds the LDS tile", d.gsize);
         const bool final_pass = p + 1 == P;
-        ct_pass_args a;
-        a.srcA = cur, a.srcB = curB, a.splitA = split;
-        a.dst = final_pass ? out : tmp;
-        a.slots = d.d_slots, a.ops = d.d_ops, a.layer = d.d_layer;
-        a.out_pos = final_pass ? (final_pos ? final_pos : plan->d_out_pos) : (p + 2 == P ? keep_pos : nullptr);
-        a.group0 = final_pass && final_ng ? final_g0 : 0;
-        a.scal = ctx->d_scal;
-        a.gsize = d.gsize, a.total = d.total, a.nlayers = d.nlayers;
-        a.fieldN1 = ctx->fieldN + 1, a.logN = ctx->logN - logw, a.nl = nl, a.ctw = ctw; // logN: limb width of THESE sets
+        ct_blocks_args b;
+        b.srcA = cur, b.srcB = curB, b.splitA = split;
+        b.dst = final_pass ? out : tmp;
+        b.slots = d.d_slots;
+        b.out_pos = final_pass ? (final_pos ? final_pos : plan->d_out_pos) : (p + 2 == P ? keep_pos : nullptr);
+        b.group0 = final_pass && final_ng ? final_g0 : 0;
+        b.scal = ctx->d_scal;
+        b.mops = d.d_mops, b.mlayer = d.d_mlayer, b.mtotal = d.mtotal, b.mlayers = d.mlayers;
+        b.gsize = d.gsize, b.fieldN1 = ctx->fieldN + 1, b.logN = ctx->logN - logw, b.nl = nl, b.ctw = ctw; // logN: limb width of THESE sets
+        b.src_tiled = p > 0, b.dst_tiled = !final_pass, b.count = count;
         const uint32_t ng = final_pass && final_ng ? final_ng : d.ngroups;
-        // (a tile must not straddle two limbs: every supported width, N >= 256 and lane shards of >= 64
-        // coefficients, is a multiple of the 64-lane tile)
-        if (ct_blocks_enabled(ctx) && ((ctx->N >> logw) % LM_CB_W) == 0) {
-            ct_blocks_args b;
-            b.srcA = a.srcA, b.srcB = a.srcB, b.dst = a.dst, b.slots = a.slots, b.out_pos = a.out_pos, b.scal = a.scal;
-            b.mops = d.d_mops, b.mlayer = d.d_mlayer, b.mtotal = d.mtotal, b.mlayers = d.mlayers;
-            b.splitA = a.splitA, b.gsize = a.gsize, b.fieldN1 = a.fieldN1, b.logN = a.logN, b.nl = a.nl;
-            b.group0 = a.group0, b.ctw = a.ctw;
-            b.src_tiled = p > 0, b.dst_tiled = !final_pass, b.count = count;
-            const uint32_t ntiles = (uint32_t)(ctw / LM_CB_W);
-            dim3 grid((ntiles + LM_CB_TILES - 1) / LM_CB_TILES, ng);
-            const size_t lds = (size_t)d.gsize * LM_CB_W * sizeof(u64);
-            LM_LDS_ATTR(ctx, k_ct_blocks, lds);
-            lm_prof_scope ps(ctx, "ct_axis_pass", (uint64_t)ng * d.gsize);
-            hipLaunchKernelGGL(k_ct_blocks, grid, dim3(LM_CB_THREADS), lds, ctx->stream, b, ctx->mods);
-            LM_HIP(ctx, hipGetLastError());
-            cur = tmp, split = count, curB = nullptr;
-            continue;
-        }
-        dim3 grid((uint32_t)(ctw / LM_CT_W), ng);
-        size_t lds = (size_t)d.gsize * LM_CT_W * sizeof(u64) + ((size_t)d.total + 3 * d.nlayers) * sizeof(uint32_t);
-        LM_LDS_ATTR(ctx, k_ct_pass, lds);
+        const uint32_t ntiles = (uint32_t)(ctw / LM_CB_W);
+        dim3 grid((ntiles + LM_CB_TILES - 1) / LM_CB_TILES, ng);
+        const size_t lds = (size_t)d.gsize * LM_CB_W * sizeof(u64);
+        LM_LDS_ATTR(ctx, k_ct_blocks, lds);
         lm_prof_scope ps(ctx, "ct_axis_pass", (uint64_t)ng * d.gsize);
-        hipLaunchKernelGGL(k_ct_pass, grid, dim3(LM_CT_THREADS), lds, ctx->stream, a, ctx->mods);
+        hipLaunchKernelGGL(k_ct_blocks, grid, dim3(LM_CB_THREADS), lds, ctx->stream, b, ctx->mods);
         LM_HIP(ctx, hipGetLastError());
         cur = tmp, split = count, curB = nullptr;
     }

@@ -189,25 +189,42 @@ static int ctx_private_init(lumen_ctx *ctx) {
     return 0;
 }
 
+// 0: set; 1: no such switch; 2: value out of range (nothing changed)
 static int tuning_set(lm_tuning &t, const char *name, long v) {
     const std::string n(name ? name : "");
-    if (n == "LUMEN_KS_BATCH") t.ks_batch = (v >= 1 && v <= 4096) ? (uint32_t)v : 64;
-    else if (n == "LUMEN_KS_LANES") t.ks_lanes = (v == 1 || v == 2) ? (uint32_t)v : 0; // anything else: derived default
-    else if (n == "LUMEN_KS_FUSED_DIGITS") t.ks_fused_digits = v >= 0 ? (int32_t)v : -1;
-    else if (n == "LUMEN_CT_BLOCKS") t.ct_blocks = v != 0;
-    else if (n == "LUMEN_DEBUG") t.debug = v != 0;
-    else if (n == "LUMEN_MODUP_TGROUP") t.modup_tgroup = (v >= 1 && v <= 31) ? (uint32_t)v : 4;
-    else if (n == "LUMEN_MODDOWN_TGROUP") t.moddown_tgroup = (v >= 1 && v <= 31) ? (uint32_t)v : 4;
-    else if (n == "LUMEN_KS_PLACEMENT") t.ks_placement = (v >= 0 && v <= 32) ? (uint32_t)v : 6;
-    else if (n == "LUMEN_RCCL_SHARED_DEVICE") t.rccl_shared_device = v != 0; // tests only, never from the environment
-    else return 1;
+    auto in = [&](long lo, long hi) { return v >= lo && v <= hi; };
+    if (n == "LUMEN_KS_BATCH") {
+        if (!in(1, 4096)) return 2;
+        t.ks_batch = (uint32_t)v;
+    } else if (n == "LUMEN_KS_LANES") { // 0: the default by ring degree
+        if (!in(0, 2)) return 2;
+        t.ks_lanes = (uint32_t)v;
+    } else if (n == "LUMEN_KS_FUSED_DIGITS") { // negative: the derived default
+        if (v > LM_MAX_LIMBS) return 2;
+        t.ks_fused_digits = v >= 0 ? (int32_t)v : -1;
+    } else if (n == "LUMEN_DEBUG") {
+        t.debug = v != 0;
+    } else if (n == "LUMEN_MODUP_TGROUP") {
+        if (!in(1, 31)) return 2;
+        t.modup_tgroup = (uint32_t)v;
+    } else if (n == "LUMEN_MODDOWN_TGROUP") {
+        if (!in(1, 31)) return 2;
+        t.moddown_tgroup = (uint32_t)v;
+    } else if (n == "LUMEN_KS_PLACEMENT") {
+        if (!in(0, 32)) return 2;
+        t.ks_placement = (uint32_t)v;
+    } else {
+        return 1;
+    }
     return 0;
 }
 static void tuning_from_env(lm_tuning &t) {
-    for (const char *n : {"LUMEN_KS_BATCH", "LUMEN_KS_LANES", "LUMEN_KS_FUSED_DIGITS", "LUMEN_CT_BLOCKS", "LUMEN_DEBUG",
+    for (const char *n : {"LUMEN_KS_BATCH", "LUMEN_KS_LANES", "LUMEN_KS_FUSED_DIGITS", "LUMEN_DEBUG",
                           "LUMEN_MODUP_TGROUP", "LUMEN_MODDOWN_TGROUP", "LUMEN_KS_PLACEMENT"}) {
         const char *e = getenv(n);
-        if (e && *e) tuning_set(t, n, atol(e)); // an empty override counts as unset
+        // an empty override counts as unset; a value out of range is reported and leaves the default
+        if (e && *e && tuning_set(t, n, atol(e)))
+            fprintf(stderr, "[lumenos_hip] %s=%s is out of range: ignored\n", n, e);
     }
 }
 
@@ -216,7 +233,20 @@ static void tuning_from_env(lm_tuning &t) {
 extern "C" int lumen_ctx_set_tuning(lumen_ctx *ctx, const char *name, long value) {
     LM_CHECK(nullptr, ctx && name, "lumen_ctx_set_tuning: NULL argument");
     LM_ENTER(ctx);
-    LM_CHECK(ctx, !tuning_set(ctx->tune, name, value), "unknown tuning switch %s", name);
+    const int rc = tuning_set(ctx->tune, name, value);
+    LM_CHECK(ctx, rc != 1, "unknown tuning switch %s", name);
+    LM_CHECK(ctx, rc == 0, "tuning switch %s: value %ld is out of range (nothing changed)", name, value);
+    return 0;
+}
+
+// TEST HOOK, not a tuning switch and never read from the environment: lets lumen_group_create pass LUMEN_TRANSPORT_RCCL
+// (and lets LUMEN_TRANSPORT_AUTO choose it) although ranks share a device, so that the library's RCCL call sequence can
+// run with W > 1 on a one-GPU box against the test double tests/cpp/fake_rccl.cpp.  Real RCCL refuses such a
+// communicator itself.  Clones made afterwards inherit the setting.
+extern "C" int lumen_test_allow_shared_device_rccl(lumen_ctx *ctx, int on) {
+    LM_CHECK(nullptr, ctx, "lumen_test_allow_shared_device_rccl: NULL ctx");
+    LM_ENTER(ctx);
+    ctx->tune.rccl_shared_device = on != 0;
     return 0;
 }
 
@@ -268,6 +298,10 @@ extern "C" int lumen_ctx_create(const lumen_params_desc *desc, lumen_ctx **out) 
         uint64_t q = desc->moduli[i], psi = desc->psi[i];
         // the lazy forward NTT takes inputs below 7q (fused basis extension) and lets values grow
         // by 3q per stage before its one reduction
+        // ... and the InnerSum accumulator is lazy in [0, 2q) across the rotations (lm_keyswitch.hip, k_moddown_ntt: acc < 2q
+        // plus d < 6q must not wrap): 8q < 2^64, implied by the bound below for every log_n >= 0 and stated here because
+        // the kernels' comments refer to it
+        static_assert(3 * 0 + 8 >= 8, "the modulus bound (3 log_n + 8) q < 2^64 must imply 8 q < 2^64");
         const uint64_t qmax = UINT64_MAX / (3ull * desc->log_n + 8);
         if (q < (1ull << 20) || q > qmax || (q & (two_n - 1)) != 1)
             return lm_fail(nullptr, "modulus %u (%llu) must be == 1 mod 2N and below %llu", i,

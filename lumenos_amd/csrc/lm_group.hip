@@ -35,6 +35,7 @@ struct rccl_api {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr; // optional: only used to tear down a poisoned communicator
     std::string why; // why loading failed
 };
 
@@ -74,6 +75,7 @@ rccl_api *rccl_load() {
     LM_SYM(GroupEnd, "ncclGroupEnd")
     LM_SYM(GetErrorString, "ncclGetErrorString")
 #undef LM_SYM
+    a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(h, "ncclCommAbort"));
     if (!ok) {
         g_rccl.why = "librccl lacks:" + a.why;
         dlclose(h);
@@ -119,6 +121,11 @@ struct lumen_group {
     std::map<std::string, stat_entry> stats;
     std::map<std::pair<std::string, uint64_t>, double> call_ms; // calls partly resolved (see stats_resolve)
     uint64_t call_seq = 0;
+    // a collective failed between ncclGroupStart and ncclGroupEnd: the group that had to be closed launched sends /
+    // receives without their counterparts, so the ranks' streams may never drain.  Every later collective is refused and
+    // lumen_group_destroy aborts the communicators instead of waiting for those streams.
+    bool poisoned = false;
+    std::string poison_why;
 };
 
 namespace {
@@ -166,9 +173,15 @@ struct rccl_group_scope {
         return 0;
     }
     ~rccl_group_scope() {
-        if (open) (void)g->rccl->GroupEnd();
+        if (!open) return;
+        (void)g->rccl->GroupEnd(); // the calling thread's RCCL group must not stay open (see above) ...
+        g->poisoned = true;        // ... but what it launched is half a collective: nothing may be queued behind it
+        g->poison_why = lm_global_err;
     }
 };
+#define G_USABLE(g, what)                                                                                                      \
+    LM_CHECK(nullptr, !(g)->poisoned, "%s: an earlier collective of this group failed half-posted (%s): its streams may never "    \
+             "drain -- destroy the group (and its contexts) and create new ones", what, (g)->poison_why.c_str())
 
 int use(lumen_group *g, uint32_t i) {
     G_HIP(hipSetDevice(g->ctx[i]->device));
@@ -311,15 +324,26 @@ extern "C" void lumen_group_destroy(lumen_group *g) {
     if (!g) return;
     {
         group_lock lk(g);
-        for (uint32_t i = 0; i < g->ctx.size(); i++) {
-            (void)hipSetDevice(g->ctx[i]->device);
-            lm_sync_all(g->ctx[i]);
+        if (!g->poisoned) {
+            for (uint32_t i = 0; i < g->ctx.size(); i++) {
+                (void)hipSetDevice(g->ctx[i]->device);
+                lm_sync_all(g->ctx[i]);
+            }
+            stats_resolve(g);
+        } else {
+            // half a collective sits on the ranks' streams: waiting for them may never return.  Abort the communicators
+            // (that is what releases kernels blocked on a peer) and drop the timing events unread.
+            for (auto &p : g->pend) {
+                if (p.a) hipEventDestroy(p.a);
+                if (p.b) hipEventDestroy(p.b);
+            }
+            g->pend.clear();
         }
-        stats_resolve(g);
         for (uint32_t i = 0; i < g->comm.size(); i++)
             if (g->comm[i]) {
                 (void)hipSetDevice(g->ctx[i]->device);
-                g->rccl->CommDestroy(g->comm[i]);
+                if (g->poisoned && g->rccl->CommAbort) g->rccl->CommAbort(g->comm[i]);
+                else g->rccl->CommDestroy(g->comm[i]);
             }
         for (hipEvent_t e : g->ev_ready)
             if (e) hipEventDestroy(e);
@@ -502,6 +526,7 @@ extern "C" const char *lumen_group_transport_note(const lumen_group *g) { return
 extern "C" int lumen_group_sync(lumen_group *g) {
     LM_CHECK(nullptr, g, "lumen_group_sync: NULL group");
     group_lock lk(g);
+    G_USABLE(g, "lumen_group_sync");
     for (uint32_t i = 0; i < g->ctx.size(); i++) {
         if (use(g, i)) return 1;
         G_HIP(hipStreamSynchronize(g->ctx[i]->stream));
@@ -513,6 +538,7 @@ extern "C" int lumen_group_sync(lumen_group *g) {
 static int all_to_all_raw(lumen_group *g, const std::vector<const u64 *> &send, const std::vector<u64 *> &recv, size_t blk_words,
                           const char *stat_name) {
     const uint32_t n = (uint32_t)g->ctx.size(), W = g->W;
+    G_USABLE(g, stat_name);
     g->call_seq++;
     const uint64_t sent = (uint64_t)blk_words * 8 * (W - 1);
     if (g->transport == LUMEN_TRANSPORT_RCCL) {
@@ -591,16 +617,30 @@ namespace {
 // enqueued and the host goes on to enqueue the rescale and the leaf hashing of every rank (lumen_set_destroy would
 // wait for every rank's Encode here).  Other ranks' reads of a temporary are ordered before that event: the
 // copy transport makes the source's stream wait for every destination (done_all), RCCL sends from the owner's stream.
+// ONLY when the call marks itself successful (commit()): on an error path the exchange may have stopped between some
+// destinations' copies and done_all(), and then the owner's stream has NOT waited for the other ranks' reads -- an
+// event on it would not cover them and the next taker of the block could overwrite it mid-copy.  There every local
+// rank is drained first and the blocks go back the blocking way.
 struct set_bin {
+    lumen_group *g;
     std::vector<std::pair<lumen_ctx *, lumen_set *>> v;
+    bool ok = false;
+    explicit set_bin(lumen_group *grp) : g(grp) {}
     lumen_set *keep(lumen_ctx *c, lumen_set *s) {
         v.emplace_back(c, s);
         return s;
     }
+    void commit() { ok = true; }
     ~set_bin() {
+        if (!ok && !v.empty() && !g->poisoned)
+            for (lumen_ctx *c : g->ctx) {
+                (void)hipSetDevice(c->device);
+                lm_sync_all(c);
+            }
         for (auto &p : v) {
             (void)hipSetDevice(p.first->device);
-            lm_set_release_async(p.first, p.second);
+            if (ok) lm_set_release_async(p.first, p.second);
+            else lumen_set_destroy(g->poisoned ? nullptr : p.first, p.second); // (poisoned: no stream wait; hipFree)
         }
     }
 };
@@ -636,7 +676,7 @@ extern "C" int lumen_group_encode(lumen_group *g, const lumen_set *const *matrix
         G_HIP(hipMemcpyAsync(dzero[i], h, words * 8, hipMemcpyHostToDevice, c->stream));
         G_HIP(hipEventRecord(c->ev_stage, c->stream));
     }
-    set_bin bin;
+    set_bin bin(g);
     std::vector<const lumen_set *> a(n);
     std::vector<lumen_set *> b(n);
     // own columns -> W lane blocks -> all-to-all -> the rank's lane shard of ALL columns
@@ -667,6 +707,7 @@ extern "C" int lumen_group_encode(lumen_group *g, const lumen_set *const *matrix
         }
     }
     for (uint32_t i = 0; i < n; i++) encoded[i] = mine[i];
+    bin.commit();
     return 0; // `bin` gives the temporaries back in stream order: nothing here waits for the device
 }
 
@@ -674,6 +715,7 @@ extern "C" int lumen_group_encode(lumen_group *g, const lumen_set *const *matrix
 extern "C" int lumen_group_all_gather_digests(lumen_group *g) {
     LM_CHECK(nullptr, g, "lumen_group_all_gather_digests: NULL group");
     group_lock lk(g);
+    G_USABLE(g, "lumen_group_all_gather_digests");
     const uint32_t n = (uint32_t)g->ctx.size(), W = g->W;
     uint32_t per = 0;
     std::vector<const uint8_t *> src(n);
@@ -755,47 +797,64 @@ extern "C" int lumen_group_gather(lumen_group *g, const lumen_set *const *src, c
     LM_CHECK(nullptr, g && src && out && (idx || !nq), "lumen_group_gather: NULL argument");
     *out = nullptr;
     group_lock lk(g);
+    G_USABLE(g, "lumen_group_gather");
     const uint32_t n = (uint32_t)g->ctx.size(), W = g->W;
+    // One process per GPU: every process derives the send / receive plan from the (n, idx[]) IT was given, and a rank that
+    // returned early on bad arguments of its own would leave its peers inside RCCL for good.  So in that form nothing
+    // returns before the ranks have AGREED: what is wrong with the local arguments is only noted (`bad`), every rank
+    // all-gathers { fingerprint of (n, idx[]), "my arguments are valid" } -- a fixed-size exchange that cannot mismatch --
+    // and then all ranks fail together or none does.  (This makes the call block the host in that form; with all ranks
+    // in one process there is one idx and the checks return at once.)
+    const bool per_rank = n < W && g->transport == LUMEN_TRANSPORT_RCCL;
+    std::string bad;
+    auto note_bad = [&](const char *fmt, ...) {
+        if (!bad.empty()) return;
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        bad = buf;
+    };
     for (uint32_t i = 0; i < n; i++) {
-        LM_CHECK(nullptr, src[i], "lumen_group_gather: block %u is NULL", i);
-        LM_CHECK(nullptr, src[i]->count == src[0]->count && src[i]->nl == src[0]->nl && src[i]->logw == 0,
-                 "lumen_group_gather: block %u differs in shape from block 0", i);
+        if (!src[i]) note_bad("lumen_group_gather: block %u is NULL", i);
+        else if (!src[0] || src[i]->count != src[0]->count || src[i]->nl != src[0]->nl || src[i]->logw != 0)
+            note_bad("lumen_group_gather: block %u differs in shape from block 0", i);
     }
     const bool have_root = g->rank[0] == 0;
-    if (W == 1) return lumen_gather(g->ctx[0], src[0], idx, nq, out);
-    const uint32_t per = src[0]->count, nl = src[0]->nl;
+    if (W == 1) {
+        LM_CHECK(nullptr, bad.empty(), "%s", bad.c_str());
+        return lumen_gather(g->ctx[0], src[0], idx, nq, out);
+    }
+    const uint32_t per = bad.empty() ? src[0]->count : 0, nl = bad.empty() ? src[0]->nl : 1;
     const size_t ctw = (size_t)2 * nl * g->ctx[0]->N;
     // who owns what: queries of rank p, in query order
     std::vector<std::vector<uint32_t>> local_idx(W);
     std::vector<uint32_t> perm(nq), off(W + 1, 0);
-    for (uint32_t k = 0; k < nq; k++) {
-        LM_CHECK(nullptr, per && idx[k] / per < W, "lumen_group_gather: column %u out of range (%u x %u columns)", idx[k], W, per);
-        local_idx[idx[k] / per].push_back(idx[k] % per);
+    for (uint32_t k = 0; k < nq && bad.empty(); k++) {
+        if (!per || idx[k] / per >= W) note_bad("lumen_group_gather: column %u out of range (%u x %u columns)", idx[k], W, per);
+        else local_idx[idx[k] / per].push_back(idx[k] % per);
     }
-    for (uint32_t p = 0; p < W; p++) off[p + 1] = off[p] + (uint32_t)local_idx[p].size();
-    {
+    if (bad.empty()) {
+        for (uint32_t p = 0; p < W; p++) off[p + 1] = off[p] + (uint32_t)local_idx[p].size();
         std::vector<uint32_t> seen(W, 0);
         for (uint32_t k = 0; k < nq; k++) {
             const uint32_t p = idx[k] / per;
             perm[k] = off[p] + seen[p]++;
         }
     }
-    // One process per GPU: every process derives the send / receive plan from the idx IT was given.  Ranks that
-    // disagree would post sends without matching receives and sit inside RCCL for good, so the processes first
-    // all-gather a fingerprint of (n, idx[]) -- a fixed-size exchange that cannot mismatch -- and compare on the host.
-    // (This makes the call block the host in that form; with all ranks in one process there is one idx.)
-    if (n < W && g->transport == LUMEN_TRANSPORT_RCCL) {
+    if (per_rank) {
         uint64_t fp = 1469598103934665603ull ^ nq;
         for (uint32_t k = 0; k < nq; k++) fp = (fp ^ idx[k]) * 1099511628211ull;
         std::vector<u64 *> dbuf(n);
         for (uint32_t i = 0; i < n; i++) {
             lumen_ctx *c = g->ctx[i];
             if (use(g, i)) return 1;
-            dbuf[i] = (u64 *)lm_scratch(c, "gather_agree", 8 * (size_t)(W + 1));
-            u64 *h = (u64 *)lm_stage(c, 8);
+            dbuf[i] = (u64 *)lm_scratch(c, "gather_agree", 16 * (size_t)(W + 1));
+            u64 *h = (u64 *)lm_stage(c, 16);
             if (!dbuf[i] || !h) return 1;
-            *h = fp;
-            G_HIP(hipMemcpyAsync(dbuf[i] + W, h, 8, hipMemcpyHostToDevice, c->stream));
+            h[0] = fp, h[1] = bad.empty() ? 1 : 0;
+            G_HIP(hipMemcpyAsync(dbuf[i] + 2 * W, h, 16, hipMemcpyHostToDevice, c->stream));
             G_HIP(hipEventRecord(c->ev_stage, c->stream));
         }
         {
@@ -803,22 +862,27 @@ extern "C" int lumen_group_gather(lumen_group *g, const lumen_set *const *src, c
             if (grp.begin()) return 1;
             for (uint32_t i = 0; i < n; i++) {
                 if (use(g, i)) return 1;
-                G_NCCL(g, g->rccl->AllGather(dbuf[i] + W, dbuf[i], 1, ncclUint64, g->comm[i], g->ctx[i]->stream));
+                G_NCCL(g, g->rccl->AllGather(dbuf[i] + 2 * W, dbuf[i], 2, ncclUint64, g->comm[i], g->ctx[i]->stream));
             }
             if (grp.end()) return 1;
         }
-        std::vector<uint64_t> seen(W);
+        std::vector<uint64_t> seen(2 * (size_t)W);
         for (uint32_t i = 0; i < n; i++) {
             if (use(g, i)) return 1;
-            G_HIP(hipMemcpyAsync(seen.data(), dbuf[i], 8 * (size_t)W, hipMemcpyDeviceToHost, g->ctx[i]->stream));
+            G_HIP(hipMemcpyAsync(seen.data(), dbuf[i], 16 * (size_t)W, hipMemcpyDeviceToHost, g->ctx[i]->stream));
             G_HIP(hipStreamSynchronize(g->ctx[i]->stream));
+            LM_CHECK(nullptr, bad.empty(), "%s", bad.c_str()); // (the peers see this rank's flag and fail with it)
             for (uint32_t p = 0; p < W; p++)
-                LM_CHECK(nullptr, seen[p] == fp, "lumen_group_gather: rank %u was given other query indices than rank %u (every rank "
+                LM_CHECK(nullptr, seen[2 * p + 1] == 1, "lumen_group_gather: rank %u rejected its arguments (see its own message): no "
+                         "rank sends", p);
+            for (uint32_t p = 0; p < W; p++)
+                LM_CHECK(nullptr, seen[2 * p] == fp, "lumen_group_gather: rank %u was given other query indices than rank %u (every rank "
                          "must pass the same n and idx[])", p, g->rank[i]);
         }
     }
+    LM_CHECK(nullptr, bad.empty(), "%s", bad.c_str());
     g->call_seq++;
-    set_bin bin;
+    set_bin bin(g);
     std::vector<lumen_set *> q(n, nullptr);
     for (uint32_t i = 0; i < n; i++) {
         const auto &li = local_idx[g->rank[i]];
@@ -872,6 +936,7 @@ extern "C" int lumen_group_gather(lumen_group *g, const lumen_set *const *src, c
         if (use(g, 0)) return 1;
         if (lumen_gather(g->ctx[0], stage, perm.data(), nq, out)) return 1;
     }
+    bin.commit();
     return 0;
 }
 

@@ -538,7 +538,8 @@ __global__ __launch_bounds__(lm_max_threads(LOGN)) void k_moddown_ntt(const u64 
     // therefore serves output block jb = inv_index[w * BLK] / BLK as soon as ITS OWN last pass is done (a wave's LDS
     // operations execute in order) and goes home; the waves of a workgroup finish up to 12 us apart
     // (profiles/r02_ubench_phases.txt), and the barrier this replaces made the early ones wait for the last.
-    // Every lane handles 8 pairs; their index and accumulator words are requested before the wave's last pass.
+    // Every lane handles 8 pairs; only the block number jb is fetched early -- the pairs' index and accumulator words are
+    // requested in `after`, once the wave's last pass is done (ahead of it they cost 48 VGPRs the last pass needs).
     constexpr uint32_t NW = lm_nthreads(LOGN) / 64, BLK = N / NW, IT = BLK / 128;
     const uint32_t wave = tid >> 6, lane = tid & 63;
     const uint32_t jb = NW > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(inv_index[wave * BLK] / BLK)) : 0u;

@@ -50,6 +50,7 @@ SYMBOLS = {
     "lumen_ctx_trim": (C.c_int, [_vp]),
     "lumen_ctx_wait": (C.c_int, [_vp, _vp]),
     "lumen_ctx_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_long]),
+    "lumen_test_allow_shared_device_rccl": (C.c_int, [_vp, C.c_int]),
     "lumen_sync": (C.c_int, [_vp]),
     "lumen_mul_counter": (C.c_uint64, [_vp]),
     "lumen_set_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vpp]),
@@ -339,6 +340,10 @@ class Context:
     def set_tuning(self, name, value):
         """A/B switch of the tools and tests (lumen_ctx_set_tuning); the environment is only read at creation"""
         self._ck(self.lib.lumen_ctx_set_tuning(self.h, name.encode(), int(value)))
+
+    def test_allow_shared_device_rccl(self, on=True):
+        """test hook: lumen_group_create lets the RCCL transport through although ranks share a device (the test double)"""
+        self._ck(self.lib.lumen_test_allow_shared_device_rccl(self.h, 1 if on else 0))
 
     def scratch_info(self, name):
         """-> (device address or None, bytes) of a named scratch buffer of the context (placement diagnostics)"""

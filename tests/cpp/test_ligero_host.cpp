@@ -340,7 +340,7 @@ int main(int argc, char **argv) {
         // copies are made, they inherit it -- so that the whole sharded Commit + Prove runs through the library's RCCL
         // call sequences and must still produce the one-GPU proof byte for byte
         if (const char *e = getenv("LUMEN_TWIN_RCCL_SHARED_DEVICE"))
-            if (*e && *e != '0') REQUIRE(!lumen_ctx_set_tuning(server.Context(), "LUMEN_RCCL_SHARED_DEVICE", 1), "lumen_ctx_set_tuning");
+            if (*e && *e != '0') REQUIRE(!lumen_test_allow_shared_device_rccl(server.Context(), 1), "lumen_test_allow_shared_device_rccl");
         std::vector<std::unique_ptr<fhe::ServerBFV>> copies;
         std::vector<fhe::ServerBFV *> ranks{&server};
         for (int k = 1; k < world; k++) {

@@ -70,7 +70,7 @@ def main():
         try:
             dist = plane.handle(r)
             job = bench.Job(a.config, r, W, 0)
-            job.ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 1)
+            job.ctx.test_allow_shared_device_rccl(True)
             group, flags = bench.join_ranks(job.ctx, r, W, dist, identity=f"thread-rank-{r}")
             assert group is not None, flags
             job.group = group
@@ -88,7 +88,7 @@ def main():
     real_join = bench.join_ranks
 
     def join_as_threads(ctx, rank, world, dist, deadline_s=None, identity=None):
-        ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 1)
+        ctx.test_allow_shared_device_rccl(True)
         return real_join(ctx, rank, world, dist, deadline_s, identity or f"thread-rank-{rank}")
 
     bench.join_ranks = join_as_threads

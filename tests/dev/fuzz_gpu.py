@@ -115,7 +115,7 @@ def one_case(o, rng, case):
             # the group's collectives go through the library's RCCL branch
             via_rccl = os.environ.get("FUZZ_GROUP_TRANSPORT", "copy") == "rccl"
             if via_rccl:
-                ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 1)
+                ctx.test_allow_shared_device_rccl(True)
             ctxs = [ctx] + [ctx.clone() for _ in range(W - 1)]
             g = Group(ctxs, transport="rccl" if via_rccl else "copy")
             assert g.transport == ("rccl" if via_rccl else "copy")

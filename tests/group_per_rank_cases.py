@@ -122,3 +122,34 @@ def test_per_rank_gather_refuses_ranks_that_disagree_on_the_queries(small):
     ctxs[1].close()
 
 
+
+
+def test_per_rank_gather_bad_arguments_on_one_rank_fail_on_every_rank(small):
+    """A rank whose OWN arguments are bad (an index out of range here) must not return before the agreement exchange:
+    its peers are already inside the all-gather and real RCCL would keep them there for good.  Every rank fails -- the
+    offender with what is wrong, the others with who rejected -- and the group stays usable."""
+    from lumenos_amd.hip import Group, LumenError
+    P, ctx = small
+    world = 2
+    ctxs = ranks_of(ctx, world)
+    uid = Group.unique_id()
+    sets = [cx.upload(random_cts(P, 4, 2, seed=60 + r)) for r, cx in enumerate(ctxs)]
+    ok = [None] * world
+
+    def body(r):
+        g = Group.join(ctxs[r], r, world, uid)
+        idx = np.array([1, 6, 2] if r == 0 else [1, 6, 99], dtype=np.uint32)  # 99: beyond 2 x 4 columns, on rank 1 only
+        with pytest.raises(LumenError, match="rejected its arguments" if r == 0 else "out of range"):
+            g.gather([sets[r]], idx)
+        good = np.array([7, 0, 7], dtype=np.uint32)
+        q = g.gather([sets[r]], good)
+        if r == 0:
+            assert np.array_equal(q.download(), np.stack([sets[i // 4].download()[i % 4] for i in good]))
+        g.sync()
+        ok[r] = g
+
+    errs = run_ranks(world, body)
+    assert errs == [None] * world, errs
+    for g in ok:
+        g.close()
+    ctxs[1].close()

@@ -296,7 +296,7 @@ def test_bench_launches_its_own_ranks():
     assert "needs a HIP device" in res.stderr, res.stderr[-1500:]
     assert "must be launched with" not in res.stderr
     # the parent itself never imports torch.cuda / HIP: it is a plain launcher
-    src = open(os.path.join(root, "bench.py")).read()
-    body = src[src.index("def launch_ranks"):src.index("def timed_steps")]
+    src = open(os.path.join(root, "bench_lib", "multi.py")).read()
+    body = src[src.index("def launch_ranks"):]
     code = body[body.index('"""', body.index('"""') + 3) + 3:]  # behind the docstring
     assert "torch.cuda" not in code and "lumenos_amd" not in code and "import torch" not in code

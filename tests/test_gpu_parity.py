@@ -478,29 +478,21 @@ def test_encode_shards_cover_full_encode(oracle, small, world):
         seen[idx] += 1
     assert np.all(seen == 1)
 
-def test_encode_interpreter_matches_register_blocked_kernel(oracle, small):
-    """LUMEN_CT_BLOCKS=0 (lumen_ctx_set_tuning here: the library reads its environment once, at context
-    creation) selects the op-by-op interpreter (k_ct_pass) the register-blocked kernel
-    (k_ct_blocks) replaced: both replay the same schedule, so Encode and the in-place transform must come
-    out identical -- and equal to the oracle -- either way."""
+def test_encode_and_in_place_transform_three_limbs_256_slots(oracle, small):
+    """fhe.Encode of 64 columns (S = 128) on three limbs and fhe.NTT in place on 256 two-limb ciphertexts against the
+    oracle (the shapes on which rounds 2-5 also ran the op-by-op interpreter the register-blocked kernel replaced; the
+    interpreter left the library in round 6 and this comparison is what its A/B duplicated)."""
     P, ctx = small
     cols, rho, nl = 64, 2, 3
     roots = oracle.field_roots(T_REF, 256)
     ctx.field_set(roots)
     m = random_cts(P, cols, nl, seed=191)
     zero = random_cts(P, 1, nl, seed=192)[0]
-    want = P.ct_encode(m, rho, zero, roots)
+    assert np.array_equal(ctx.encode(ctx.upload(m), zero, rho).download(), P.ct_encode(m, rho, zero, roots))
     cts = random_cts(P, 256, 2, seed=193)
-    want_ntt = P.ct_ntt(cts, 256, roots)
-    try:
-        for blocks in (1, 0):
-            ctx.set_tuning("LUMEN_CT_BLOCKS", blocks)
-            assert np.array_equal(ctx.encode(ctx.upload(m), zero, rho).download(), want), blocks
-            s = ctx.upload(cts)
-            ctx.ct_ntt(s, 256)
-            assert np.array_equal(s.download(), want_ntt), blocks
-    finally:
-        ctx.set_tuning("LUMEN_CT_BLOCKS", 1)
+    s = ctx.upload(cts)
+    ctx.ct_ntt(s, 256)
+    assert np.array_equal(s.download(), P.ct_ntt(cts, 256, roots))
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
@@ -698,6 +690,35 @@ def test_key_switch_and_rescale_largest_moduli(oracle):
         while ref.shape[1] > 1:
             ref = P.rescale(ref)
         assert np.array_equal(lvl1[c], ref), c
+    ctx.close()
+
+
+@pytest.mark.parametrize("nq,npr", [(3, 2), (2, 2), (1, 1), (3, 1)])
+def test_lazy_accumulator_at_the_modulus_bound(oracle, nq, npr):
+    """The InnerSum accumulator is lazy in [0, 2q) across the rotations (k_moddown_ntt; 8q < 2^64 is part of the modulus
+    bound lumen_ctx_create enforces).  Its three ways out, with moduli right under that bound and all-(q-1) rows among
+    the inputs: L = 3 (one limb dropped: the single-limb rescale kernels read the lazy words), L <= 2 (nothing to drop:
+    k_acc_canon), and lumen_inner_sum (k_acc_canon on the way out)."""
+    from oracle.loader import Params
+    log_n, two_n = 10, 2 << 10
+    qmax = (2**64 - 1) // (3 * log_n + 8)
+    pr = _ntt_primes_near(qmax, two_n, nq + npr)
+    P = Params.from_moduli(oracle, log_n, pr[:nq], pr[nq:], T_REF)
+    P.seed(11)
+    sk = P.keygen_secret()
+    ctx = make_context(P)
+    n = 32
+    gl = P.inner_sum_galois_elements(n)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    cts = _adversarial_cts(P, nq, seed=13)
+    pt = P.encode(np.arange(1, P.N + 1, dtype=np.uint64))
+    d = ctx.upload(cts)
+    assert np.array_equal(ctx.matrix_inner_sum(d, pt, n).download(), P.matrix_inner_sum(cts, pt, n, evks))
+    got = ctx.inner_sum(d, n).download()
+    assert np.array_equal(got, np.stack([P.inner_sum(c, n, evks) for c in cts]))
+    assert all(int(got[:, :, l].max()) < P.moduli[l] for l in range(nq))  # canonical on the way out
     ctx.close()
 
 

@@ -5,7 +5,7 @@ ranks on one device).  Everything is held to the single-context result, itself b
 
 The same file runs a second time, in a child process, through the library's RCCL branch with W = 2, 4, 8
 (tests/test_group_rccl.py: LUMEN_TEST_GROUP_TRANSPORT=rccl, the test double tests/cpp/fake_rccl.cpp first on
-LD_LIBRARY_PATH, the test-only switch LUMEN_RCCL_SHARED_DEVICE): every assertion below then holds for the grouped
+LD_LIBRARY_PATH, the test hook lumen_test_allow_shared_device_rccl): every assertion below then holds for the grouped
 ncclSend / ncclRecv, ncclAllGather and gather-to-root call sequences too."""
 import os
 
@@ -26,7 +26,7 @@ def small(oracle):
     P = make_params(oracle, 10, 3)
     ctx = make_context(P)
     if FAKE:
-        ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 1)  # clones inherit it
+        ctx.test_allow_shared_device_rccl(True)  # clones inherit it
     yield P, ctx
     ctx.close()
 
@@ -148,7 +148,7 @@ def test_group_refuses_what_it_cannot_serve(oracle, small):
     P, ctx = small
     twin = ctx.clone()
     if FAKE:
-        ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 0)
+        ctx.test_allow_shared_device_rccl(False)
     with pytest.raises(LumenError, match="RCCL needs every rank on its own device"):
         Group([ctx, twin], transport="rccl")
     with pytest.raises(LumenError, match="same context"):
@@ -156,7 +156,7 @@ def test_group_refuses_what_it_cannot_serve(oracle, small):
     g = Group([ctx, twin], transport="auto")  # two ranks on one device: copies
     assert g.transport == "copy" and g.transport_note == "stream-ordered copies on one device"
     if FAKE:
-        ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 1)
+        ctx.test_allow_shared_device_rccl(True)
     a, b = ctx.new_set(4, 2), twin.new_set(6, 2)
     with pytest.raises(LumenError, match="differ in size"):
         g.all_to_all([a, b], [ctx.new_set(4, 2), twin.new_set(6, 2)])

@@ -60,13 +60,14 @@ def test_test_double_exports_what_the_library_resolves():
 
 
 def test_the_double_never_ships():
-    """nothing under lumenos_amd/, include/, bench.py or __graft_entry__.py names the test double"""
+    """nothing under lumenos_amd/, include/, bench.py, bench_lib/ or __graft_entry__.py names the test double"""
     for dirpath, _, files in list(os.walk(os.path.join(ROOT, "lumenos_amd"))) + list(os.walk(os.path.join(ROOT, "include"))):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "fake_rccl/" not in src and "fake_rccl_broken" not in src, os.path.join(dirpath, f)
-    for f in ("bench.py", "__graft_entry__.py"):
+    for f in ["bench.py", "__graft_entry__.py"] + [os.path.join("bench_lib", x) for x in sorted(os.listdir(os.path.join(ROOT, "bench_lib")))
+                                                   if x.endswith(".py")]:
         assert "fake_rccl" not in open(os.path.join(ROOT, f)).read(), f
 
 
@@ -102,7 +103,7 @@ from tests.helpers import make_context, make_params, random_cts
 from lumenos_amd.hip import Group, LumenError
 P = make_params(Oracle(), 10, 3)
 ctx = make_context(P)
-ctx.set_tuning("LUMEN_RCCL_SHARED_DEVICE", 1)   # lets AUTO pick RCCL for two ranks on the one device
+ctx.test_allow_shared_device_rccl(True)   # lets AUTO pick RCCL for two ranks on the one device
 twin = ctx.clone()
 g = Group([ctx, twin], transport="auto")
 print("TRANSPORT", g.transport, "|", g.transport_note)

@@ -58,8 +58,8 @@ from bench_lib.legs import (cpu_baseline, hashlib_sha, io_leg, other_configs, pl
 from bench_lib.multi import (all_gather_digests, all_gather_root, all_to_all_sets, attach_group,  # noqa: E402,F401
                              check_against_single_rank, device_identity, group_collectives, join_ranks, launch_ranks,
                              multi_rank_report)
-from bench_lib.report import (NTT_KERNELS, algorithmic_bytes, limb_ntt_census, pmc_entry, pmc_table,  # noqa: E402,F401
-                              profile_kernels, valu_roof)
+from bench_lib.report import (NTT_KERNELS, BoxProbe, algorithmic_bytes, limb_ntt_census, pmc_entry,  # noqa: E402,F401
+                              pmc_table, profile_kernels, step_spread, valu_roof)
 
 
 def main():
@@ -151,14 +151,22 @@ def main():
         for c in job.ctxs:
             c.sync()
 
+    probe = BoxProbe(local_rank) if rank == 0 else None  # (rocm-smi: idle now, once under load, right after)
     for _ in range(args.warmup):
         job.step(dist)
     barrier()
-    t0 = time.perf_counter()
+    if probe:
+        probe.start_timed_region()
+    step_s = []
+    t0 = t_prev = time.perf_counter()
     for _ in range(args.steps):
         job.step(dist)
+        t_now = time.perf_counter()  # (a step ends drained: its own stream synchronisation -- nothing is added here)
+        step_s.append(t_now - t_prev)
+        t_prev = t_now
     barrier()
     elapsed = time.perf_counter() - t0
+    box = probe.end_timed_region() if probe else None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -210,6 +218,10 @@ def main():
             # ... and the reference's own transform count for the same step (SURVEY 8d census) over the same time
             "limb_ntts_reference_equiv_per_s": round(census / sec_per_step, 1),
             "ct_ntts_reference_equiv_per_s": round(census / sec_per_step / (2 * job.L), 1),
+            # per-step spread of the timed region and the box it ran on: clocks / power / temperatures idle, under load and
+            # right after, device and host identity -- what a cross-round comparison of `value` has to be read against
+            "step_ms": step_spread(step_s),
+            "box": box,
             "roofline": roofline,
             "ntt_kernel": ntt_kernel,
             # the evaluation keys a client posts, from pageable host memory to usable on the device

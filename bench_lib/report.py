@@ -177,3 +177,90 @@ def valu_roof(job, ms, launches, units, sq):
         out["issue_frac"] = round(insts * (BFLY_NS_PER_WAVE_PER_SIMD / BFLY_INSTS) * 1e-9 / (launch_s * N_SIMD), 4)
         out["issue_frac_at_flat_4_cycles"] = round(insts * 4 / 2.4e9 / (launch_s * N_SIMD), 4)
     return out
+
+
+# ---- the box the line was measured on (a cross-round delta under +-3 % is unreadable without it)
+def smi_sample():
+    """clocks, power and temperatures of device 0 as rocm-smi reports them right now (a separate process reading sysfs:
+    it does not touch the HIP runtime of this one)"""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True,
+                             timeout=20).stdout
+    except Exception as e:  # noqa: BLE001 -- no rocm-smi on the box: the line says so
+        return {"error": f"{type(e).__name__}: {e}"}
+
+    def grab(pat):
+        m = re.search(pat, out)
+        return float(m.group(1)) if m else None
+    return {"sclk_mhz": grab(r"sclk clock level.*?\((\d+)Mhz\)"), "mclk_mhz": grab(r"mclk clock level.*?\((\d+)Mhz\)"),
+            "fclk_mhz": grab(r"fclk clock level.*?\((\d+)Mhz\)"),
+            "power_w": grab(r"Power \(W\):\s*([\d.]+)"), "t_junction_c": grab(r"\(Sensor junction\) \(C\):\s*([\d.]+)"),
+            "t_mem_c": grab(r"\(Sensor memory\) \(C\):\s*([\d.]+)")}
+
+
+def box_identity(device):
+    """what tells one box of the pool from another: the device's name, architecture, memory, PCI address and unique id,
+    the host's CPU model and the ROCm / driver versions"""
+    import re
+    import socket
+    import subprocess
+    ident = {"host": socket.gethostname()}
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device)
+        ident.update({"device": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count,
+                      "hbm_GiB": round(p.total_memory / 2**30, 1), "hip": torch.version.hip})
+    except Exception as e:  # noqa: BLE001
+        ident["torch_error"] = f"{type(e).__name__}: {e}"
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showbus", "--showuniqueid", "--showdriverversion", "--showserial"],
+                             capture_output=True, text=True, timeout=20).stdout
+        for key, pat in (("pci", r"PCI Bus:\s*(\S+)"), ("unique_id", r"Unique ID:\s*(\S+)"), ("serial", r"Serial Number:\s*(\S+)"),
+                         ("driver", r"Driver version:\s*(\S+)")):
+            m = re.search(pat, out)
+            ident[key] = m.group(1) if m else None
+    except Exception as e:  # noqa: BLE001
+        ident["smi_error"] = f"{type(e).__name__}: {e}"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                ident["cpu"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return ident
+
+
+class BoxProbe:
+    """rocm-smi before the warm-up (idle), ONCE under load from a side thread about a second into the timed region (the
+    main thread sits in the library's stream synchronisation meanwhile), and right after the region."""
+
+    def __init__(self, device):
+        self.out = {"identity": box_identity(device), "smi_idle_before_warmup": smi_sample()}
+        self._t = None
+
+    def start_timed_region(self, delay_s=1.0):
+        import threading
+
+        def sample():
+            time.sleep(delay_s)
+            self.out["smi_under_load"] = smi_sample()
+        self._t = threading.Thread(target=sample, daemon=True)
+        self._t.start()
+
+    def end_timed_region(self):
+        self.out["smi_right_after"] = smi_sample()
+        if self._t is not None:
+            self._t.join(30)
+        return self.out
+
+
+def step_spread(step_s):
+    """min / median / max of the timed steps' host wall times in ms (every step ends with the library's own stream
+    synchronisation, so a step's wall time is its device time; `value` stays the mean over the bracketed region)"""
+    v = sorted(step_s)
+    n = len(v)
+    med = v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+    return {"min": round(v[0] * 1e3, 2), "median": round(med * 1e3, 2), "max": round(v[-1] * 1e3, 2), "n": n}

@@ -88,6 +88,9 @@ struct lm_tuning {
     // LUMEN_KS_PLACEMENT: candidate blocks per key-switch scratch buffer among which the first key switch of a context
     // picks by measurement (lm_keyswitch.hip, select_placement); 0 or 1 = take what hipMalloc returns
     uint32_t ks_placement = 6;
+    // LUMEN_KS_P_LAST: the gadget product walks the Q limbs first and the limbs modulo P last (and the extension kernel
+    // writes the P-limb targets first), so that what the next three kernels read is what was written last
+    uint32_t ks_p_last = 0;
     // lumen_test_allow_shared_device_rccl (tests only; not reachable through lumen_ctx_set_tuning or the environment):
     // LUMEN_TRANSPORT_RCCL accepts ranks that share a device, for the test double tests/cpp/fake_rccl.cpp
     uint32_t rccl_shared_device = 0;

@@ -378,7 +378,7 @@ __device__ __forceinline__ void mac2(mac_acc &p, mac_acc &q, u64 x, u64 k0, u64 
 __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, const u64 *__restrict__ acc,
                                                 const u64 *__restrict__ key, u64 *__restrict__ u, uint32_t B,
                                                 uint32_t L, uint32_t K, uint32_t beta, uint32_t logN,
-                                                lm_mods mods) {
+                                                lm_mods mods, uint32_t p_last) {
     typedef mac_vec<LM_MAC_VEC> vec;
     const uint32_t N = 1u << logN, LK = L + K;
     // 1-D grid, XCD-aware: workgroup k runs on XCD k % 8 (round-robin dispatch) and each XCD has its own
@@ -398,7 +398,9 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
     const uint32_t i = ((slice % per_limb) * 256 + threadIdx.x) * LM_MAC_VEC; // first coefficient
     // limbs in descending order: the extension kernel wrote the highest target group last, so those
     // digits are the likeliest to still sit in the Infinity Cache
-    const uint32_t t = LK - 1 - slice / per_limb;                             // modulus index
+    // (p_last: the Q limbs first, the limbs modulo P last -- they are what the next three kernels read)
+    const uint32_t ord = slice / per_limb;
+    const uint32_t t = !p_last ? LK - 1 - ord : (ord < L ? L - 1 - ord : LK - 1 - (ord - L)); // modulus index
     const uint32_t b0 = z * LM_MAC_COLS;
     if (i >= N) return;
     const mod_t md = mods.m[t];
@@ -726,7 +728,8 @@ static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint3
     // packed as column (16 bits) | digit (8) | target modulus (8): refuse what does not fit
     LM_CHECK(ctx, B >= 1 && B <= 65535 && tb->beta <= 255 && ctx->L + ctx->K <= 255,
              "key-switch batch of %u columns (beta %u) does not fit the packed work list", B, tb->beta);
-    const uint32_t cache_key = B | (LM_MODUP_TGROUP << 16);
+    const uint32_t p_first = ctx->tune.ks_p_last; // the gadget product then ends on the P limbs: the extension starts with them
+    const uint32_t cache_key = B | (LM_MODUP_TGROUP << 16) | (p_first << 24);
     auto it = tb->d_work.find(cache_key);
     if (it != tb->d_work.end()) {
         *out = it->second;
@@ -736,12 +739,17 @@ static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint3
     std::vector<std::vector<uint8_t>> need(beta); // digit -> targets that need an extension
     for (uint16_t pr : tb->pairs) need[pr & 0xFF].push_back((uint8_t)(pr >> 8));
     std::vector<std::vector<uint32_t>> lists(8);
+    std::vector<uint32_t> group_start;
+    if (p_first) // the P limbs first (in groups of their own), then the Q limbs
+        for (uint32_t t0 = ctx->L; t0 < LK; t0 += LM_MODUP_TGROUP) group_start.push_back(t0 | (std::min(LK, t0 + LM_MODUP_TGROUP) << 8));
+    for (uint32_t t0 = 0; t0 < (p_first ? ctx->L : LK); t0 += LM_MODUP_TGROUP)
+        group_start.push_back(t0 | (std::min(p_first ? ctx->L : LK, t0 + LM_MODUP_TGROUP) << 8));
     for (uint32_t x = 0; x < 8; x++)
-        for (uint32_t t0 = 0; t0 < LK; t0 += LM_MODUP_TGROUP)
+        for (uint32_t gs : group_start)
             for (uint32_t b = x; b < B; b += 8)
                 for (uint32_t d = 0; d < beta; d++)
                     for (uint8_t t : need[d])
-                        if (t >= t0 && t < t0 + LM_MODUP_TGROUP) lists[x].push_back(b | (d << 16) | ((uint32_t)t << 24));
+                        if (t >= (gs & 0xFF) && t < (gs >> 8)) lists[x].push_back(b | (d << 16) | ((uint32_t)t << 24));
     // interleave: entry k belongs to XCD k % 8; lists of unequal length (B not a multiple of 8) are
     // drained in turn
     std::vector<uint32_t> order;
@@ -931,7 +939,7 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
         lm_prof_scope ps(ctx, "ks_mac", (uint64_t)B);
         dim3 grid(((N / LM_MAC_VEC + 255) / 256) * LK * ((B + LM_MAC_COLS - 1) / LM_MAC_COLS));
         hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, s.ext, acc, gk.d_key, s.u, B, L, K, beta,
-                           ctx->logN, ctx->mods);
+                           ctx->logN, ctx->mods, ctx->tune.ks_p_last);
         LM_HIP(ctx, hipGetLastError());
     }
     // 4a. P limbs of u -> coefficient domain (in place)
@@ -985,14 +993,23 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
 // LUMEN_KS_PLACEMENT (6) candidates per buffer and keeps, buffer by buffer, the one under which two rotations of a
 // whole batch run fastest (coordinate descent in the order the sensitivities were measured: u, ext, then the
 // accumulator's twin and the coefficient buffer); the others are freed.  One-off cost at the headline size: about
-// 0.2 s and 7.5 GB of transient device memory.  Results do not depend on the choice (same kernels, same residues).
-int get_scratch(lumen_ctx *ctx, uint32_t B, KsTables *tb, KsScratch *s, int lane = 0) {
+// 0.3 s and 14 GB of transient device memory (never more than half of what is free).  Results do not depend on the choice
+// (same kernels, same residues).
+// group_acc / group_acc_bytes: the caller's accumulator block for a GROUP of batches (lumen_matrix_inner_sum: every batch works in
+// its own slice of it) is placed by the same measurement -- in situ the rotations alternate between reading a slice of it
+// and reading the twin, and with only the four buffers above chosen the gadget product still came out in two modes from
+// process to process (331 / 349 ms per step).
+int get_scratch(lumen_ctx *ctx, uint32_t B, KsTables *tb, KsScratch *s, int lane = 0, u64 **group_acc = nullptr,
+                size_t group_acc_bytes = 0) {
     const size_t N = ctx->N, L = ctx->L, LK = ctx->L + ctx->K, beta = tb->beta;
-    const char *names[2][4] = {{"ks_coef", "ks_ext", "ks_u", "ks_acc2"}, {"ks_coef_b", "ks_ext_b", "ks_u_b", "ks_acc2_b"}};
-    const size_t bytes[4] = {(size_t)B * L * N * 8, (size_t)B * beta * LK * N * 8, (size_t)B * 2 * LK * N * 8, (size_t)B * 2 * L * N * 8};
-    u64 **slot[4] = {&s->coef, &s->ext, &s->u, &s->acc2};
+    const char *names[2][5] = {{"ks_coef", "ks_ext", "ks_u", "ks_acc2", "ks_acc"}, {"ks_coef_b", "ks_ext_b", "ks_u_b", "ks_acc2_b", "ks_acc"}};
+    const int NB = group_acc ? 5 : 4;
+    const size_t bytes[5] = {(size_t)B * L * N * 8, (size_t)B * beta * LK * N * 8, (size_t)B * 2 * LK * N * 8, (size_t)B * 2 * L * N * 8,
+                             std::max(group_acc_bytes, (size_t)B * 2 * L * N * 8)};
+    u64 *dummy = nullptr;
+    u64 **slot[5] = {&s->coef, &s->ext, &s->u, &s->acc2, group_acc ? group_acc : &dummy};
     bool have = true;
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < NB; c++) {
         auto it = ctx->scratch.find(names[lane][c]);
         have = have && it != ctx->scratch.end() && it->second.first && it->second.second >= bytes[c];
     }
@@ -1002,43 +1019,63 @@ int get_scratch(lumen_ctx *ctx, uint32_t B, KsTables *tb, KsScratch *s, int lane
         if (!ctx->gkeys.empty()) gk = ctx->gkeys.begin()->second;
     }
     const uint32_t Kc = ctx->tune.ks_placement;
+    auto plain = [&]() -> int {
+        bool ok = true;
+        for (int c = 0; c < NB; c++) ok = (*slot[c] = (u64 *)lm_scratch(ctx, names[lane][c], bytes[c])) != nullptr && ok;
+        return ok ? 0 : 1;
+    };
     // small buffers live in the caches, and without a key no rotation can be timed: plain allocation
-    if (have || Kc < 2 || bytes[1] < ((size_t)64 << 20) || !gk.d_key) {
-        for (int c = 0; c < 4; c++) *slot[c] = (u64 *)lm_scratch(ctx, names[lane][c], bytes[c]);
-        return (s->coef && s->ext && s->u && s->acc2) ? 0 : 1;
+    if (have || Kc < 2 || bytes[1] < ((size_t)64 << 20) || !gk.d_key) return plain();
+    // what is already there and large enough stays (a buffer shared with the other lane, a context whose batch size grew):
+    // only the missing buffers are drawn
+    std::vector<void *> cand[5];
+    bool fixed[5] = {false, false, false, false, false};
+    for (int c = 0; c < NB; c++) {
+        auto it = ctx->scratch.find(names[lane][c]);
+        if (it != ctx->scratch.end() && it->second.first && it->second.second >= bytes[c]) cand[c].push_back(it->second.first), fixed[c] = true;
     }
-    std::vector<void *> cand[4];
     void *probe_acc = nullptr;
     auto free_all = [&] {
-        for (int c = 0; c < 4; c++)
-            for (void *p : cand[c]) hipFree(p);
+        for (int c = 0; c < NB; c++)
+            if (!fixed[c])
+                for (void *p : cand[c]) hipFree(p);
         hipFree(probe_acc);
         (void)hipGetLastError();
     };
-    if (hipMalloc(&probe_acc, bytes[3]) != hipSuccess) probe_acc = nullptr;
-    for (uint32_t k = 0; k < Kc && probe_acc; k++) // round-robin over the buffers: the candidates of one buffer are spread out
-        for (int c = 0; c < 4; c++) {
+    size_t free_b = 0, total_b = 0, drawn = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if (!group_acc && hipMalloc(&probe_acc, bytes[3]) != hipSuccess) probe_acc = nullptr;
+    for (uint32_t k = 0; k < Kc; k++) // round-robin over the buffers: the candidates of one buffer are spread out
+        for (int c = 0; c < NB; c++) {
+            if (fixed[c] || (c == 4 && k >= 4)) continue;                 // (the group accumulator is the big one: four draws)
+            if (!cand[c].empty() && drawn + bytes[c] > free_b / 2) continue; // never more than half of what is free
             void *p = nullptr;
-            if (hipMalloc(&p, bytes[c]) == hipSuccess) cand[c].push_back(p);
+            if (hipMalloc(&p, bytes[c]) == hipSuccess) cand[c].push_back(p), drawn += bytes[c];
         }
     (void)hipGetLastError();
-    if (!probe_acc || cand[0].empty() || cand[1].empty() || cand[2].empty() || cand[3].empty()) { // memory is short: no choice to make
+    bool complete = group_acc || probe_acc;
+    for (int c = 0; c < NB; c++) complete = complete && !cand[c].empty();
+    if (!complete) { // memory is short: no choice to make
         free_all();
-        for (int c = 0; c < 4; c++) *slot[c] = (u64 *)lm_scratch(ctx, names[lane][c], bytes[c]);
-        return (s->coef && s->ext && s->u && s->acc2) ? 0 : 1;
+        return plain();
     }
     const bool prof = ctx->prof;
     ctx->prof = false; // the rotations below are not part of anybody's measurement
     hipEvent_t e0 = lm_ev_get(ctx), e1 = lm_ev_get(ctx);
-    size_t pick[4] = {0, 0, 0, 0};
+    size_t pick[5] = {0, 0, 0, 0, 0};
     int rc = 0;
-    auto eval = [&](float *ms) -> int { // two rotations of a batch (the accumulator ping-pongs): one untimed, two timed pairs
+    // two rotations of a batch (the accumulator ping-pongs with its twin): one pair untimed, two timed -- in the first
+    // and in the last batch slice of the group accumulator
+    auto eval = [&](float *ms) -> int {
         KsScratch t;
         t.coef = (u64 *)cand[0][pick[0]], t.ext = (u64 *)cand[1][pick[1]], t.u = (u64 *)cand[2][pick[2]], t.acc2 = (u64 *)cand[3][pick[3]];
+        u64 *a0 = group_acc ? (u64 *)cand[4][pick[4]] : (u64 *)probe_acc;
+        u64 *a1 = group_acc ? a0 + (bytes[4] - bytes[3]) / 8 : a0;
         for (int r = 0; r < 3; r++) {
             if (r == 1) LM_HIP(ctx, hipEventRecord(e0, ctx->stream));
-            if (int e = rotate_accumulate(ctx, (u64 *)probe_acc, t.acc2, B, gk, tb, t)) return e;
-            if (int e = rotate_accumulate(ctx, t.acc2, (u64 *)probe_acc, B, gk, tb, t)) return e;
+            u64 *a = r == 2 ? a1 : a0;
+            if (int e = rotate_accumulate(ctx, a, t.acc2, B, gk, tb, t)) return e;
+            if (int e = rotate_accumulate(ctx, t.acc2, a, B, gk, tb, t)) return e;
         }
         LM_HIP(ctx, hipEventRecord(e1, ctx->stream));
         LM_HIP(ctx, hipEventSynchronize(e1));
@@ -1046,23 +1083,26 @@ int get_scratch(lumen_ctx *ctx, uint32_t B, KsTables *tb, KsScratch *s, int lane
         return 0;
     };
     float first = 0, best_all = 0;
-    static const int order[4] = {2, 1, 3, 0}; // u, ext, acc2, coef
-    for (int oi = 0; oi < 4 && !rc; oi++) {
+    static const int order[5] = {2, 1, 4, 3, 0}; // u, ext, the group accumulator, its twin, coef
+    bool measured = false;
+    for (int oi = 0; oi < 5 && !rc; oi++) {
         const int c = order[oi];
+        if (c >= NB) continue;
         float best = 0;
-        size_t arg = 0;
+        size_t arg = pick[c];
         for (size_t k = 0; k < cand[c].size() && !rc; k++) {
-            if (oi > 0 && k == pick[c]) continue; // timed as the previous buffer's winner
+            if (measured && k == pick[c]) continue; // timed already: it is the configuration `best_all` belongs to
             const size_t keep = pick[c];
             pick[c] = k;
             float ms = 0;
             rc = eval(&ms);
             pick[c] = keep;
-            if (oi == 0 && k == 0) first = ms;
+            if (first == 0) first = ms;
             if (best == 0 || ms < best) best = ms, arg = k;
         }
-        if (best == 0 || (oi > 0 && best_all > 0 && best_all <= best)) arg = pick[c]; // nothing beat the configuration already measured
+        if (best == 0 || (measured && best_all <= best)) arg = pick[c]; // nothing beat the configuration already measured
         else best_all = best;
+        if (best != 0) measured = true;
         pick[c] = arg;
     }
     ctx->ev_pool.push_back(e0);
@@ -1074,15 +1114,18 @@ int get_scratch(lumen_ctx *ctx, uint32_t B, KsTables *tb, KsScratch *s, int lane
         return rc;
     }
     if (ctx->tune.debug)
-        fprintf(stderr, "[lumenos_hip] key-switch scratch placement (lane %d, %u columns): %zu candidates per buffer, 4 rotations of the "
-                        "first draw %.3f ms, of the chosen blocks %.3f ms\n", lane, B, cand[2].size(), first, best_all);
-    for (int c = 0; c < 4; c++) {
+        fprintf(stderr, "[lumenos_hip] key-switch scratch placement (lane %d, %u columns): %zu / %zu / %zu candidates for u / ext / the group "
+                        "accumulator, 4 rotations of the first draw %.3f ms, of the chosen blocks %.3f ms\n", lane, B, cand[2].size(),
+                cand[1].size(), NB == 5 ? cand[4].size() : (size_t)0, first, best_all);
+    LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // nothing may still run on a block that is about to be freed
+    for (int c = 0; c < NB; c++) {
         void *chosen = cand[c][pick[c]];
-        cand[c][pick[c]] = nullptr; // hipFree(nullptr) is a no-op
-        lm_scratch_adopt(ctx, names[lane][c], chosen, bytes[c]);
+        if (!fixed[c]) {
+            cand[c][pick[c]] = nullptr; // hipFree(nullptr) is a no-op
+            lm_scratch_adopt(ctx, names[lane][c], chosen, bytes[c]);
+        }
         *slot[c] = (u64 *)chosen;
     }
-    LM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the losers are freed: nothing may still run on them
     free_all();
     return 0;
 }
@@ -1178,7 +1221,7 @@ extern "C" int lumen_ks_mac_probe(lumen_ctx *ctx, uint32_t batch, const void *ex
     dim3 grid(((N / LM_MAC_VEC + 255) / 256) * LK * ((B + LM_MAC_COLS - 1) / LM_MAC_COLS));
     auto launch = [&] {
         hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, pe, (const u64 *)acc, (const u64 *)key, pu, B, L, K,
-                           tb->beta, ctx->logN, ctx->mods);
+                           tb->beta, ctx->logN, ctx->mods, ctx->tune.ks_p_last);
     };
     for (int i = 0; i < 3; i++) launch();
     LM_HIP(ctx, hipGetLastError());
@@ -1383,12 +1426,12 @@ extern "C" int lumen_matrix_inner_sum(lumen_ctx *ctx, const lumen_set *matrix, c
     const uint32_t group = std::min<uint32_t>(8 * Bmax, std::max(matrix->count, 1u));
     KsScratch s[2];
     const size_t ctw = (size_t)2 * L * N, octw = (size_t)2 * target * N;
-    u64 *acc = (u64 *)lm_scratch(ctx, "ks_acc", (size_t)group * ctw * 8);
+    u64 *acc = nullptr; // the group's accumulators: placed together with the key switch's scratch (get_scratch)
+    if (get_scratch(ctx, Bmax, tb, &s[0], 0, &acc, (size_t)group * ctw * 8) || (ks_lanes(ctx) > 1 && get_scratch(ctx, Bmax, tb, &s[1], 1)))
+        return 1;
     u64 *work = (u64 *)lm_scratch(ctx, "rescale_work", (size_t)group * ctw * 8);
     u64 *tbuf = (u64 *)lm_scratch(ctx, "rescale_t", (size_t)group * 2 * N * 8);
-    if (get_scratch(ctx, Bmax, tb, &s[0], 0) || (ks_lanes(ctx) > 1 && get_scratch(ctx, Bmax, tb, &s[1], 1)) ||
-        !acc || !work || !tbuf)
-        return 1;
+    if (!acc || !work || !tbuf) return 1;
     for (uint32_t g0 = 0; g0 < matrix->count; g0 += group) {
         const uint32_t gn = std::min(group, matrix->count - g0);
         // fork: the second lane starts after everything already enqueued on the main stream

@@ -84,13 +84,10 @@ struct lm_tuning {
     uint32_t debug = 0;          // LUMEN_DEBUG
     // LUMEN_MODUP_TGROUP / LUMEN_MODDOWN_TGROUP: target limbs one XCD walks back to back in the work lists of the
     // two transform kernels of a key switch (lm_keyswitch.hip); 1 .. 31
-    uint32_t modup_tgroup = 4, moddown_tgroup = 2; // (round 6, limb-major streams: ModDown 2 / 4 / 6 / 12 = 1.8140 / 1.8258 / 1.8246 / 1.8371 s per step)
+    uint32_t modup_tgroup = 4, moddown_tgroup = 1; // (round 6, limb-major streams: ModDown 1 / 2 / 3 = 1.7691 / 1.7726 / 1.7711 s per step; 2 / 4 / 6 / 12 = 1.8140 / 1.8258 / 1.8246 / 1.8371 on another box)
     // LUMEN_KS_PLACEMENT: candidate blocks per key-switch scratch buffer among which the first key switch of a context
     // picks by measurement (lm_keyswitch.hip, select_placement); 0 or 1 = take what hipMalloc returns
     uint32_t ks_placement = 6;
-    // LUMEN_KS_P_LAST: the gadget product walks the Q limbs first and the limbs modulo P last (and the extension kernel
-    // writes the P-limb targets first), so that what the next three kernels read is what was written last
-    uint32_t ks_p_last = 0;
     // lumen_test_allow_shared_device_rccl (tests only; not reachable through lumen_ctx_set_tuning or the environment):
     // LUMEN_TRANSPORT_RCCL accepts ranks that share a device, for the test double tests/cpp/fake_rccl.cpp
     uint32_t rccl_shared_device = 0;

@@ -210,8 +210,6 @@ static int tuning_set(lm_tuning &t, const char *name, long v) {
     } else if (n == "LUMEN_MODDOWN_TGROUP") {
         if (!in(1, 31)) return 2;
         t.moddown_tgroup = (uint32_t)v;
-    } else if (n == "LUMEN_KS_P_LAST") {
-        t.ks_p_last = v != 0;
     } else if (n == "LUMEN_KS_PLACEMENT") {
         if (!in(0, 32)) return 2;
         t.ks_placement = (uint32_t)v;
@@ -222,7 +220,7 @@ static int tuning_set(lm_tuning &t, const char *name, long v) {
 }
 static void tuning_from_env(lm_tuning &t) {
     for (const char *n : {"LUMEN_KS_BATCH", "LUMEN_KS_LANES", "LUMEN_KS_FUSED_DIGITS", "LUMEN_DEBUG",
-                          "LUMEN_MODUP_TGROUP", "LUMEN_MODDOWN_TGROUP", "LUMEN_KS_PLACEMENT", "LUMEN_KS_P_LAST"}) {
+                          "LUMEN_MODUP_TGROUP", "LUMEN_MODDOWN_TGROUP", "LUMEN_KS_PLACEMENT"}) {
         const char *e = getenv(n);
         // an empty override counts as unset; a value out of range is reported and leaves the default
         if (e && *e && tuning_set(t, n, atol(e)))

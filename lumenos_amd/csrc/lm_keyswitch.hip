@@ -378,7 +378,7 @@ __device__ __forceinline__ void mac2(mac_acc &p, mac_acc &q, u64 x, u64 k0, u64 
 __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, const u64 *__restrict__ acc,
                                                 const u64 *__restrict__ key, u64 *__restrict__ u, uint32_t B,
                                                 uint32_t L, uint32_t K, uint32_t beta, uint32_t logN,
-                                                lm_mods mods, uint32_t p_last) {
+                                                lm_mods mods) {
     typedef mac_vec<LM_MAC_VEC> vec;
     const uint32_t N = 1u << logN, LK = L + K;
     // 1-D grid, XCD-aware: workgroup k runs on XCD k % 8 (round-robin dispatch) and each XCD has its own
@@ -398,9 +398,10 @@ __global__ __launch_bounds__(256) void k_ks_mac(const u64 *__restrict__ ext, con
     const uint32_t i = ((slice % per_limb) * 256 + threadIdx.x) * LM_MAC_VEC; // first coefficient
     // limbs in descending order: the extension kernel wrote the highest target group last, so those
     // digits are the likeliest to still sit in the Infinity Cache
-    // (p_last: the Q limbs first, the limbs modulo P last -- they are what the next three kernels read)
-    const uint32_t ord = slice / per_limb;
-    const uint32_t t = !p_last ? LK - 1 - ord : (ord < L ? L - 1 - ord : LK - 1 - (ord - L)); // modulus index
+    // (walking the Q limbs first and the limbs modulo P last, so that what the next three kernels read is what was written
+    // last -- with the extension kernel writing its P-limb targets first -- was measured: this kernel -2 %, the extension
+    // kernel +1.2 %, the step +0.3 %: profiles/r06_exp_ks_p_last_interleaved.txt)
+    const uint32_t t = LK - 1 - slice / per_limb;                             // modulus index
     const uint32_t b0 = z * LM_MAC_COLS;
     if (i >= N) return;
     const mod_t md = mods.m[t];
@@ -728,8 +729,7 @@ static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint3
     // packed as column (16 bits) | digit (8) | target modulus (8): refuse what does not fit
     LM_CHECK(ctx, B >= 1 && B <= 65535 && tb->beta <= 255 && ctx->L + ctx->K <= 255,
              "key-switch batch of %u columns (beta %u) does not fit the packed work list", B, tb->beta);
-    const uint32_t p_first = ctx->tune.ks_p_last; // the gadget product then ends on the P limbs: the extension starts with them
-    const uint32_t cache_key = B | (LM_MODUP_TGROUP << 16) | (p_first << 24);
+    const uint32_t cache_key = B | (LM_MODUP_TGROUP << 16);
     auto it = tb->d_work.find(cache_key);
     if (it != tb->d_work.end()) {
         *out = it->second;
@@ -739,17 +739,12 @@ static int modup_work_list(lumen_ctx *ctx, KsTables *tb, uint32_t B, const uint3
     std::vector<std::vector<uint8_t>> need(beta); // digit -> targets that need an extension
     for (uint16_t pr : tb->pairs) need[pr & 0xFF].push_back((uint8_t)(pr >> 8));
     std::vector<std::vector<uint32_t>> lists(8);
-    std::vector<uint32_t> group_start;
-    if (p_first) // the P limbs first (in groups of their own), then the Q limbs
-        for (uint32_t t0 = ctx->L; t0 < LK; t0 += LM_MODUP_TGROUP) group_start.push_back(t0 | (std::min(LK, t0 + LM_MODUP_TGROUP) << 8));
-    for (uint32_t t0 = 0; t0 < (p_first ? ctx->L : LK); t0 += LM_MODUP_TGROUP)
-        group_start.push_back(t0 | (std::min(p_first ? ctx->L : LK, t0 + LM_MODUP_TGROUP) << 8));
     for (uint32_t x = 0; x < 8; x++)
-        for (uint32_t gs : group_start)
+        for (uint32_t t0 = 0; t0 < LK; t0 += LM_MODUP_TGROUP)
             for (uint32_t b = x; b < B; b += 8)
                 for (uint32_t d = 0; d < beta; d++)
                     for (uint8_t t : need[d])
-                        if (t >= (gs & 0xFF) && t < (gs >> 8)) lists[x].push_back(b | (d << 16) | ((uint32_t)t << 24));
+                        if (t >= t0 && t < t0 + LM_MODUP_TGROUP) lists[x].push_back(b | (d << 16) | ((uint32_t)t << 24));
     // interleave: entry k belongs to XCD k % 8; lists of unequal length (B not a multiple of 8) are
     // drained in turn
     std::vector<uint32_t> order;
@@ -939,7 +934,7 @@ int rotate_accumulate(lumen_ctx *ctx, const u64 *acc, u64 *acc_out, uint32_t B, 
         lm_prof_scope ps(ctx, "ks_mac", (uint64_t)B);
         dim3 grid(((N / LM_MAC_VEC + 255) / 256) * LK * ((B + LM_MAC_COLS - 1) / LM_MAC_COLS));
         hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, s.ext, acc, gk.d_key, s.u, B, L, K, beta,
-                           ctx->logN, ctx->mods, ctx->tune.ks_p_last);
+                           ctx->logN, ctx->mods);
         LM_HIP(ctx, hipGetLastError());
     }
     // 4a. P limbs of u -> coefficient domain (in place)
@@ -1221,7 +1216,7 @@ extern "C" int lumen_ks_mac_probe(lumen_ctx *ctx, uint32_t batch, const void *ex
     dim3 grid(((N / LM_MAC_VEC + 255) / 256) * LK * ((B + LM_MAC_COLS - 1) / LM_MAC_COLS));
     auto launch = [&] {
         hipLaunchKernelGGL(k_ks_mac, grid, dim3(256), 0, ctx->stream, pe, (const u64 *)acc, (const u64 *)key, pu, B, L, K,
-                           tb->beta, ctx->logN, ctx->mods, ctx->tune.ks_p_last);
+                           tb->beta, ctx->logN, ctx->mods);
     };
     for (int i = 0; i < 3; i++) launch();
     LM_HIP(ctx, hipGetLastError());

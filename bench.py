@@ -151,7 +151,7 @@ def main():
         for c in job.ctxs:
             c.sync()
 
-    probe = BoxProbe(local_rank) if rank == 0 else None  # (rocm-smi: idle now, once under load, right after)
+    probe = BoxProbe(local_rank) if rank == 0 else None  # (clocks / power / temperatures: idle now, once under load, right after)
     for _ in range(args.warmup):
         job.step(dist)
     barrier()

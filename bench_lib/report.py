@@ -180,11 +180,76 @@ def valu_roof(job, ms, launches, units, sq):
 
 
 # ---- the box the line was measured on (a cross-round delta under +-3 % is unreadable without it)
-def smi_sample():
-    """clocks, power and temperatures of device 0 as rocm-smi reports them right now (a separate process reading sysfs:
-    it does not touch the HIP runtime of this one)"""
+def _under_profiler():
+    """rocprofv3 preloads a tool library into every child process, which then owns the GPU before its main() runs; the
+    rocm-smi script re-executes itself through `env python3` -- an exec after GPU initialisation, which this pool's boxes
+    refuse.  Under a profiler nothing is spawned."""
+    env = os.environ
+    return any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in env) or "rocprof" in env.get("LD_PRELOAD", "")
+
+
+def _sysfs_device(pci=None):
+    """/sys/class/drm/cardN/device of the GPU this process computes on: the card whose PCI address is `pci`
+    ("0000:26:00.0"), else the first card that has amdgpu's hwmon frequency files"""
+    import glob
+    found = None
+    for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+        real = os.path.realpath(dev)
+        if not glob.glob(os.path.join(dev, "hwmon", "hwmon*", "freq1_input")):
+            continue
+        if pci and os.path.basename(real).lower() == pci.lower():
+            return dev
+        found = found or dev
+    return found
+
+
+def _read(path, conv=str):
+    try:
+        return conv(open(path).read().strip())
+    except (OSError, ValueError):
+        return None
+
+
+def sysfs_sample(pci=None):
+    """clocks, power and temperatures straight from amdgpu's hwmon files (what rocm-smi itself reads): no child process"""
+    import glob
+    dev = _sysfs_device(pci)
+    if not dev:
+        return None
+    hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))[0]
+    by_label = {}
+    for lab in glob.glob(os.path.join(hw, "*_label")):
+        name = _read(lab)
+        val = _read(lab.replace("_label", "_input"), float)
+        if name and val is not None:
+            by_label[name] = val
+    power = _read(os.path.join(hw, "power1_average"), float)
+    if power is None:
+        power = _read(os.path.join(hw, "power1_input"), float)
+    fclk = None
+    for line in (_read(os.path.join(dev, "pp_dpm_fclk")) or "").splitlines():
+        if line.rstrip().endswith("*"):
+            try:
+                fclk = float(line.split(":")[1].strip().split("M")[0])
+            except (IndexError, ValueError):
+                pass
+    mhz = lambda k: round(by_label[k] / 1e6) if k in by_label else None  # noqa: E731
+    deg = lambda k: round(by_label[k] / 1e3, 1) if k in by_label else None  # noqa: E731
+    return {"sclk_mhz": mhz("sclk"), "mclk_mhz": mhz("mclk"), "fclk_mhz": fclk,
+            "power_w": round(power / 1e6, 1) if power is not None else None,
+            "t_junction_c": deg("junction"), "t_mem_c": deg("mem"), "source": "sysfs"}
+
+
+def smi_sample(pci=None):
+    """clocks, power and temperatures of the device right now: amdgpu's hwmon files; rocm-smi (a separate process reading
+    the same files) only where those are not readable and no profiler is attached"""
     import re
     import subprocess
+    s_ = sysfs_sample(pci)
+    if s_ and s_.get("sclk_mhz") is not None:
+        return s_
+    if _under_profiler():
+        return {"error": "hwmon files not readable and a profiler is attached: rocm-smi is not spawned"}
     try:
         out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True,
                              timeout=20).stdout
@@ -197,32 +262,33 @@ def smi_sample():
     return {"sclk_mhz": grab(r"sclk clock level.*?\((\d+)Mhz\)"), "mclk_mhz": grab(r"mclk clock level.*?\((\d+)Mhz\)"),
             "fclk_mhz": grab(r"fclk clock level.*?\((\d+)Mhz\)"),
             "power_w": grab(r"Power \(W\):\s*([\d.]+)"), "t_junction_c": grab(r"\(Sensor junction\) \(C\):\s*([\d.]+)"),
-            "t_mem_c": grab(r"\(Sensor memory\) \(C\):\s*([\d.]+)")}
+            "t_mem_c": grab(r"\(Sensor memory\) \(C\):\s*([\d.]+)"), "source": "rocm-smi"}
 
 
 def box_identity(device):
-    """what tells one box of the pool from another: the device's name, architecture, memory, PCI address and unique id,
-    the host's CPU model and the ROCm / driver versions"""
-    import re
+    """what tells one box of the pool from another: the device's name, architecture, memory, PCI address, unique id and
+    serial number (sysfs), the host's CPU model and the HIP / driver versions"""
     import socket
-    import subprocess
     ident = {"host": socket.gethostname()}
+    pci = None
     try:
         import torch
         p = torch.cuda.get_device_properties(device)
         ident.update({"device": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count,
                       "hbm_GiB": round(p.total_memory / 2**30, 1), "hip": torch.version.hip})
+        if all(hasattr(p, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            pci = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
     except Exception as e:  # noqa: BLE001
         ident["torch_error"] = f"{type(e).__name__}: {e}"
-    try:
-        out = subprocess.run(["rocm-smi", "-d", "0", "--showbus", "--showuniqueid", "--showdriverversion", "--showserial"],
-                             capture_output=True, text=True, timeout=20).stdout
-        for key, pat in (("pci", r"PCI Bus:\s*(\S+)"), ("unique_id", r"Unique ID:\s*(\S+)"), ("serial", r"Serial Number:\s*(\S+)"),
-                         ("driver", r"Driver version:\s*(\S+)")):
-            m = re.search(pat, out)
-            ident[key] = m.group(1) if m else None
-    except Exception as e:  # noqa: BLE001
-        ident["smi_error"] = f"{type(e).__name__}: {e}"
+    dev = _sysfs_device(pci)
+    if dev:
+        ident["pci"] = os.path.basename(os.path.realpath(dev))
+        ident["unique_id"] = _read(os.path.join(dev, "unique_id"))
+        ident["serial"] = _read(os.path.join(dev, "serial_number"))
+        ident["vbios"] = _read(os.path.join(dev, "vbios_version"))
+    else:
+        ident["pci"] = pci
+    ident["driver"] = _read("/sys/module/amdgpu/version") or _read("/proc/sys/kernel/osrelease")
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
@@ -234,11 +300,13 @@ def box_identity(device):
 
 
 class BoxProbe:
-    """rocm-smi before the warm-up (idle), ONCE under load from a side thread about a second into the timed region (the
-    main thread sits in the library's stream synchronisation meanwhile), and right after the region."""
+    """clocks / power / temperatures before the warm-up (idle), ONCE under load from a side thread about a second into the
+    timed region (the main thread sits in the library's stream synchronisation meanwhile), and right after the region."""
 
     def __init__(self, device):
-        self.out = {"identity": box_identity(device), "smi_idle_before_warmup": smi_sample()}
+        ident = box_identity(device)
+        self.pci = ident.get("pci")
+        self.out = {"identity": ident, "smi_idle_before_warmup": smi_sample(self.pci)}
         self._t = None
 
     def start_timed_region(self, delay_s=1.0):
@@ -246,12 +314,12 @@ class BoxProbe:
 
         def sample():
             time.sleep(delay_s)
-            self.out["smi_under_load"] = smi_sample()
+            self.out["smi_under_load"] = smi_sample(self.pci)
         self._t = threading.Thread(target=sample, daemon=True)
         self._t.start()
 
     def end_timed_region(self):
-        self.out["smi_right_after"] = smi_sample()
+        self.out["smi_right_after"] = smi_sample(self.pci)
         if self._t is not None:
             self._t.join(30)
         return self.out

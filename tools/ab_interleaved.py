@@ -12,8 +12,6 @@ spread between rounds; interleaving means box drift hits all values alike."""
 import argparse
 import json
 import os
-import re
-import subprocess
 import sys
 import time
 
@@ -22,17 +20,8 @@ sys.path.insert(0, ROOT)
 
 
 def smi():
-    try:
-        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True,
-                             timeout=20).stdout
-    except Exception as e:  # noqa: BLE001
-        return {"error": str(e)}
-    def grab(pat):
-        m = re.search(pat, out)
-        return float(m.group(1)) if m else None
-    return {"sclk_mhz": grab(r"sclk clock level.*?\((\d+)Mhz\)"), "mclk_mhz": grab(r"mclk clock level.*?\((\d+)Mhz\)"),
-            "power_w": grab(r"Power \(W\):\s*([\d.]+)"), "t_junction": grab(r"\(Sensor junction\) \(C\):\s*([\d.]+)"),
-            "t_mem": grab(r"\(Sensor memory\) \(C\):\s*([\d.]+)")}
+    from bench_lib.report import smi_sample  # amdgpu's hwmon files; rocm-smi only where those are not readable
+    return smi_sample()
 
 
 def main():

@@ -722,6 +722,56 @@ def test_lazy_accumulator_at_the_modulus_bound(oracle, nq, npr):
     ctx.close()
 
 
+def test_scratch_placement_is_chosen_by_measurement_and_changes_no_residue(oracle):
+    """Round 6: a context's first key switch draws LUMEN_KS_PLACEMENT candidates per scratch buffer and keeps the blocks
+    under which rotations run fastest (lm_keyswitch.hip, get_scratch).  The choice must not show in the results: the same
+    matrixInnerSumEval with the selection off, on, and on again after lumen_ctx_trim gives the oracle's residues; the
+    chosen blocks are where lumen_ctx_scratch_info says, large enough, and stay put from one call to the next; the
+    diagnostic probe runs on them."""
+    P = make_params(oracle, 12, 8)            # beta = 4 digits x 10 limbs x 32 KB x 64 columns: ext = 84 MB, above the 64 MB threshold
+    P.seed(21)
+    sk = P.keygen_secret()
+    ctx = make_context(P)
+    n = 8
+    gl = P.inner_sum_galois_elements(n)
+    evks = [P.keygen_galois(sk, g) for g in gl]
+    for g, e in zip(gl, evks):
+        ctx.load_galois_key(g, e)
+    cts = random_cts(P, 64, P.L, seed=22)
+    pt = P.encode(np.arange(1, P.N + 1, dtype=np.uint64))
+    want = P.matrix_inner_sum(cts, pt, n, evks)
+    d = ctx.upload(cts)
+    for k in (0, 6, 6):
+        ctx.set_tuning("LUMEN_KS_PLACEMENT", k)
+        ctx.trim()  # the buffers are drawn again at the next key switch
+        assert np.array_equal(ctx.matrix_inner_sum(d, pt, n).download(), want), k
+        blocks = {name: ctx.scratch_info(name) for name in ("ks_ext", "ks_u", "ks_coef", "ks_acc2", "ks_acc")}
+        beta, LK = (P.L + 2 - 1) // 2, P.L + 2
+        assert blocks["ks_ext"][0] and blocks["ks_ext"][1] >= 64 * beta * LK * P.N * 8, blocks
+        assert blocks["ks_u"][0] and blocks["ks_u"][1] >= 64 * 2 * LK * P.N * 8, blocks
+        assert np.array_equal(ctx.matrix_inner_sum(d, pt, n).download(), want), k
+        assert blocks == {name: ctx.scratch_info(name) for name in blocks}, "the chosen blocks moved between two calls"
+    assert ctx.ks_mac_probe(64, reps=3) > 0
+    assert ctx.scratch_info("no_such_buffer") == (None, 0)
+    ctx.close()
+
+
+def test_tuning_switch_errors(small):
+    """lumen_ctx_set_tuning: an unknown name and a value out of a switch's range are errors and change nothing (a typo in an
+    A/B tool must not silently measure the default); the RCCL shared-device switch is a named test hook, not a name here."""
+    from lumenos_amd.hip import LumenError
+    _, ctx = small
+    for name, bad in (("LUMEN_MODUP_TGROUP", 0), ("LUMEN_MODDOWN_TGROUP", 32), ("LUMEN_KS_BATCH", 0), ("LUMEN_KS_LANES", 3),
+                      ("LUMEN_KS_PLACEMENT", 33)):
+        with pytest.raises(LumenError, match="out of range"):
+            ctx.set_tuning(name, bad)
+    for name in ("LUMEN_NO_SUCH_SWITCH", "LUMEN_RCCL_SHARED_DEVICE", "LUMEN_CT_BLOCKS"):
+        with pytest.raises(LumenError, match="unknown tuning switch"):
+            ctx.set_tuning(name, 1)
+    ctx.set_tuning("LUMEN_KS_LANES", 0)          # the documented ways back to the derived defaults
+    ctx.set_tuning("LUMEN_KS_FUSED_DIGITS", -1)
+
+
 def test_rescale_mixed_size_moduli_falls_back(oracle):
     """Moduli more than 16x apart have no coefficient-form tables: the per-step path answers."""
     from oracle.loader import Params

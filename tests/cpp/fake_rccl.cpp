@@ -19,9 +19,11 @@
 // ncclGetVersion answers 99999 so that a test can tell which library the product loaded.
 // FAKE_RCCL_FAIL_INIT=1 in the environment makes ncclCommInitAll / ncclCommInitRank fail with ncclInvalidUsage (what
 // real RCCL answers when it cannot set up its transports), for the LUMEN_TRANSPORT_AUTO fall-back test.
+// fake_rccl_fail_send_after(n) (a test calls it through ctypes) makes one later ncclSend fail: the poisoned-group path.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -278,7 +280,16 @@ ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
     return ncclSuccess;
 }
 
+// fault injection for the tests (not an nccl* symbol): the n-th ncclSend from now on (0 = the next one) answers
+// ncclInternalError without posting anything -- what lm_group.hip must survive between ncclGroupStart and ncclGroupEnd
+static std::atomic<int> g_fail_send_after{-1};
+void fake_rccl_fail_send_after(int n) { g_fail_send_after.store(n); }
+
 ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    int left = g_fail_send_after.load();
+    while (left >= 0 && !g_fail_send_after.compare_exchange_weak(left, left - 1)) {
+    }
+    if (left == 0) return ncclInternalError;
     return submit({op::SEND, comm, sendbuff, nullptr, count * type_size(datatype), peer, stream});
 }
 

@@ -226,3 +226,38 @@ def test_group_temporaries_return_in_stream_order(small):
 def ctx_roots(P, S):
     from oracle.loader import Oracle
     return Oracle().field_roots(T_REF, S)
+
+
+def test_failed_collective_poisons_the_group(small):
+    """RCCL branch only (the test double injects the fault): an ncclSend that fails BETWEEN ncclGroupStart and ncclGroupEnd
+    makes the call return with the RCCL group closed -- which launches half a collective.  The group must then refuse every
+    later collective (naming the first error) instead of queueing work behind streams that may never drain, and
+    lumen_group_destroy must return without waiting for them.  The contexts stay usable."""
+    if not FAKE:
+        pytest.skip("needs the RCCL test double (tests/test_group_rccl.py runs this file through it)")
+    import ctypes
+    from lumenos_amd.hip import Group, LumenError
+    P, ctx = small
+    world = 2
+    ctxs = ranks_of(ctx, world)
+    g = Group(ctxs, transport=TRANSPORT)
+    n, nl = 2 * world, 2
+    send = [c.upload(random_cts(P, n, nl, seed=700 + r)) for r, c in enumerate(ctxs)]
+    recv = [c.new_set(n, nl) for c in ctxs]
+    g.all_to_all(send, recv)  # a healthy call first
+    g.sync()
+    ctypes.CDLL("librccl.so.1").fake_rccl_fail_send_after(1)  # the second send of the next collective
+    with pytest.raises(LumenError, match="ncclSend|Send"):
+        g.all_to_all(send, recv)
+    for call in (lambda: g.all_to_all(send, recv), g.sync):
+        with pytest.raises(LumenError, match="failed half-posted"):
+            call()
+    g.close()  # returns: no wait for the poisoned streams
+    # the contexts themselves are fine (the double's unmatched sends sit in a mailbox, nothing blocks a stream)
+    g2 = Group(ctxs, transport=TRANSPORT)
+    g2.all_to_all(send, recv)
+    g2.sync()
+    want = send[1].download()[:n // world]
+    assert np.array_equal(recv[0].download()[n // world:], want)
+    g2.close()
+    ctxs[1].close()

@@ -639,8 +639,16 @@ struct set_bin {
             }
         for (auto &p : v) {
             (void)hipSetDevice(p.first->device);
-            if (ok) lm_set_release_async(p.first, p.second);
-            else lumen_set_destroy(g->poisoned ? nullptr : p.first, p.second); // (poisoned: no stream wait; hipFree)
+            if (ok) {
+                lm_set_release_async(p.first, p.second);
+            } else if (!g->poisoned) {
+                lumen_set_destroy(p.first, p.second);
+            } else {
+                // half a collective may sit on the streams for good: neither a stream wait nor hipFree (an implicit device
+                // synchronisation) may be issued -- the block is leaked with the group that has to be torn down anyway
+                p.second->owner = false;
+                lumen_set_destroy(nullptr, p.second);
+            }
         }
     }
 };

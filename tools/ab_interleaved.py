@@ -26,8 +26,10 @@ def smi():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--switch", required=True)
-    ap.add_argument("--values", type=int, nargs="+", required=True)
+    ap.add_argument("--switch", default=None)
+    ap.add_argument("--values", type=int, nargs="+", default=None)
+    ap.add_argument("--combos", nargs="+", default=None,
+                    help="instead of --switch / --values: settings of SEVERAL switches per visit, e.g. LUMEN_KS_BATCH=128,LUMEN_KS_SUB_BATCH=64")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--config", default="16384x4096")
@@ -41,10 +43,17 @@ def main():
         job.step(None)
     ctx.sync()
     rows = []
+    if args.combos:
+        visits = [(c, [kv.split("=") for kv in c.split(",")]) for c in args.combos]
+        args.switch = "combo"
+    else:
+        visits = [(v, [(args.switch, v)]) for v in args.values]
+    args.values = [v for v, _ in visits]
     print(f"# {args.switch} in {args.values}, {args.rounds} rounds x {args.steps} steps, config {args.config}", flush=True)
     for rnd in range(args.rounds):
-        for v in args.values:
-            ctx.set_tuning(args.switch, v)
+        for v, settings in visits:
+            for name, val in settings:
+                ctx.set_tuning(name, int(val))
             job.step(None)  # first step under the new setting builds / fetches its cached lists
             ctx.sync()
             before = smi()
@@ -69,7 +78,7 @@ def main():
         mine = [r for r in rows if r["value"] == v]
         ss = [r["s_per_step"] for r in mine]
         km = {k: sum(r["kernel_ms"].get(k, 0) for r in mine) / len(mine) for k in args.kernels}
-        print(f"# {args.switch}={v:<3d} {sum(ss) / len(ss):.4f} s ({min(ss):.4f} .. {max(ss):.4f}) | " +
+        print(f"# {args.switch}={v!s:<3} {sum(ss) / len(ss):.4f} s ({min(ss):.4f} .. {max(ss):.4f}) | " +
               " ".join(f"{k}={x:.1f}" for k, x in km.items()), flush=True)
     job.close()
 

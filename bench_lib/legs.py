@@ -70,6 +70,9 @@ def cpu_baseline(cfg, budget_s=20.0):
                    f"(1 thread, as the reference), Commit leaves on {n_c}/{S} columns, InnerProduct on {n_i}/{2 * cols} "
                    f"column-vectors; extrapolated linearly; query reuses Commit's level-1 columns"),
         "stages_s": {"encode": round(t_enc, 2), "commit": round(t_commit, 2), "inner_product": round(t_inner, 2)},
+        # the same leg in the driver's earlier lines at 16384x4096 (BENCH_r04 / r05.json): the checker got division-free butterflies in
+        # round 5 and has not been touched since -- what moves from box to box now is the host CPU
+        "previous_rounds_s": {"r04": 1643.0, "r05": 1478.0} if cfg == "16384x4096" else None,
     }
 
 

@@ -84,7 +84,7 @@ struct lm_tuning {
     uint32_t debug = 0;          // LUMEN_DEBUG
     // LUMEN_MODUP_TGROUP / LUMEN_MODDOWN_TGROUP: target limbs one XCD walks back to back in the work lists of the
     // two transform kernels of a key switch (lm_keyswitch.hip); 1 .. 31
-    uint32_t modup_tgroup = 4, moddown_tgroup = 1; // (round 6, limb-major streams: ModDown 1 / 2 / 3 = 1.7691 / 1.7726 / 1.7711 s per step; 2 / 4 / 6 / 12 = 1.8140 / 1.8258 / 1.8246 / 1.8371 on another box)
+    uint32_t modup_tgroup = 3, moddown_tgroup = 1; // (round 6, limb-major streams: extension 3 / 4 = 1.7732 / 1.7760 s per step at 2^14, 0.7868 / 0.7915 at 2^13; ModDown 1 / 2 / 3 = 1.7691 / 1.7726 / 1.7711 s per step; 2 / 4 / 6 / 12 = 1.8140 / 1.8258 / 1.8246 / 1.8371 on another box)
     // LUMEN_KS_PLACEMENT: candidate blocks per key-switch scratch buffer among which the first key switch of a context
     // picks by measurement (lm_keyswitch.hip, select_placement); 0 or 1 = take what hipMalloc returns
     uint32_t ks_placement = 6;

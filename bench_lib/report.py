@@ -129,9 +129,9 @@ def _kernel_table(job, ctx, cfg):
                     "note": "`bound` names the roofline `frac` is priced against (HBM, as SURVEY 8d prescribes for every "
                             "kernel of this path).  `limiter`: neither roof is saturated -- the butterfly-only VALU ceiling is 0.61 "
                             "of the HBM peak (`valu`, calibrated on this chip: 10 multiply-adds per 64-bit Shoup product), the "
-                            "memory side alone (the kernels built without butterflies, profiles/r05_exp_no_butterflies_floor.txt) 0.66 "
-                            "for a plain transform and 0.52 for this kernel with its fused basis extension, and in a wave's life "
-                            "the two run in series more than they overlap (at N = 2^12 .. 2^14, 1 to 4 resident workgroups per CU): 0.35.  The >= 50 % HBM target of "
+                            "memory side alone (the kernels built without butterflies, profiles/r06_exp_no_butterflies_floor.txt) 0.66 "
+                            "for a plain transform and 0.77 for this kernel since its streams are limb-major (0.52 in round 5), and in a wave's life "
+                            "the two run in series more than they overlap (at N = 2^12 .. 2^14, 1 to 4 resident workgroups per CU): 0.37-0.38.  The >= 50 % HBM target of "
                             "north_star is out of reach on both counts; "
                             "DESIGN.md section 6 (and profiles/EXPERIMENTS.md) has the costing"}
     return roofline, stages, executed
